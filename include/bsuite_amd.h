@@ -1,0 +1,208 @@
+/* bsuite_amd.h — C ABI of the MI355X-native batched bsuite environment engine.
+ *
+ * The reference (google-deepmind/bsuite) has no FFI: its boundary is the Python protocol
+ *   env.reset() -> dm_env.TimeStep ; env.step(action:int) -> dm_env.TimeStep
+ * of bsuite/environments/base.py:54-65.  This header is the batched, device-side form of exactly
+ * that protocol: one *lane* per environment instance, struct-of-arrays state columns, and one
+ * entry point per environment family.  Every entry point is the drop-in for the `_step/_reset`
+ * pair it cites.  All pointers are DEVICE pointers (HIP) unless a comment says "host"; nothing
+ * here allocates, synchronises or reads back — calls are asynchronous on the caller's stream and
+ * safe to capture into a hipGraph.
+ *
+ * Return value of every function: 0 = ok, <0 = argument error (see bsx_strerror), >0 = hipError_t.
+ *
+ * Batched TimeStep encoding (dm_env is third-party):
+ *   step_type int8: 0 FIRST, 1 MID, 2 LAST.   FIRST lanes carry reward 0 / discount 1 in the
+ *   batched arrays (the reference returns None/None there; the batch=1 Python view restores None).
+ *
+ * The random-draw stream ("bsx stream v1") is specified in include/bsx_stream.h.
+ */
+#ifndef BSUITE_AMD_H_
+#define BSUITE_AMD_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define BSX_ABI_VERSION 1
+
+#define BSX_FIRST 0
+#define BSX_MID 1
+#define BSX_LAST 2
+
+/* error codes (<0) */
+#define BSX_EINVAL (-1)     /* bad scalar argument (size, n_lanes, ...)            */
+#define BSX_ENULL (-2)      /* a required pointer is NULL                          */
+#define BSX_EALIGN (-3)     /* observation pointer not 16-byte aligned             */
+#define BSX_ERANGE (-4)     /* parameter outside the supported range of the family */
+
+/* Random stream coordinates of one call (include/bsx_stream.h).  The reference gives every env its
+ * own np.random.RandomState (e.g. deep_sea.py:77, catch.py:58); here a lane's draws are a pure
+ * function of (seed, global lane id, step_index, draw#) so shards of any size reproduce the same
+ * trajectories.  `step_base` (device, nullable) is added to `step_index` on the device so that a
+ * captured hipGraph can advance its own call counter. */
+typedef struct {
+  uint64_t seed;            /* Philox key                                                     */
+  uint64_t lane_offset;     /* global id of this shard's lane 0                               */
+  uint64_t step_index;      /* index of this reset()/step() call (monotonic per env batch)    */
+  const uint64_t* step_base; /* device pointer or NULL                                        */
+} bsx_stream_t;
+
+/* Fused reward epilogue = bsuite/utils/wrappers.py RewardNoise (:275-283) / RewardScale (:338-346):
+ * applied to non-FIRST lanes only; bsuite_info accumulators see the un-perturbed reward. */
+#define BSX_WRAP_NONE 0
+#define BSX_WRAP_SCALE 1
+#define BSX_WRAP_NOISE 2
+typedef struct {
+  int32_t kind;
+  int32_t _pad;
+  double param;        /* reward_scale or noise_scale (sigma)                                   */
+  uint64_t seed;       /* key of the wrapper's own stream (RewardNoise has its own RNG, :267)   */
+} bsx_reward_wrap_t;
+
+/* The batched dm_env.TimeStep, written in full on every call (dense contract). */
+typedef struct {
+  float* reward;        /* [B]                                   */
+  float* discount;      /* [B]                                   */
+  int8_t* step_type;    /* [B]                                   */
+  float* observation;   /* [B, obs_numel], 16-byte aligned       */
+} bsx_timestep_t;
+
+/* Per-call control shared by all families. */
+typedef struct {
+  int64_t n_lanes;          /* B of this shard                                                   */
+  int32_t force_reset;      /* 1: this call is env.reset() (base.py:54-57) for every lane        */
+  int32_t _pad;
+  bsx_stream_t stream;
+  bsx_reward_wrap_t wrap;
+  uint64_t* counters;       /* device, nullable: [0] += lanes that emitted LAST, [1] += lanes that
+                               emitted FIRST (wave-ballot popcount, one atomic per wavefront)     */
+  void* hip_stream;         /* hipStream_t                                                       */
+} bsx_call_t;
+
+/* ---- deep_sea : bsuite/environments/deep_sea.py:51-155 ------------------------------------ */
+#define BSX_DEEP_SEA_MAX_SIZE 64
+typedef struct {
+  int32_t size;                 /* N (deep_sea.py:52); 2..64                                      */
+  int32_t deterministic;        /* deep_sea.py:53                                                 */
+  double move_cost;             /* unscaled_move_cost / size, evaluated in f64 on the host (:132) */
+  double inv_size;              /* 1 / size in f64 (:130)                                         */
+  uint32_t mapping_bits[BSX_DEEP_SEA_MAX_SIZE * BSX_DEEP_SEA_MAX_SIZE / 32];
+                                /* action_mapping[row,col] bit (row*N+col), host-built (:77-85)   */
+} bsx_deep_sea_t;
+/* state: int32 [B] = row | col<<8 | bad_episode<<16 | reset_next<<17  (initialise to 1<<17)
+ * info : double [2,B] = total_bad_episodes, denoised_return (deep_sea.py:153-155)
+ * obs  : float [B, N, N] */
+int bsx_deep_sea_step(const bsx_deep_sea_t* cfg /*host*/, const bsx_call_t* call /*host*/,
+                      const int32_t* action, int32_t* state, bsx_timestep_t out, double* info);
+
+/* ---- catch : bsuite/environments/catch.py:45-117 ------------------------------------------ */
+typedef struct {
+  int32_t rows;     /* catch.py:46 (default 10); 2..64 */
+  int32_t columns;  /* catch.py:47 (default 5);  1..64 */
+} bsx_catch_t;
+/* state: int32 [B] = ball_x | ball_y<<8 | paddle_x<<16 | reset_next<<24 (initialise to 1<<24)
+ * info : double [1,B] = total_regret (catch.py:116-117)
+ * obs  : float [B, rows, columns] */
+int bsx_catch_step(const bsx_catch_t* cfg, const bsx_call_t* call, const int32_t* action,
+                   int32_t* state, bsx_timestep_t out, double* info);
+
+/* ---- bandit : bsuite/environments/bandit.py:35-73 ----------------------------------------- */
+#define BSX_BANDIT_MAX_ACTIONS 32
+typedef struct {
+  int32_t num_actions;                       /* bandit.py:35 (default 11) */
+  int32_t _pad;
+  double rewards[BSX_BANDIT_MAX_ACTIONS];    /* permuted linspace, host-built (bandit.py:45-47) */
+} bsx_bandit_t;
+/* state: int32 [B] = reset_next (initialise to 1); info: double [1,B] = total_regret; obs [B,1,1] */
+int bsx_bandit_step(const bsx_bandit_t* cfg, const bsx_call_t* call, const int32_t* action,
+                    int32_t* state, bsx_timestep_t out, double* info);
+
+/* ---- memory_chain : bsuite/environments/memory_chain.py:37-112 ---------------------------- */
+typedef struct {
+  int32_t memory_length;  /* L  (memory_chain.py:39); >=1         */
+  int32_t num_bits;       /* nb (memory_chain.py:40); 1..62       */
+} bsx_memory_chain_t;
+/* state: int32 [B] = timestep | query<<20 | reset_next<<28 (initialise to 1<<28)
+ * context: uint64 [B] (bit i = context[i])
+ * info : double [2,B] = total_perfect, total_regret (memory_chain.py:108-112)
+ * obs  : float [B, 1, nb+2] */
+int bsx_memory_chain_step(const bsx_memory_chain_t* cfg, const bsx_call_t* call,
+                          const int32_t* action, int32_t* state, uint64_t* context,
+                          bsx_timestep_t out, double* info);
+
+/* ---- umbrella_chain : bsuite/environments/umbrella_chain.py:37-114 ------------------------- */
+typedef struct {
+  int32_t chain_length;   /* L  (umbrella_chain.py:38); >=1   */
+  int32_t n_distractor;   /* nd (umbrella_chain.py:39); 0..253 */
+} bsx_umbrella_chain_t;
+/* state: int32 [B] = timestep | need<<20 | has<<21 | reset_next<<22 (initialise to 1<<22)
+ * info : double [1,B] = total_regret; obs float [B, 1, 3+nd] */
+int bsx_umbrella_chain_step(const bsx_umbrella_chain_t* cfg, const bsx_call_t* call,
+                            const int32_t* action, int32_t* state, bsx_timestep_t out,
+                            double* info);
+
+/* ---- discounting_chain : bsuite/environments/discounting_chain.py:40-105 ------------------- */
+typedef struct {
+  int32_t bonus_chain;    /* mapping_seed % 5 (discounting_chain.py:52-56) */
+  int32_t _pad;
+} bsx_discounting_chain_t;
+/* state: int32 [B] = timestep | (context+1)<<8 | reset_next<<12 (initialise to 1<<12)
+ * info : none (discounting_chain.py:104-105 returns {}); obs float [B,1,2] */
+int bsx_discounting_chain_step(const bsx_discounting_chain_t* cfg, const bsx_call_t* call,
+                               const int32_t* action, int32_t* state, bsx_timestep_t out);
+
+/* ---- cartpole (+ swingup) : bsuite/environments/cartpole.py:37-181,
+ *      bsuite/experiments/cartpole_swingup/cartpole_swingup.py:30-155 ------------------------ */
+#define BSX_CARTPOLE_MAX_STEPS 4096
+typedef struct {
+  int32_t swingup;              /* 0: Cartpole, 1: CartpoleSwingup                              */
+  int32_t last_step;            /* first k with f64-accumulated time_elapsed > max_time (host)  */
+  float height_threshold;       /* cartpole.py:84 / swingup:39                                   */
+  float x_threshold;            /* cartpole.py:85 / swingup:43                                   */
+  float theta_dot_threshold;    /* swingup:40                                                    */
+  float x_reward_threshold;     /* swingup:41                                                    */
+  float move_cost;              /* swingup:42                                                    */
+  float timescale;              /* cartpole.py:86                                                */
+  double init_range;            /* cartpole.py:88                                                */
+  double theta_offset;          /* 0 (cartpole) or pi (swingup :87)                              */
+  float mass_cart, mass_pole, length, force_mag, gravity; /* cartpole.py:106-112                 */
+  int32_t _pad;
+  const float* time_frac;       /* device [last_step+1]: f32(time_elapsed_k / max_time), host-
+                                   built from the f64 running sum (cartpole.py:63,176)           */
+} bsx_cartpole_t;
+/* state: float [4,B] = x, x_dot, theta, theta_dot ; steps: int32 [B] = k | reset_next<<30
+ * (initialise to 1<<30); info double [4,B] = raw_return, best_episode, episode_return,
+ * total_upright (cartpole.py:179-181, swingup:152-155); obs float [B,1,6] or [B,1,8] */
+int bsx_cartpole_step(const bsx_cartpole_t* cfg, const bsx_call_t* call, const int32_t* action,
+                      float* state, int32_t* steps, bsx_timestep_t out, double* info);
+
+/* ---- mountain_car : bsuite/environments/mountain_car.py:32-102 ----------------------------- */
+typedef struct {
+  int32_t max_steps;   /* mountain_car.py:36 */
+  int32_t _pad;
+} bsx_mountain_car_t;
+/* state: float [2,B] = position, velocity ; steps: int32 [B] = timestep | reset_next<<30
+ * info double [1,B] = raw_return; obs float [B,1,3] */
+int bsx_mountain_car_step(const bsx_mountain_car_t* cfg, const bsx_call_t* call,
+                          const int32_t* action, float* state, int32_t* steps,
+                          bsx_timestep_t out, double* info);
+
+/* ---- misc ---------------------------------------------------------------------------------- */
+int bsx_abi_version(void);
+const char* bsx_strerror(int code);
+/* Pure-store calibration: writes n_bytes of zeros with the same 16-B cooperative pattern the
+ * observation writers use; the measured rate is the practical ceiling for store-bound families. */
+int bsx_calib_fill(void* dst, int64_t n_bytes, int32_t nontemporal, void* hip_stream);
+/* Fill words [0,n) of the draw stream for (seed, lane, step, stream_id) — used by tests to pin the
+ * device Philox/normal implementation against the oracle's independent one. */
+int bsx_stream_dump(uint64_t seed, uint64_t lane0, int64_t n_lanes, uint64_t step, int32_t stream_id,
+                    int32_t n_words, uint32_t* words /*[n_lanes,n_words]*/,
+                    double* normals /*[n_lanes,n_words/2] or NULL*/, void* hip_stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* BSUITE_AMD_H_ */

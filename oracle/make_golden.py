@@ -1,0 +1,267 @@
+"""ORACLE (test infrastructure): generate tests/golden/*.npz from the UNMODIFIED reference.
+
+Run in the build container (needs /root/reference):   python -m oracle.make_golden
+Each fixture records, for a handful of lanes and T consecutive reset()/step() calls, exactly what
+the reference environment returned when its RandomState was replaced by a replay of the engine's
+draw stream (oracle/replay.py): step_type, reward (f64), discount, observation (f32) and
+bsuite_info() after every call.  The C restatement (oracle/oracle.c) and the HIP kernels are both
+checked against these files; the files are the "outputs of the reference itself run here" pin.
+"""
+import json
+import os
+import sys
+
+import numpy as np
+
+_ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if _ROOT not in sys.path:
+  sys.path.insert(0, _ROOT)
+
+from oracle import replay  # noqa: E402
+
+OUT_DIR = os.path.join(_ROOT, 'tests', 'golden')
+
+BIG_LANE = (1 << 33) + 5        # exercises counter word 1
+BIG_STEP = (1 << 34) + 77       # exercises the step[47:32] counter bits
+
+
+def _make_env(bs, family, kwargs, wrap):
+  from bsuite.environments import (bandit, cartpole, catch, deep_sea, discounting_chain,  # pylint: disable=import-outside-toplevel
+                                   memory_chain, mountain_car, umbrella_chain)
+  from bsuite.experiments.cartpole_swingup import cartpole_swingup  # pylint: disable=import-outside-toplevel
+  from bsuite.utils import wrappers  # pylint: disable=import-outside-toplevel
+  import warnings  # pylint: disable=import-outside-toplevel
+  ctor = dict(
+      deep_sea=deep_sea.DeepSea, catch=catch.Catch, bandit=bandit.SimpleBandit,
+      memory_chain=memory_chain.MemoryChain, umbrella_chain=umbrella_chain.UmbrellaChain,
+      discounting_chain=discounting_chain.DiscountingChain, cartpole=cartpole.Cartpole,
+      cartpole_swingup=cartpole_swingup.CartpoleSwingup, mountain_car=mountain_car.MountainCar,
+  )[family]
+  with warnings.catch_warnings():
+    warnings.simplefilter('ignore')
+    env = ctor(**kwargs)
+  if wrap is not None:
+    kind, param = wrap
+    if kind == 'noise':
+      env = wrappers.RewardNoise(env=env, noise_scale=param, seed=None)
+    else:
+      env = wrappers.RewardScale(env=env, reward_scale=param, seed=None)
+  return env
+
+
+def _raw(env):
+  return env._env if hasattr(env, '_env') else env  # pylint: disable=protected-access
+
+
+def _policy_action(family, raw, policy, rnd, num_actions):
+  """Scripted actions so the fixtures reach the rare branches (goal, timeout, walls)."""
+  if policy == 'random':
+    return int(rnd.integers(num_actions))
+  if family == 'deep_sea':
+    r, c = raw._row, raw._column  # pylint: disable=protected-access
+    if r >= raw._size:  # pylint: disable=protected-access
+      return 0
+    right = int(raw._action_mapping[r, c])  # pylint: disable=protected-access
+    return right if policy == 'optimal' else 1 - right
+  if family == 'catch':
+    if raw._ball_x is None:  # pylint: disable=protected-access
+      return 1
+    d = int(np.sign(raw._ball_x - raw._paddle_x))  # pylint: disable=protected-access
+    return d + 1 if policy == 'optimal' else 0
+  if family in ('cartpole', 'cartpole_swingup'):
+    s = raw._state  # pylint: disable=protected-access
+    th = (s.theta + np.pi) % (2 * np.pi) - np.pi
+    u = th + 0.5 * s.theta_dot + 0.02 * s.x + 0.05 * s.x_dot
+    return 2 if u > 0 else 0
+  if family == 'mountain_car':
+    return 2 if raw._velocity >= 0 else 0  # pylint: disable=protected-access
+  if family == 'memory_chain':
+    return int(raw._context[raw._query])  # pylint: disable=protected-access
+  if family == 'umbrella_chain':
+    return int(raw._need_umbrella)  # pylint: disable=protected-access
+  return int(rnd.integers(num_actions))
+
+
+def _phys_state(family, raw):
+  if family in ('cartpole', 'cartpole_swingup'):
+    s = raw._state  # pylint: disable=protected-access
+    return [float(s.x), float(s.x_dot), float(s.theta), float(s.theta_dot), float(s.time_elapsed)]
+  if family == 'mountain_car':
+    return [float(raw._position), float(raw._velocity), float(raw._timestep)]  # pylint: disable=protected-access
+  return None
+
+
+def run_case(bs, name, family, kwargs, lanes, T, seed=42, step0=0, wrap=None, policies=None,
+             reset_at=(), case_seed=0):
+  lanes = [int(x) for x in lanes]
+  L = len(lanes)
+  policies = list(policies or []) + ['random'] * L
+  envs, rngs = [], []
+  for lane in lanes:
+    env = _make_env(bs, family, kwargs, wrap)
+    rngs.append(replay.attach_replay(env, seed, lane))
+    envs.append(env)
+  num_actions = envs[0].action_spec().num_values
+  obs_shape = tuple(envs[0].observation_spec().shape)
+  info_keys = sorted(envs[0].bsuite_info().keys())
+  rnd = np.random.default_rng(case_seed)
+
+  actions = np.zeros((T, L), np.int32)
+  step_type = np.zeros((T, L), np.int8)
+  reward = np.full((T, L), np.nan, np.float64)
+  discount = np.full((T, L), np.nan, np.float64)
+  obs = np.zeros((T, L) + obs_shape, np.float32)
+  info = np.zeros((T, L, len(info_keys)), np.float64)
+  ps0 = _phys_state(family, _raw(envs[0]))
+  phys = np.zeros((T, L, len(ps0)), np.float64) if ps0 is not None else None
+
+  for t in range(T):
+    for l, env in enumerate(envs):
+      for r in rngs[l]:
+        r.begin_step(step0 + t)
+      a = _policy_action(family, _raw(env), policies[l], rnd, num_actions)
+      actions[t, l] = a
+      ts = env.reset() if t in reset_at else env.step(a)
+      step_type[t, l] = int(ts.step_type)
+      if ts.reward is not None:
+        reward[t, l] = float(ts.reward)
+        discount[t, l] = float(ts.discount)
+      o = np.asarray(ts.observation)
+      assert o.dtype == np.float32 and o.shape == obs_shape, (o.dtype, o.shape)
+      obs[t, l] = o
+      bi = env.bsuite_info()
+      info[t, l] = [float(bi[k]) for k in info_keys]
+      if phys is not None:
+        phys[t, l] = _phys_state(family, _raw(env))
+
+  meta = dict(name=name, family=family, kwargs=kwargs, seed=seed, step0=step0,
+              wrap=list(wrap) if wrap else None, info_keys=info_keys,
+              reset_at=[int(x) for x in reset_at], num_actions=int(num_actions),
+              obs_shape=list(obs_shape), policies=policies[:L])
+  out = dict(meta=np.array(json.dumps(meta)), lanes=np.array(lanes, np.uint64), actions=actions,
+             step_type=step_type, reward=reward, discount=discount, obs=obs, info=info)
+  if phys is not None:
+    out['phys'] = phys
+  os.makedirs(OUT_DIR, exist_ok=True)
+  path = os.path.join(OUT_DIR, name + '.npz')
+  np.savez_compressed(path, **out)
+  n_last = int((step_type == 2).sum())
+  print(f'{name:42s} T={T:5d} L={L} LAST={n_last:4d} {os.path.getsize(path)/1024:7.1f} KiB')
+
+
+LANES = [0, 1, 2, 3, 63, 64, 1000003, BIG_LANE]
+
+
+def cases():
+  c = []
+  add = lambda *a, **k: c.append((a, k))  # noqa: E731
+  ds_pol = ['optimal', 'anti', 'optimal']
+  # deep_sea (deep_sea.py) — sweep sizes are 10..50 even (experiments/deep_sea/sweep.py:20)
+  add('deep_sea_n10', 'deep_sea', dict(size=10, mapping_seed=42), LANES, 60, policies=ds_pol)
+  add('deep_sea_n30', 'deep_sea', dict(size=30, mapping_seed=42), LANES, 100, policies=ds_pol)
+  add('deep_sea_n50', 'deep_sea', dict(size=50, mapping_seed=42), LANES[:4], 110, policies=ds_pol)
+  add('deep_sea_n7_seed3_cost', 'deep_sea', dict(size=7, mapping_seed=3, unscaled_move_cost=0.05),
+      LANES, 50, policies=ds_pol, reset_at=(17, 18, 33))
+  add('deep_sea_n12_stochastic', 'deep_sea', dict(size=12, deterministic=False, mapping_seed=42),
+      LANES, 120, policies=ds_pol, step0=BIG_STEP)
+  add('deep_sea_n30_stochastic', 'deep_sea', dict(size=30, deterministic=False, mapping_seed=42),
+      LANES, 100, policies=ds_pol)
+  add('deep_sea_n8_nomap', 'deep_sea', dict(size=8, randomize_actions=False), LANES[:4], 40,
+      policies=ds_pol)
+  add('deep_sea_n10_noise', 'deep_sea', dict(size=10, mapping_seed=42), LANES[:4], 50,
+      wrap=('noise', 0.3), policies=ds_pol)
+  # catch (catch.py)
+  add('catch_10x5', 'catch', dict(), LANES, 80, policies=['optimal', 'left'])
+  add('catch_6x7', 'catch', dict(rows=6, columns=7), LANES, 60, policies=['optimal', 'left'],
+      reset_at=(13,), step0=BIG_STEP)
+  add('catch_noise', 'catch', dict(), LANES[:4], 60, wrap=('noise', 1.0), policies=['optimal'])
+  add('catch_scale', 'catch', dict(), LANES[:4], 60, wrap=('scale', 0.03), policies=['optimal'])
+  # bandit (bandit.py)
+  add('bandit_seed0', 'bandit', dict(mapping_seed=0), LANES, 40)
+  add('bandit_seed7', 'bandit', dict(mapping_seed=7), LANES, 40, reset_at=(5, 6))
+  add('bandit_noise', 'bandit', dict(mapping_seed=1), LANES[:4], 40, wrap=('noise', 3.0))
+  add('bandit_scale', 'bandit', dict(mapping_seed=2), LANES[:4], 40, wrap=('scale', 1000.0))
+  # memory_chain (memory_chain.py)
+  add('memory_len1', 'memory_chain', dict(memory_length=1, num_bits=1, seed=0), LANES, 30,
+      policies=['optimal'])
+  add('memory_len12', 'memory_chain', dict(memory_length=12, num_bits=1, seed=0), LANES, 90,
+      policies=['optimal'])
+  add('memory_size40', 'memory_chain', dict(memory_length=2, num_bits=40, seed=0), LANES, 40,
+      policies=['optimal'], reset_at=(9,))
+  add('memory_l5_b3', 'memory_chain', dict(memory_length=5, num_bits=3, seed=0), LANES, 60,
+      policies=['optimal'], step0=BIG_STEP)
+  add('memory_len100', 'memory_chain', dict(memory_length=100, num_bits=1, seed=0), LANES[:3], 210,
+      policies=['optimal'])
+  # umbrella_chain (umbrella_chain.py)
+  add('umbrella_l1_d20', 'umbrella_chain', dict(chain_length=1, n_distractor=20), LANES, 30,
+      policies=['optimal'])
+  add('umbrella_l12_d20', 'umbrella_chain', dict(chain_length=12, n_distractor=20), LANES, 80,
+      policies=['optimal'])
+  add('umbrella_l20_d100', 'umbrella_chain', dict(chain_length=20, n_distractor=100), LANES[:4],
+      70, policies=['optimal'], reset_at=(30,))
+  add('umbrella_l20_d1', 'umbrella_chain', dict(chain_length=20, n_distractor=1), LANES[:4], 70,
+      policies=['optimal'])
+  add('umbrella_l5_d0', 'umbrella_chain', dict(chain_length=5, n_distractor=0), LANES[:4], 40,
+      policies=['optimal'], step0=BIG_STEP)
+  add('umbrella_l3_d33', 'umbrella_chain', dict(chain_length=3, n_distractor=33), LANES[:4], 40)
+  # discounting_chain (discounting_chain.py)
+  add('discounting_seed0', 'discounting_chain', dict(mapping_seed=0), LANES, 230)
+  add('discounting_seed3', 'discounting_chain', dict(mapping_seed=3), LANES[:5], 230,
+      reset_at=(57,))
+  add('discounting_seed14', 'discounting_chain', dict(mapping_seed=14), LANES[:5], 120)
+  # cartpole (cartpole.py) — lane 0 runs a PD controller so the 1001-step timeout is reached
+  add('cartpole_default', 'cartpole', dict(), LANES[:6], 1300, policies=['optimal'])
+  add('cartpole_short', 'cartpole', dict(max_time=0.05), LANES[:4], 60, policies=['optimal'],
+      step0=BIG_STEP)
+  add('cartpole_noise', 'cartpole', dict(), LANES[:3], 200, wrap=('noise', 0.1))
+  add('cartpole_scale', 'cartpole', dict(), LANES[:3], 200, wrap=('scale', 30.0))
+  for n in (0, 10, 19):  # experiments/cartpole_swingup/sweep.py:22-23
+    add(f'swingup_{n}', 'cartpole_swingup',
+        dict(height_threshold=n / 20, x_reward_threshold=1 - n / 20), LANES[:4], 1100,
+        policies=['optimal'])
+  # mountain_car (mountain_car.py)
+  add('mountain_car_default', 'mountain_car', dict(), LANES[:4], 1300, policies=['optimal'])
+  add('mountain_car_max20', 'mountain_car', dict(max_steps=20), LANES, 70, policies=['optimal'],
+      reset_at=(11,))
+  add('mountain_car_noise', 'mountain_car', dict(max_steps=50), LANES[:3], 120,
+      wrap=('noise', 10.0))
+  add('mountain_car_scale', 'mountain_car', dict(max_steps=50), LANES[:3], 120,
+      wrap=('scale', 0.001))
+  return c
+
+
+def main():
+  bs = replay.import_reference()
+  for i, (a, k) in enumerate(cases()):
+    run_case(bs, *a, case_seed=1000 + i, **k)
+  # Host-side constant tables of the reference (numpy RandomState on the host): pins for the
+  # engine's host code, which must reproduce them with numpy alone.
+  from bsuite.environments import bandit, deep_sea, discounting_chain  # pylint: disable=import-outside-toplevel
+  import warnings  # pylint: disable=import-outside-toplevel
+  consts = {}
+  with warnings.catch_warnings():
+    warnings.simplefilter('ignore')
+    for n in list(range(10, 51, 2)) + [7]:
+      for ms in (42, 3):
+        consts[f'deep_sea_mapping_{n}_{ms}'] = deep_sea.DeepSea(n, mapping_seed=ms)._action_mapping.astype(np.uint8)  # pylint: disable=protected-access
+    for n in (10, 30):
+      for det in (True, False):
+        consts[f'deep_sea_optimal_return_{n}_{int(det)}'] = np.float64(
+            deep_sea.DeepSea(n, deterministic=det, mapping_seed=42)._optimal_return)  # pylint: disable=protected-access
+  for ms in range(20):
+    consts[f'bandit_rewards_{ms}'] = np.asarray(bandit.SimpleBandit(ms)._rewards, np.float64)  # pylint: disable=protected-access
+    consts[f'discounting_rewards_{ms}'] = np.asarray(
+        discounting_chain.DiscountingChain(ms)._rewards, np.float64)  # pylint: disable=protected-access
+  np.savez_compressed(os.path.join(OUT_DIR, 'host_constants.npz'), **consts)
+  # The sweep tables (bsuite/sweep.py:108-150) as plain JSON, to pin bsuite_amd.sweep.
+  from bsuite import sweep  # pylint: disable=import-outside-toplevel
+  sw = dict(SWEEP=list(sweep.SWEEP), TESTING=list(sweep.TESTING),
+            SETTINGS={k: dict(v) for k, v in sweep.SETTINGS.items()},
+            EPISODES=dict(sweep.EPISODES), TAGS={k: list(v) for k, v in sweep.TAGS.items()})
+  with open(os.path.join(OUT_DIR, 'sweep.json'), 'w') as f:
+    json.dump(sw, f, sort_keys=True)
+  print('host_constants.npz, sweep.json written')
+
+
+if __name__ == '__main__':
+  main()

@@ -1,0 +1,33 @@
+"""Helpers shared by the parity tests: load tests/golden/*.npz (reference outputs)."""
+import glob
+import json
+import os
+
+import numpy as np
+
+GOLDEN_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
+PHYSICS = ('cartpole', 'cartpole_swingup', 'mountain_car')
+
+
+def case_names():
+  names = [os.path.basename(p)[:-4] for p in sorted(glob.glob(os.path.join(GOLDEN_DIR, '*.npz')))]
+  return [n for n in names if n != 'host_constants']
+
+
+def load_case(name):
+  g = np.load(os.path.join(GOLDEN_DIR, name + '.npz'))
+  meta = json.loads(str(g['meta']))
+  return meta, {k: g[k] for k in g.files if k != 'meta'}
+
+
+def contiguous_runs(lanes):
+  """Split a list of global lane ids into (start_index, lane_offset, count) contiguous runs."""
+  runs, i = [], 0
+  lanes = [int(x) for x in lanes]
+  while i < len(lanes):
+    j = i
+    while j + 1 < len(lanes) and lanes[j + 1] == lanes[j] + 1:
+      j += 1
+    runs.append((i, lanes[i], j - i + 1))
+    i = j + 1
+  return runs

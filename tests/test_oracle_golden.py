@@ -1,0 +1,51 @@
+"""CPU: the C restatement (oracle/oracle.c) against outputs of the unmodified reference
+(tests/golden/*.npz, made by oracle/make_golden.py).  Integer/grid families: exact in f64.
+Physics families: the oracle is f64 like the reference, so only libm-vs-numpy sin/cos ulps differ."""
+import numpy as np
+import pytest
+
+from oracle import coracle
+from tests import golden_util as gu
+
+
+@pytest.mark.parametrize('name', gu.case_names())
+def test_oracle_matches_reference(name):
+  meta, g = gu.load_case(name)
+  fam = meta['family']
+  env = coracle.OracleEnv(fam, meta['kwargs'], g['lanes'], seed=meta['seed'],
+                          wrap=tuple(meta['wrap']) if meta['wrap'] else None)
+  assert list(env.obs_shape) == meta['obs_shape']
+  assert env.num_actions == meta['num_actions']
+  T = g['actions'].shape[0]
+  phys = fam in gu.PHYSICS
+  for t in range(T):
+    st, r, d, o = env.call(g['actions'][t], meta['step0'] + t, force_reset=t in meta['reset_at'])
+    np.testing.assert_array_equal(st, g['step_type'][t], err_msg=f't={t}')
+    first = st == 0
+    assert np.isnan(r[first]).all() and np.isnan(g['reward'][t][first]).all()
+    if phys:
+      np.testing.assert_allclose(r[~first], g['reward'][t][~first], rtol=1e-12, atol=1e-12)
+      np.testing.assert_allclose(o, g['obs'][t], rtol=1e-6, atol=1e-7, err_msg=f't={t}')
+    else:
+      np.testing.assert_array_equal(r[~first], g['reward'][t][~first], err_msg=f't={t}')
+      np.testing.assert_array_equal(o, g['obs'][t], err_msg=f't={t}')
+    np.testing.assert_array_equal(d[~first], g['discount'][t][~first])
+    info = env.bsuite_info()
+    for j, k in enumerate(meta['info_keys']):
+      if phys:
+        np.testing.assert_allclose(info[k], g['info'][t, :, j], rtol=1e-12, err_msg=f'{k} t={t}')
+      else:
+        np.testing.assert_array_equal(info[k], g['info'][t, :, j], err_msg=f'{k} t={t}')
+    if phys and fam != 'mountain_car':
+      np.testing.assert_allclose(env.s['state'], g['phys'][t], rtol=1e-9, atol=1e-12)
+
+
+def test_fixtures_reach_rare_branches():
+  """The fixtures must actually contain the branches the kernels special-case."""
+  _, g = gu.load_case('cartpole_default')
+  assert (np.diff(np.where(g['step_type'][:, 0] != 1)[0]) >= 1001).any()   # 1001-step timeout
+  _, g = gu.load_case('deep_sea_n30')
+  assert g['info'][-1, 0, 0] == 3.0 and g['info'][-1, 1, 1] == 3.0          # goal + bad episodes
+  _, g = gu.load_case('mountain_car_default')
+  assert ((g['step_type'] == 2) & (g['obs'][..., 0, 0] >= 0.5)).any()        # goal reached
+  assert ((g['step_type'] == 2) & (g['obs'][..., 0, 2] == 1.0)).any()        # timeout
