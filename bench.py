@@ -1,0 +1,162 @@
+"""bench.py — env-steps/sec of the batched bsuite step() path on MI355X.
+
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--workload deep_sea|catch|...] [--lanes B]
+
+One "step" = one env.step(actions) call on every lane of the batch (auto-reset calls included,
+they are real API calls: bsuite/environments/base.py:61-62).  Default workload is BASELINE.json
+configs[1]: deep_sea size=30 (bsuite_id deep_sea/10), 2^20 lanes per GPU, uniform random actions
+pre-generated on the device (the batched analogue of bsuite/baselines/random/agent.py:35-37).
+Every TimeStep field is materialised in HBM on every step (dense contract).  For N>1 the driver
+launches one process per GPU (torch.distributed, backend nccl = RCCL); lanes shard with no
+data-path collective; the only collective is the end-of-rollout all-gather of per-rank summaries.
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+  sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
+
+# workload -> (bsuite_id, oracle family, oracle kwargs, obs_numel, state bytes in+out per lane)
+WORKLOADS = {
+    'deep_sea': ('deep_sea/10', 'deep_sea', dict(size=30, mapping_seed=42), 900, 8),
+    'catch': ('catch/0', 'catch', dict(), 50, 8),
+    'cartpole': ('cartpole/0', 'cartpole', dict(), 6, 48),
+    'mountain_car': ('mountain_car/0', 'mountain_car', dict(), 3, 24),
+    'bandit': ('bandit/0', 'bandit', dict(mapping_seed=0), 1, 8),
+    'memory_len': ('memory_len/10', 'memory_chain', dict(memory_length=12, num_bits=1), 3, 24),
+    'umbrella_length': ('umbrella_length/10', 'umbrella_chain', dict(chain_length=12, n_distractor=20), 23, 8),
+    'discounting_chain': ('discounting_chain/0', 'discounting_chain', dict(mapping_seed=0), 2, 8),
+}
+
+
+def algorithmic_bytes_per_step(obs_numel, state_bytes):
+  # action i32 + reward f32 + discount f32 + step_type i8 + obs f32 + state in/out
+  return 4 + 4 + 4 + 1 + 4 * obs_numel + state_bytes
+
+
+def cpu_baseline(family, kwargs, num_actions, budget_s=12.0):
+  """The oracle (C restatement of the reference's numpy step) on ONE host core, bounded sample."""
+  import numpy as np
+  from oracle import coracle
+  lanes = 4096
+  env = coracle.OracleEnv(family, kwargs, np.arange(lanes, dtype=np.uint64), seed=42)
+  rng = np.random.default_rng(0)
+  acts = rng.integers(0, num_actions, size=(64, lanes)).astype(np.int32)
+  for t in range(8):
+    env.call(acts[t % 64], t)
+  t0 = time.perf_counter()
+  n = 0
+  while time.perf_counter() - t0 < budget_s:
+    for _ in range(16):
+      env.call(acts[n % 64], 8 + n)
+      n += 1
+  dt = time.perf_counter() - t0
+  return dict(value=lanes * n / dt, unit='env-steps/s', cores=1, kind='port',
+              sample=f'{lanes} lanes x {n} step() calls of {family} {kwargs} through oracle/oracle.c '
+                     f'(gcc -O2, single thread, {dt:.1f} s)')
+
+
+def main():
+  ap = argparse.ArgumentParser()
+  ap.add_argument('--gpus', type=int, default=1)
+  ap.add_argument('--steps', type=int, default=200)
+  ap.add_argument('--warmup', type=int, default=20)
+  ap.add_argument('--workload', default='deep_sea', choices=sorted(WORKLOADS))
+  ap.add_argument('--lanes', type=int, default=1 << 20, help='lanes per GPU')
+  ap.add_argument('--no-cpu-baseline', action='store_true')
+  args = ap.parse_args()
+
+  import torch
+  import torch.distributed as dist
+  import bsuite_amd
+
+  world = int(os.environ.get('WORLD_SIZE', '1'))
+  rank = int(os.environ.get('RANK', '0'))
+  local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+  if world > 1:
+    os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+    dist.init_process_group('nccl')
+  assert args.gpus == world, f'--gpus {args.gpus} but WORLD_SIZE={world}'
+  torch.cuda.set_device(local_rank)
+  dev = torch.device('cuda', local_rank)
+
+  bsuite_id, family, okw, obs_numel, state_bytes = WORKLOADS[args.workload]
+  B = args.lanes
+  env = bsuite_amd.load_from_id(bsuite_id, batch=B, device=dev, seed=42, lane_offset=rank * B,
+                                num_buffers=2)
+  num_actions = env.action_spec().num_values
+  gen = torch.Generator(device=dev)
+  gen.manual_seed(1234 + rank)
+  n_act = 32
+  actions = torch.randint(num_actions, (n_act, B), generator=gen, device=dev, dtype=torch.int32)
+
+  def sync_all():
+    torch.cuda.synchronize(dev)
+    if world > 1:
+      dist.barrier()
+      torch.cuda.synchronize(dev)
+
+  for t in range(args.warmup):
+    env.step(actions[t % n_act])
+  sync_all()
+  ev0 = torch.cuda.Event(enable_timing=True)
+  ev1 = torch.cuda.Event(enable_timing=True)
+  t0 = time.perf_counter()
+  ev0.record()
+  for t in range(args.steps):
+    env.step(actions[t % n_act])
+  ev1.record()
+  torch.cuda.synchronize(dev)
+  wall = time.perf_counter() - t0
+  sync_all()
+  kernel_ms = ev0.elapsed_time(ev1) / args.steps   # HIP events on the launch stream
+
+  # end-of-rollout summary: per-rank [episodes finished, episodes started, sum of info columns]
+  counters = env.episode_counters().to(torch.float64)
+  info_sums = torch.stack([v.sum() for v in env.bsuite_info().values()]) if env.bsuite_info() else counters[:0]
+  summary = torch.cat([counters, info_sums])
+  if world > 1:
+    gathered = torch.empty((world,) + summary.shape, dtype=summary.dtype, device=dev)
+    dist.all_gather_into_tensor(gathered, summary)       # RCCL all-gather over xGMI
+    t_wall = torch.tensor([wall], dtype=torch.float64, device=dev)
+    dist.all_reduce(t_wall, op=dist.ReduceOp.MAX)
+    wall = float(t_wall.item())
+    k_ms = torch.tensor([kernel_ms], dtype=torch.float64, device=dev)
+    dist.all_reduce(k_ms, op=dist.ReduceOp.MAX)
+    kernel_ms = float(k_ms.item())
+    summary = gathered.sum(0)
+
+  if rank == 0:
+    total_steps = B * world * args.steps
+    bytes_per_step = algorithmic_bytes_per_step(obs_numel, state_bytes)
+    achieved = bytes_per_step * B / (kernel_ms * 1e-3) / 1e9
+    line = {
+        'metric': 'env-steps/sec', 'value': total_steps / wall, 'unit': 'env-steps/s',
+        'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+        'ms_per_step': wall / args.steps * 1e3, 'higher_is_better': True, 'scaling': 'weak',
+        'vs_baseline': None, 'dtype': 'f32' if family in ('cartpole', 'mountain_car') else 'int32',
+        'data': 'synthetic',
+        'config': {'workload': f'{bsuite_id} ({family} {okw}) random-action rollout, dense TimeStep',
+                   'lanes_per_gpu': B, 'global_lanes': B * world, 'sharding': f'lanes x{world}',
+                   'bytes_per_env_step': bytes_per_step},
+        'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBPS, 'unit': 'GB/s',
+                     'frac': achieved / HBM_PEAK_GBPS, 'traffic': None,
+                     'kernel_ms': kernel_ms},
+        'episodes_finished': float(summary[0].item()),
+    }
+    if world == 1 and not args.no_cpu_baseline:
+      line['cpu_baseline'] = cpu_baseline(family, okw, num_actions)
+    print(json.dumps(line), flush=True)
+  if world > 1:
+    dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+  main()

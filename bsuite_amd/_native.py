@@ -1,0 +1,148 @@
+"""ctypes binding of the C ABI in include/bsuite_amd.h (libbsuite_amd.so: hand-written HIP, gfx950).
+
+There is no CPU fallback: if the shared library cannot be loaded the import of this module raises,
+and every environment in bsuite_amd.environments depends on it.
+"""
+import ctypes
+import os
+
+import torch  # noqa: F401  (must be imported first: its libamdhip64 is the HIP runtime we bind to)
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+SO_PATH = os.path.join(_HERE, '_lib', 'libbsuite_amd.so')
+
+FIRST, MID, LAST = 0, 1, 2
+WRAP_NONE, WRAP_SCALE, WRAP_NOISE = 0, 1, 2
+DEEP_SEA_MAX_SIZE = 64
+BANDIT_MAX_ACTIONS = 32
+
+
+class NativeLibraryError(RuntimeError):
+  pass
+
+
+def _load():
+  if not os.path.exists(SO_PATH):
+    # Build in-tree on first use when a toolchain is present; otherwise fail loudly.
+    try:
+      from bsuite_amd import build as _build  # pylint: disable=import-outside-toplevel
+      _build.build()
+    except Exception as e:  # pylint: disable=broad-except
+      raise NativeLibraryError(
+          f'{SO_PATH} is missing and could not be built with hipcc ({e}). bsuite_amd has no CPU '
+          'fallback: run `python -m bsuite_amd.build`.') from e
+  try:
+    return ctypes.CDLL(SO_PATH)
+  except OSError as e:
+    raise NativeLibraryError(f'cannot load {SO_PATH}: {e}') from e
+
+
+class Stream(ctypes.Structure):
+  _fields_ = [('seed', ctypes.c_uint64), ('lane_offset', ctypes.c_uint64),
+              ('step_index', ctypes.c_uint64), ('step_base', ctypes.c_void_p)]
+
+
+class RewardWrap(ctypes.Structure):
+  _fields_ = [('kind', ctypes.c_int32), ('_pad', ctypes.c_int32), ('param', ctypes.c_double),
+              ('seed', ctypes.c_uint64)]
+
+
+class TimeStepPtrs(ctypes.Structure):
+  _fields_ = [('reward', ctypes.c_void_p), ('discount', ctypes.c_void_p),
+              ('step_type', ctypes.c_void_p), ('observation', ctypes.c_void_p)]
+
+
+class Call(ctypes.Structure):
+  _fields_ = [('n_lanes', ctypes.c_int64), ('force_reset', ctypes.c_int32), ('_pad', ctypes.c_int32),
+              ('stream', Stream), ('wrap', RewardWrap), ('counters', ctypes.c_void_p),
+              ('hip_stream', ctypes.c_void_p)]
+
+
+class DeepSeaCfg(ctypes.Structure):
+  _fields_ = [('size', ctypes.c_int32), ('deterministic', ctypes.c_int32),
+              ('move_cost', ctypes.c_double), ('inv_size', ctypes.c_double),
+              ('mapping_bits', ctypes.c_uint32 * (DEEP_SEA_MAX_SIZE * DEEP_SEA_MAX_SIZE // 32))]
+
+
+class CatchCfg(ctypes.Structure):
+  _fields_ = [('rows', ctypes.c_int32), ('columns', ctypes.c_int32)]
+
+
+class BanditCfg(ctypes.Structure):
+  _fields_ = [('num_actions', ctypes.c_int32), ('_pad', ctypes.c_int32),
+              ('rewards', ctypes.c_double * BANDIT_MAX_ACTIONS)]
+
+
+class MemoryChainCfg(ctypes.Structure):
+  _fields_ = [('memory_length', ctypes.c_int32), ('num_bits', ctypes.c_int32)]
+
+
+class UmbrellaChainCfg(ctypes.Structure):
+  _fields_ = [('chain_length', ctypes.c_int32), ('n_distractor', ctypes.c_int32)]
+
+
+class DiscountingChainCfg(ctypes.Structure):
+  _fields_ = [('bonus_chain', ctypes.c_int32), ('_pad', ctypes.c_int32)]
+
+
+class CartpoleCfg(ctypes.Structure):
+  _fields_ = [('swingup', ctypes.c_int32), ('last_step', ctypes.c_int32),
+              ('height_threshold', ctypes.c_float), ('x_threshold', ctypes.c_float),
+              ('theta_dot_threshold', ctypes.c_float), ('x_reward_threshold', ctypes.c_float),
+              ('timescale', ctypes.c_float),
+              ('mass_cart', ctypes.c_float), ('mass_pole', ctypes.c_float),
+              ('length', ctypes.c_float), ('force_mag', ctypes.c_float),
+              ('gravity', ctypes.c_float),
+              ('move_cost', ctypes.c_double), ('init_range', ctypes.c_double),
+              ('theta_offset', ctypes.c_double), ('time_frac', ctypes.c_void_p)]
+
+
+class MountainCarCfg(ctypes.Structure):
+  _fields_ = [('max_steps', ctypes.c_int32), ('_pad', ctypes.c_int32)]
+
+
+lib = _load()
+
+_P = ctypes.c_void_p
+_SIGS = {
+    'bsx_abi_version': ([], ctypes.c_int),
+    'bsx_strerror': ([ctypes.c_int], ctypes.c_char_p),
+    'bsx_calib_fill': ([_P, ctypes.c_int64, ctypes.c_int32, _P], ctypes.c_int),
+    'bsx_stream_dump': ([ctypes.c_uint64, ctypes.c_uint64, ctypes.c_int64, ctypes.c_uint64,
+                         ctypes.c_int32, ctypes.c_int32, _P, _P, _P], ctypes.c_int),
+    'bsx_deep_sea_step': ([ctypes.POINTER(DeepSeaCfg), ctypes.POINTER(Call), _P, _P, TimeStepPtrs, _P],
+                          ctypes.c_int),
+    'bsx_catch_step': ([ctypes.POINTER(CatchCfg), ctypes.POINTER(Call), _P, _P, TimeStepPtrs, _P],
+                       ctypes.c_int),
+    'bsx_bandit_step': ([ctypes.POINTER(BanditCfg), ctypes.POINTER(Call), _P, _P, TimeStepPtrs, _P],
+                        ctypes.c_int),
+    'bsx_memory_chain_step': ([ctypes.POINTER(MemoryChainCfg), ctypes.POINTER(Call), _P, _P, _P,
+                               TimeStepPtrs, _P], ctypes.c_int),
+    'bsx_umbrella_chain_step': ([ctypes.POINTER(UmbrellaChainCfg), ctypes.POINTER(Call), _P, _P,
+                                 TimeStepPtrs, _P], ctypes.c_int),
+    'bsx_discounting_chain_step': ([ctypes.POINTER(DiscountingChainCfg), ctypes.POINTER(Call), _P, _P,
+                                    TimeStepPtrs], ctypes.c_int),
+    'bsx_cartpole_step': ([ctypes.POINTER(CartpoleCfg), ctypes.POINTER(Call), _P, _P, _P,
+                           TimeStepPtrs, _P], ctypes.c_int),
+    'bsx_mountain_car_step': ([ctypes.POINTER(MountainCarCfg), ctypes.POINTER(Call), _P, _P, _P,
+                               TimeStepPtrs, _P], ctypes.c_int),
+}
+EXPORTED = tuple(sorted(_SIGS))
+MISSING = []
+for _name, (_args, _res) in _SIGS.items():
+  try:
+    _fn = getattr(lib, _name)
+  except AttributeError:
+    MISSING.append(_name)
+    continue
+  _fn.argtypes = _args
+  _fn.restype = _res
+if MISSING:
+  raise NativeLibraryError(f'{SO_PATH} does not export {MISSING}; rebuild with `python -m bsuite_amd.build --force`')
+if lib.bsx_abi_version() != 1:
+  raise NativeLibraryError('ABI version mismatch between bsuite_amd/_native.py and libbsuite_amd.so')
+
+
+def check(rc, what):
+  if rc != 0:
+    raise RuntimeError(f'{what} failed: {lib.bsx_strerror(rc).decode()} (code {rc})')

@@ -1,0 +1,427 @@
+// small_obs.hip — the families whose observation is a short row (1..256 floats per lane):
+//   bandit            bsuite/environments/bandit.py:54-64
+//   memory_chain      bsuite/environments/memory_chain.py:60-97
+//   umbrella_chain    bsuite/environments/umbrella_chain.py:60-92
+//   discounting_chain bsuite/environments/discounting_chain.py:63-88
+//   cartpole/swingup  bsuite/environments/cartpole.py:37-177,
+//                     bsuite/experiments/cartpole_swingup/cartpole_swingup.py:81-150
+//   mountain_car      bsuite/environments/mountain_car.py:62-90
+// each with the auto-reset of bsuite/environments/base.py:54-65.
+//
+// One kernel shape for all of them: thread t advances lane (block*LPB + t) from coalesced SoA
+// column loads, writes its observation row into an LDS tile [LPB x numel], and after one barrier
+// the whole block streams that tile to HBM as consecutive 16-byte chunks (a lane-per-row global
+// store would be a stride-(4*numel) scatter).  Physics state is f32 on the device (the reference
+// holds Python floats); rewards and the time-fraction observation are formed in f64 exactly as the
+// reference forms them and cast once.
+#include "bsx_host.h"
+
+template <class Env, int LPB>
+__global__ void __launch_bounds__(BSX_BLOCK) small_obs_kernel(const typename Env::args a) {
+  extern __shared__ __attribute__((aligned(16))) float s_obs[];
+  const int numel = a.obs_numel;
+  const int64_t lane0 = (int64_t)blockIdx.x * LPB;
+  const int64_t remaining = a.ctl.n_lanes - lane0;
+  const int lanes_here = remaining < LPB ? (int)remaining : LPB;
+
+  if (LPB == BSX_BLOCK || threadIdx.x < LPB) {
+    const int64_t i = lane0 + threadIdx.x;
+    int type = -1;
+    if ((int)threadIdx.x < lanes_here) {
+      const uint64_t lane = a.ctl.lane_offset + (uint64_t)i;
+      const uint64_t step = bsx_step_of(a.ctl);
+      double reward = 0.0;
+      type = Env::step(a, i, lane, step, s_obs + (int)threadIdx.x * numel, reward);
+      bsx_emit(a.ctl, a.out, i, lane, step, type, reward);
+    }
+    bsx_count_types(a.ctl, type);
+  }
+  __syncthreads();
+
+  // stream the tile: [lanes_here x numel] floats, contiguous in HBM, 16-byte aligned start
+  float* __restrict__ tile = a.out.observation + lane0 * (int64_t)numel;
+  const int total = lanes_here * numel;
+  const int n_chunks = total >> 2;
+  const bsx_f4* s4 = reinterpret_cast<const bsx_f4*>(s_obs);
+  bsx_f4* __restrict__ t4 = reinterpret_cast<bsx_f4*>(tile);
+  for (int ch = threadIdx.x; ch < n_chunks; ch += BSX_BLOCK) t4[ch] = s4[ch];
+  const int f = (n_chunks << 2) + (int)threadIdx.x;
+  if (f < total) tile[f] = s_obs[f];
+}
+
+template <class Env>
+static int launch_small_obs(const typename Env::args& a, int numel, void* hip_stream) {
+  hipStream_t st = (hipStream_t)hip_stream;
+  // Full 256-lane tiles while the LDS tile stays <= 32 KiB (8 resident blocks/CU); 64-lane tiles
+  // for the wide umbrella/memory rows.
+  if (numel <= 32) {
+    const int64_t blocks = (a.ctl.n_lanes + 255) / 256;
+    if (blocks > 0x7FFFFFFF) return BSX_EINVAL;
+    small_obs_kernel<Env, 256><<<dim3((unsigned)blocks), dim3(BSX_BLOCK), (size_t)256 * numel * 4, st>>>(a);
+  } else {
+    const int64_t blocks = (a.ctl.n_lanes + 63) / 64;
+    if (blocks > 0x7FFFFFFF) return BSX_EINVAL;
+    small_obs_kernel<Env, 64><<<dim3((unsigned)blocks), dim3(BSX_BLOCK), (size_t)64 * numel * 4, st>>>(a);
+  }
+  return bsx_launch_status();
+}
+
+// ------------------------------------------------------------------------------ bandit
+struct bandit_env {
+  struct args {
+    bsx_ctl ctl; const int32_t* action; int32_t* state; bsx_timestep_t out; double* info;
+    int32_t obs_numel; int32_t num_actions; double rewards[BSX_BANDIT_MAX_ACTIONS];
+  };
+  __device__ static int step(const args& a, int64_t i, uint64_t, uint64_t, float* o, double& reward) {
+    BSX_NO_CONTRACT
+    o[0] = 1.0f;                                                // bandit.py:54 (ones)
+    if (a.ctl.force_reset || a.state[i]) { a.state[i] = 0; return BSX_FIRST; }
+    int act = a.action[i];
+    act = act < 0 ? 0 : (act >= a.num_actions ? a.num_actions - 1 : act);   // never read OOB
+    reward = a.rewards[act];                                    // :61
+    a.info[i] += 1.0 - reward;                                  // :62
+    a.state[i] = 1;
+    return BSX_LAST;                                            // :64
+  }
+};
+
+extern "C" int bsx_bandit_step(const bsx_bandit_t* cfg, const bsx_call_t* call, const int32_t* action,
+                               int32_t* state, bsx_timestep_t out, double* info) {
+  if (cfg == nullptr) return BSX_ENULL;
+  int rc = bsx_check_call(call, action, out);
+  if (rc != 0) return rc;
+  if (cfg->num_actions < 1 || cfg->num_actions > BSX_BANDIT_MAX_ACTIONS) return BSX_ERANGE;
+  if (call->n_lanes == 0) return 0;
+  if (state == nullptr || info == nullptr) return BSX_ENULL;
+  bandit_env::args a;
+  a.ctl = bsx_make_ctl(call); a.action = action; a.state = state; a.out = out; a.info = info;
+  a.obs_numel = 1; a.num_actions = cfg->num_actions;
+  for (int k = 0; k < BSX_BANDIT_MAX_ACTIONS; ++k) a.rewards[k] = cfg->rewards[k];
+  return launch_small_obs<bandit_env>(a, 1, call->hip_stream);
+}
+
+// ------------------------------------------------------------------------------ memory_chain
+#define MC_RESET_BIT (1 << 28)
+struct memory_chain_env {
+  struct args {
+    bsx_ctl ctl; const int32_t* action; int32_t* state; uint64_t* context; bsx_timestep_t out;
+    double* info; int32_t obs_numel; int32_t L; int32_t nb;
+  };
+  __device__ static void observe(const args& a, float* o, int t, int query, uint64_t ctx) {
+    BSX_NO_CONTRACT
+    o[0] = (float)(1.0 - (double)t / (double)a.L);              // memory_chain.py:64
+    o[1] = (t == a.L - 1) ? (float)query : 0.0f;                // :66-67
+    for (int b = 0; b < a.nb; ++b)                              // :69-70
+      o[2 + b] = (t == 0) ? (float)(2 * (int)((ctx >> b) & 1ull) - 1) : 0.0f;
+  }
+  __device__ static int step(const args& a, int64_t i, uint64_t lane, uint64_t step, float* o, double& reward) {
+    int32_t st = a.state[i];
+    int t = st & 0xFFFFF, query = (st >> 20) & 0xFF;
+    uint64_t ctx = a.context[i];
+    if (a.ctl.force_reset || (st & MC_RESET_BIT)) {             // :91-97
+      bsx_draws d;
+      bsx_draws_init(&d, a.ctl.seed, lane, step, BSX_STREAM_ENV);
+      uint64_t w0 = bsx_word(&d);                               // BernVec(nb)
+      uint64_t w1 = a.nb > 32 ? bsx_word(&d) : 0ull;
+      ctx = (w0 | (w1 << 32)) & (a.nb >= 64 ? ~0ull : ((1ull << a.nb) - 1ull));
+      query = (int)bsx_randint(&d, (uint32_t)a.nb);
+      t = 0;
+      a.context[i] = ctx;
+      a.state[i] = t | (query << 20);
+      observe(a, o, t, query, ctx);
+      return BSX_FIRST;
+    }
+    observe(a, o, t, query, ctx);                               // :74 — before the increment
+    t += 1;                                                     // :75
+    if (t - 1 < a.L) { a.state[i] = t | (query << 20); return BSX_MID; }   // :77-79
+    if (a.action[i] == (int)((ctx >> query) & 1ull)) { reward = 1.0; a.info[i] += 1.0; }   // :83-85
+    else { reward = -1.0; a.info[a.ctl.n_lanes + i] += 2.0; }   // :86-88
+    a.state[i] = t | (query << 20) | MC_RESET_BIT;
+    return BSX_LAST;
+  }
+};
+
+extern "C" int bsx_memory_chain_step(const bsx_memory_chain_t* cfg, const bsx_call_t* call,
+                                     const int32_t* action, int32_t* state, uint64_t* context,
+                                     bsx_timestep_t out, double* info) {
+  if (cfg == nullptr) return BSX_ENULL;
+  int rc = bsx_check_call(call, action, out);
+  if (rc != 0) return rc;
+  if (cfg->memory_length < 1 || cfg->memory_length > 1000000 || cfg->num_bits < 1 || cfg->num_bits > 62)
+    return BSX_ERANGE;
+  if (call->n_lanes == 0) return 0;
+  if (state == nullptr || context == nullptr || info == nullptr) return BSX_ENULL;
+  memory_chain_env::args a;
+  a.ctl = bsx_make_ctl(call); a.action = action; a.state = state; a.context = context; a.out = out;
+  a.info = info; a.obs_numel = cfg->num_bits + 2; a.L = cfg->memory_length; a.nb = cfg->num_bits;
+  return launch_small_obs<memory_chain_env>(a, a.obs_numel, call->hip_stream);
+}
+
+// ------------------------------------------------------------------------------ umbrella_chain
+#define UC_RESET_BIT (1 << 22)
+struct umbrella_chain_env {
+  struct args {
+    bsx_ctl ctl; const int32_t* action; int32_t* state; bsx_timestep_t out; double* info;
+    int32_t obs_numel; int32_t L; int32_t nd;
+  };
+  __device__ static void observe(const args& a, float* o, int t, int need, int has, bsx_draws* d) {
+    BSX_NO_CONTRACT
+    o[0] = (float)need;                                         // umbrella_chain.py:62
+    o[1] = (float)has;                                          // :63
+    o[2] = (float)(1.0 - (double)t / (double)a.L);              // :64
+    uint32_t w = 0;
+    for (int b = 0; b < a.nd; ++b) {                            // :65 BernVec(nd)
+      if ((b & 31) == 0) w = bsx_word(d);
+      o[3 + b] = (float)((w >> (b & 31)) & 1u);
+    }
+  }
+  __device__ static int step(const args& a, int64_t i, uint64_t lane, uint64_t step, float* o, double& reward) {
+    BSX_NO_CONTRACT
+    int32_t st = a.state[i];
+    int t = st & 0xFFFFF, need = (st >> 20) & 1, has = (st >> 21) & 1;
+    bsx_draws d;
+    bsx_draws_init(&d, a.ctl.seed, lane, step, BSX_STREAM_ENV);
+    if (a.ctl.force_reset || (st & UC_RESET_BIT)) {             // :87-92
+      t = 0;
+      need = (int)bsx_bern(&d);
+      has = (int)bsx_bern(&d);
+      observe(a, o, t, need, has, &d);
+      a.state[i] = t | (need << 20) | (has << 21);
+      return BSX_FIRST;
+    }
+    t += 1;                                                     // :69
+    if (t == 1) has = (a.action[i] == 1);                       // :71-72 (action_spec: {0,1})
+    int type;
+    if (t == a.L) {                                             // :74-81
+      if (has == need) reward = 1.0;
+      else { reward = -1.0; a.info[i] += 2.0; }
+      observe(a, o, t, need, has, &d);
+      type = BSX_LAST;
+    } else {                                                    // :83-85
+      reward = 2.0 * (double)bsx_bern(&d) - 1.0;
+      observe(a, o, t, need, has, &d);
+      type = BSX_MID;
+    }
+    a.state[i] = t | (need << 20) | (has << 21) | (type == BSX_LAST ? UC_RESET_BIT : 0);
+    return type;
+  }
+};
+
+extern "C" int bsx_umbrella_chain_step(const bsx_umbrella_chain_t* cfg, const bsx_call_t* call,
+                                       const int32_t* action, int32_t* state, bsx_timestep_t out,
+                                       double* info) {
+  if (cfg == nullptr) return BSX_ENULL;
+  int rc = bsx_check_call(call, action, out);
+  if (rc != 0) return rc;
+  if (cfg->chain_length < 1 || cfg->chain_length > 1000000 || cfg->n_distractor < 0 || cfg->n_distractor > 253)
+    return BSX_ERANGE;
+  if (call->n_lanes == 0) return 0;
+  if (state == nullptr || info == nullptr) return BSX_ENULL;
+  umbrella_chain_env::args a;
+  a.ctl = bsx_make_ctl(call); a.action = action; a.state = state; a.out = out; a.info = info;
+  a.obs_numel = 3 + cfg->n_distractor; a.L = cfg->chain_length; a.nd = cfg->n_distractor;
+  return launch_small_obs<umbrella_chain_env>(a, a.obs_numel, call->hip_stream);
+}
+
+// ------------------------------------------------------------------------------ discounting_chain
+#define DC_RESET_BIT (1 << 12)
+struct discounting_chain_env {
+  struct args {
+    bsx_ctl ctl; const int32_t* action; int32_t* state; bsx_timestep_t out;
+    int32_t obs_numel; int32_t bonus;
+  };
+  __device__ static int step(const args& a, int64_t i, uint64_t, uint64_t, float* o, double& reward) {
+    BSX_NO_CONTRACT
+    int32_t st = a.state[i];
+    int t = st & 0xFF, ctx = ((st >> 8) & 0xF) - 1;
+    if (a.ctl.force_reset || (st & DC_RESET_BIT)) {             // discounting_chain.py:69-73
+      t = 0; ctx = -1;
+      o[0] = -1.0f; o[1] = 0.0f;
+      a.state[i] = 0;
+      return BSX_FIRST;
+    }
+    if (t == 0) {                                               // :76-77
+      ctx = a.action[i];
+      ctx = ctx < 0 ? 0 : (ctx > 4 ? 4 : ctx);                  // action_spec: 5 values; never OOB
+    }
+    t += 1;
+    const int when = ctx == 0 ? 1 : ctx == 1 ? 3 : ctx == 2 ? 10 : ctx == 3 ? 30 : 100;   // :49
+    if (t == when) reward = (ctx == a.bonus) ? 1.0 + 0.1 : 1.0;                            // :57-58,80-83
+    o[0] = (float)ctx;                                          // :65
+    o[1] = (float)((double)t / 100.0);                          // :66
+    const int type = (t == 100) ? BSX_LAST : BSX_MID;           // :86-88
+    a.state[i] = t | ((ctx + 1) << 8) | (type == BSX_LAST ? DC_RESET_BIT : 0);
+    return type;
+  }
+};
+
+extern "C" int bsx_discounting_chain_step(const bsx_discounting_chain_t* cfg, const bsx_call_t* call,
+                                          const int32_t* action, int32_t* state, bsx_timestep_t out) {
+  if (cfg == nullptr) return BSX_ENULL;
+  int rc = bsx_check_call(call, action, out);
+  if (rc != 0) return rc;
+  if (cfg->bonus_chain < 0 || cfg->bonus_chain > 4) return BSX_ERANGE;
+  if (call->n_lanes == 0) return 0;
+  if (state == nullptr) return BSX_ENULL;
+  discounting_chain_env::args a;
+  a.ctl = bsx_make_ctl(call); a.action = action; a.state = state; a.out = out;
+  a.obs_numel = 2; a.bonus = cfg->bonus_chain;
+  return launch_small_obs<discounting_chain_env>(a, 2, call->hip_stream);
+}
+
+// ------------------------------------------------------------------------------ cartpole / swingup
+#define CP_RESET_BIT (1 << 30)
+struct cartpole_env {
+  struct args {
+    bsx_ctl ctl; const int32_t* action; float* state; int32_t* steps; bsx_timestep_t out;
+    double* info; int32_t obs_numel; bsx_cartpole_t cfg;
+  };
+  __device__ static int step(const args& a, int64_t i, uint64_t lane, uint64_t step, float* o, double& reward) {
+    BSX_NO_CONTRACT
+    const int64_t B = a.ctl.n_lanes;
+    const bsx_cartpole_t& g = a.cfg;
+    const int32_t sk = a.steps[i];
+    int k = sk & 0x3FFFFFFF;
+    float x, xd, th, thd;
+    int type;
+    if (a.ctl.force_reset || (sk & CP_RESET_BIT)) {             // cartpole.py:118-128 / swingup:81-91
+      bsx_draws d;
+      bsx_draws_init(&d, a.ctl.seed, lane, step, BSX_STREAM_ENV);
+      const double lo = -g.init_range, hi = g.init_range;
+      x = (float)(lo + (hi - lo) * bsx_uniform(&d));
+      xd = (float)(lo + (hi - lo) * bsx_uniform(&d));
+      th = (float)(g.theta_offset + (lo + (hi - lo) * bsx_uniform(&d)));
+      thd = (float)(lo + (hi - lo) * bsx_uniform(&d));
+      k = 0;
+      a.info[2 * B + i] = 0.0;                                  // _episode_return = 0
+      type = BSX_FIRST;
+    } else {
+      x = a.state[i]; xd = a.state[B + i]; th = a.state[2 * B + i]; thd = a.state[3 * B + i];
+      const int act = a.action[i];
+      // step_cartpole, cartpole.py:37-65, in f32
+      const float force = (float)(act - 1) * g.force_mag;
+      const float co = cosf(th), si = sinf(th);
+      const float pl = g.mass_pole * g.length;
+      const float m_total = g.mass_cart + g.mass_pole;
+      const float temp = (force + pl * (thd * thd) * si) / m_total;
+      const float theta_acc = (g.gravity * si - co * temp) / (g.length * (4.0f / 3.0f - g.mass_pole * (co * co) / m_total));
+      const float x_acc = temp - pl * theta_acc * co / m_total;
+      const float nx = x + g.timescale * xd;
+      const float nxd = xd + g.timescale * x_acc;
+      // np.remainder(theta + dt*theta_dot, 2*pi): range-reduce in f64 so the period is not the f32 2*pi
+      double ang = fmod((double)th + (double)g.timescale * (double)thd, 6.283185307179586);
+      if (ang < 0.0) ang += 6.283185307179586;
+      const float nthd = thd + g.timescale * theta_acc;
+      x = nx; xd = nxd; th = (float)ang; thd = nthd;
+      k += 1;                                                   // time_elapsed += timescale (:63)
+      const bool timeout = k >= g.last_step;                    // time_elapsed > max_time
+      bool end;
+      double r;
+      if (!g.swingup) {                                         // cartpole.py:142-153
+        const bool ok = (cosf(th) > g.height_threshold) && (fabsf(x) < g.x_threshold);
+        r = ok ? 1.0 : 0.0;
+        end = timeout || !ok;
+      } else {                                                  // swingup:104-123
+        const bool up = (cosf(th) > g.height_threshold) && (fabsf(thd) < g.theta_dot_threshold) &&
+                        (fabsf(x) < g.x_reward_threshold);
+        r = -1.0 * fabs((double)(act - 1)) * g.move_cost;
+        if (up) { r += 1.0; a.info[3 * B + i] += 1.0; }
+        end = timeout || (fabsf(x) > g.x_threshold);
+      }
+      reward = r;
+      a.info[i] += r;                                           // _raw_return
+      const double ep = a.info[2 * B + i] + r;                  // _episode_return
+      a.info[2 * B + i] = ep;
+      if (end) {
+        const double best = a.info[B + i];
+        a.info[B + i] = ep > best ? ep : best;                  // max(episode_return, best_episode)
+        type = BSX_LAST;
+      } else {
+        type = BSX_MID;
+      }
+    }
+    a.state[i] = x; a.state[B + i] = xd; a.state[2 * B + i] = th; a.state[3 * B + i] = thd;
+    a.steps[i] = k | (type == BSX_LAST ? CP_RESET_BIT : 0);
+    o[0] = x / g.x_threshold;                                   // cartpole.py:171-176
+    o[1] = xd / g.x_threshold;
+    o[2] = sinf(th);
+    o[3] = cosf(th);
+    o[4] = thd;
+    o[5] = g.time_frac[k < g.last_step ? k : g.last_step];
+    if (g.swingup) {                                            // swingup:147-149
+      o[6] = (fabsf(x) < g.x_reward_threshold) ? 1.0f : -1.0f;
+      o[7] = (fabsf(thd) < g.theta_dot_threshold) ? 1.0f : -1.0f;
+    }
+    return type;
+  }
+};
+
+extern "C" int bsx_cartpole_step(const bsx_cartpole_t* cfg, const bsx_call_t* call, const int32_t* action,
+                                 float* state, int32_t* steps, bsx_timestep_t out, double* info) {
+  if (cfg == nullptr) return BSX_ENULL;
+  int rc = bsx_check_call(call, action, out);
+  if (rc != 0) return rc;
+  if (cfg->last_step < 1 || cfg->last_step >= (1 << 30)) return BSX_ERANGE;
+  if (call->n_lanes == 0) return 0;
+  if (state == nullptr || steps == nullptr || info == nullptr || cfg->time_frac == nullptr) return BSX_ENULL;
+  cartpole_env::args a;
+  a.ctl = bsx_make_ctl(call); a.action = action; a.state = state; a.steps = steps; a.out = out;
+  a.info = info; a.obs_numel = cfg->swingup ? 8 : 6; a.cfg = *cfg;
+  return launch_small_obs<cartpole_env>(a, a.obs_numel, call->hip_stream);
+}
+
+// ------------------------------------------------------------------------------ mountain_car
+struct mountain_car_env {
+  struct args {
+    bsx_ctl ctl; const int32_t* action; float* state; int32_t* steps; bsx_timestep_t out;
+    double* info; int32_t obs_numel; int32_t max_steps;
+  };
+  __device__ static int step(const args& a, int64_t i, uint64_t lane, uint64_t step, float* o, double& reward) {
+    BSX_NO_CONTRACT
+    const int64_t B = a.ctl.n_lanes;
+    const int32_t sk = a.steps[i];
+    int t = sk & 0x3FFFFFFF;
+    float pos, vel;
+    int type;
+    if (a.ctl.force_reset || (sk & CP_RESET_BIT)) {             // mountain_car.py:66-71
+      bsx_draws d;
+      bsx_draws_init(&d, a.ctl.seed, lane, step, BSX_STREAM_ENV);
+      t = 0;
+      pos = (float)(-0.6 + (-0.4 - -0.6) * bsx_uniform(&d));
+      vel = 0.0f;
+      type = BSX_FIRST;
+    } else {
+      pos = a.state[i]; vel = a.state[B + i];
+      t += 1;                                                   // :74
+      reward = -1.0;
+      a.info[i] += reward;                                      // :76
+      vel += (float)(a.action[i] - 1) * 0.001f + cosf(3.0f * pos) * -0.0025f;   // :79-80
+      vel = fminf(fmaxf(vel, -0.07f), 0.07f);                   // :81
+      pos += vel;                                               // :82
+      pos = fminf(fmaxf(pos, -1.2f), 0.6f);                     // :83
+      if (pos == -1.2f) vel = fminf(fmaxf(vel, 0.0f), 0.07f);   // :84-85
+      type = (pos >= 0.5f || t >= a.max_steps) ? BSX_LAST : BSX_MID;   // :88-90
+    }
+    a.state[i] = pos; a.state[B + i] = vel;
+    a.steps[i] = t | (type == BSX_LAST ? CP_RESET_BIT : 0);
+    o[0] = pos;                                                 // :62-64
+    o[1] = vel;
+    o[2] = (float)((double)t / (double)a.max_steps);
+    return type;
+  }
+};
+
+extern "C" int bsx_mountain_car_step(const bsx_mountain_car_t* cfg, const bsx_call_t* call,
+                                     const int32_t* action, float* state, int32_t* steps,
+                                     bsx_timestep_t out, double* info) {
+  if (cfg == nullptr) return BSX_ENULL;
+  int rc = bsx_check_call(call, action, out);
+  if (rc != 0) return rc;
+  if (cfg->max_steps < 1 || cfg->max_steps >= (1 << 30)) return BSX_ERANGE;
+  if (call->n_lanes == 0) return 0;
+  if (state == nullptr || steps == nullptr || info == nullptr) return BSX_ENULL;
+  mountain_car_env::args a;
+  a.ctl = bsx_make_ctl(call); a.action = action; a.state = state; a.steps = steps; a.out = out;
+  a.info = info; a.obs_numel = 3; a.max_steps = cfg->max_steps;
+  return launch_small_obs<mountain_car_env>(a, 3, call->hip_stream);
+}

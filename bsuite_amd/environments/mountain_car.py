@@ -1,0 +1,33 @@
+"""Batched MountainCar (counterpart of bsuite/environments/mountain_car.py; csrc/small_obs.hip)."""
+import ctypes
+from typing import Optional
+
+import torch
+
+from bsuite_amd import _native
+from bsuite_amd.environments import base
+
+NUM_EPISODES = 1000  # bsuite/experiments/mountain_car/sweep.py:19
+
+
+class MountainCar(base.Environment):
+  """Mountain Car, an underpowered car must power up a hill (mountain_car.py:29-57)."""
+
+  _info_keys = ('raw_return',)
+
+  def __init__(self, max_steps: int = 1000, seed: Optional[int] = None, **engine_kwargs):
+    if max_steps < 1:
+      raise ValueError('max_steps must be >= 1')
+    super().__init__(obs_shape=(1, 3), num_actions=3, seed=seed, **engine_kwargs)
+    self._max_steps = max_steps
+    self._cfg = _native.MountainCarCfg(max_steps, 0)
+    self.bsuite_num_episodes = NUM_EPISODES
+
+  def _state_tensors(self):
+    return dict(state=torch.zeros((2, self._batch), dtype=torch.float32, device=self._device),
+                steps=torch.full((self._batch,), 1 << 30, dtype=torch.int32, device=self._device))
+
+  def _launch(self, call, action_ptr, out):
+    return _native.lib.bsx_mountain_car_step(
+        ctypes.byref(self._cfg), ctypes.byref(call), action_ptr, self._state['state'].data_ptr(),
+        self._state['steps'].data_ptr(), out, self._info.data_ptr())

@@ -156,7 +156,6 @@ int bsx_discounting_chain_step(const bsx_discounting_chain_t* cfg, const bsx_cal
 
 /* ---- cartpole (+ swingup) : bsuite/environments/cartpole.py:37-181,
  *      bsuite/experiments/cartpole_swingup/cartpole_swingup.py:30-155 ------------------------ */
-#define BSX_CARTPOLE_MAX_STEPS 4096
 typedef struct {
   int32_t swingup;              /* 0: Cartpole, 1: CartpoleSwingup                              */
   int32_t last_step;            /* first k with f64-accumulated time_elapsed > max_time (host)  */
@@ -164,12 +163,11 @@ typedef struct {
   float x_threshold;            /* cartpole.py:85 / swingup:43                                   */
   float theta_dot_threshold;    /* swingup:40                                                    */
   float x_reward_threshold;     /* swingup:41                                                    */
-  float move_cost;              /* swingup:42                                                    */
   float timescale;              /* cartpole.py:86                                                */
+  float mass_cart, mass_pole, length, force_mag, gravity; /* cartpole.py:106-112                 */
+  double move_cost;             /* swingup:42 (f64: the reward is formed in f64 like the ref)    */
   double init_range;            /* cartpole.py:88                                                */
   double theta_offset;          /* 0 (cartpole) or pi (swingup :87)                              */
-  float mass_cart, mass_pole, length, force_mag, gravity; /* cartpole.py:106-112                 */
-  int32_t _pad;
   const float* time_frac;       /* device [last_step+1]: f32(time_elapsed_k / max_time), host-
                                    built from the f64 running sum (cartpole.py:63,176)           */
 } bsx_cartpole_t;

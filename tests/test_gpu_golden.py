@@ -1,0 +1,62 @@
+"""GPU: the HIP kernels, through the C ABI, against outputs of the unmodified reference
+(tests/golden/*.npz).  Integer / grid families: bit-exact (f32 reward == np.float32(reference f64
+reward), observation bitwise).  Physics families: per-step teacher-forced, |a-b| <= 1e-6*max(1,|b|)
+(BASELINE.json north_star tolerance)."""
+import numpy as np
+import pytest
+import torch
+
+from tests import engine_util as eu
+from tests import golden_util as gu
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-6
+
+
+def _force_physics_state(env, fam, phys_prev, idx):
+  r = eu.raw(env)
+  if fam == 'mountain_car':
+    st = np.stack([phys_prev[idx, 0], phys_prev[idx, 1]]).astype(np.float32)
+  else:
+    st = phys_prev[idx, :4].T.astype(np.float32)
+  r._state['state'].copy_(torch.from_numpy(np.ascontiguousarray(st)).to(r.device))
+
+
+@pytest.mark.parametrize('name', gu.case_names())
+def test_engine_matches_reference(name):
+  meta, g = gu.load_case(name)
+  fam = meta['family']
+  phys = fam in gu.PHYSICS
+  wrap = tuple(meta['wrap']) if meta['wrap'] else None
+  T = g['actions'].shape[0]
+  for (i0, lane0, n) in gu.contiguous_runs(g['lanes']):
+    idx = slice(i0, i0 + n)
+    env = eu.make_env(fam, meta['kwargs'], batch=n, lane_offset=lane0, seed=meta['seed'], wrap=wrap)
+    eu.raw(env)._step_index = meta['step0']
+    for t in range(T):
+      if phys and t > 0:
+        _force_physics_state(env, fam, g['phys'][t - 1], idx)
+      if t in meta['reset_at']:
+        ts = env.reset()
+      else:
+        ts = env.step(torch.from_numpy(g['actions'][t, idx]).to('cuda'))
+      st, r, d, o = eu.to_np(ts)
+      gst, gr, gd, go = g['step_type'][t, idx], g['reward'][t, idx], g['discount'][t, idx], g['obs'][t, idx]
+      np.testing.assert_array_equal(st, gst, err_msg=f'{name} step_type t={t}')
+      first = gst == 0
+      assert (r[first] == 0).all() and (d[first] == 1).all()
+      np.testing.assert_array_equal(d[~first], gd[~first].astype(np.float32))
+      if phys:
+        np.testing.assert_allclose(o, go, rtol=TOL, atol=TOL, err_msg=f'{name} obs t={t}')
+        np.testing.assert_allclose(r[~first], gr[~first], rtol=TOL, atol=TOL)
+      else:
+        np.testing.assert_array_equal(eu.f32_bits(r[~first]), eu.f32_bits(gr[~first].astype(np.float32)),
+                                      err_msg=f'{name} reward t={t}')
+        np.testing.assert_array_equal(eu.f32_bits(o), eu.f32_bits(go), err_msg=f'{name} obs t={t}')
+      info = env.bsuite_info()
+      for j, k in enumerate(meta['info_keys']):
+        got = info[k].cpu().numpy()
+        if phys:
+          np.testing.assert_allclose(got, g['info'][t, idx, j], rtol=1e-9, atol=1e-9, err_msg=f'{k} t={t}')
+        else:
+          np.testing.assert_array_equal(got, g['info'][t, idx, j], err_msg=f'{name} {k} t={t}')
