@@ -71,6 +71,9 @@ def main():
   ap.add_argument('--workload', default='deep_sea', choices=sorted(WORKLOADS))
   ap.add_argument('--lanes', type=int, default=1 << 20, help='lanes per GPU')
   ap.add_argument('--no-cpu-baseline', action='store_true')
+  ap.add_argument('--graph', type=int, default=0,
+                  help='capture this many consecutive step() launches into one HIP graph and replay it '
+                       '(for the tiny families whose per-step kernel is shorter than a host launch)')
   args = ap.parse_args()
 
   import torch
@@ -90,11 +93,11 @@ def main():
   bsuite_id, family, okw, obs_numel, state_bytes = WORKLOADS[args.workload]
   B = args.lanes
   env = bsuite_amd.load_from_id(bsuite_id, batch=B, device=dev, seed=42, lane_offset=rank * B,
-                                num_buffers=2)
+                                num_buffers=2, device_step_counter=bool(args.graph))
   num_actions = env.action_spec().num_values
   gen = torch.Generator(device=dev)
   gen.manual_seed(1234 + rank)
-  n_act = 32
+  n_act = max(32, args.graph)
   actions = torch.randint(num_actions, (n_act, B), generator=gen, device=dev, dtype=torch.int32)
 
   def sync_all():
@@ -103,20 +106,55 @@ def main():
       dist.barrier()
       torch.cuda.synchronize(dev)
 
-  for t in range(args.warmup):
-    env.step(actions[t % n_act])
+  if args.graph:
+    assert args.steps % args.graph == 0 and args.warmup % args.graph == 0, '--steps/--warmup must be multiples of --graph'
+    env.step(actions[0])                       # allocate outside capture
+    side = torch.cuda.Stream(device=dev)
+    side.wait_stream(torch.cuda.current_stream(dev))
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.stream(side):
+      with torch.cuda.graph(graph, stream=side):
+        for t in range(args.graph):
+          env.step(actions[t])
+    torch.cuda.current_stream(dev).wait_stream(side)
+
+    def run(n_steps):
+      for _ in range(n_steps // args.graph):
+        graph.replay()
+  else:
+    def run(n_steps):
+      for t in range(n_steps):
+        env.step(actions[t % n_act])
+
+  run(args.warmup)
   sync_all()
   ev0 = torch.cuda.Event(enable_timing=True)
   ev1 = torch.cuda.Event(enable_timing=True)
   t0 = time.perf_counter()
   ev0.record()
-  for t in range(args.steps):
-    env.step(actions[t % n_act])
+  run(args.steps)
   ev1.record()
   torch.cuda.synchronize(dev)
   wall = time.perf_counter() - t0
   sync_all()
   kernel_ms = ev0.elapsed_time(ev1) / args.steps   # HIP events on the launch stream
+
+  # Pure-store ceiling of THIS box (same 16-B cooperative store shape, no other work): context for
+  # the roofline fraction of the store-bound families.  Not part of the timed region.
+  from bsuite_amd import _native
+  scratch = env._out[0]['observation'] if hasattr(env, '_out') else env.raw_env._out[0]['observation']
+  nbytes = (scratch.numel() * 4) // 16 * 16
+  stream_h = torch.cuda.current_stream(dev).cuda_stream
+  for _ in range(3):
+    _native.lib.bsx_calib_fill(scratch.data_ptr(), nbytes, 0, stream_h)
+  c0 = torch.cuda.Event(enable_timing=True)
+  c1 = torch.cuda.Event(enable_timing=True)
+  c0.record()
+  for _ in range(10):
+    _native.lib.bsx_calib_fill(scratch.data_ptr(), nbytes, 0, stream_h)
+  c1.record()
+  torch.cuda.synchronize(dev)
+  store_ceiling_gbps = nbytes * 10 / (c0.elapsed_time(c1) * 1e-3) / 1e9
 
   # end-of-rollout summary: per-rank [episodes finished, episodes started, sum of info columns]
   counters = env.episode_counters().to(torch.float64)
@@ -148,7 +186,10 @@ def main():
                    'bytes_per_env_step': bytes_per_step},
         'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBPS, 'unit': 'GB/s',
                      'frac': achieved / HBM_PEAK_GBPS, 'traffic': None,
-                     'kernel_ms': kernel_ms},
+                     'kernel_ms': kernel_ms,
+                     'box_store_ceiling_GBps': store_ceiling_gbps,
+                     'frac_of_box_store_ceiling': achieved / store_ceiling_gbps},
+        'launch': f'hipGraph x{args.graph}' if args.graph else 'eager',
         'episodes_finished': float(summary[0].item()),
     }
     if world == 1 and not args.no_cpu_baseline:

@@ -13,6 +13,7 @@ SO_PATH = os.path.join(_HERE, '_lib', 'libbsuite_amd.so')
 
 FIRST, MID, LAST = 0, 1, 2
 WRAP_NONE, WRAP_SCALE, WRAP_NOISE = 0, 1, 2
+COUNTER_SHARDS, COUNTER_STRIDE = 256, 16
 DEEP_SEA_MAX_SIZE = 64
 BANDIT_MAX_ACTIONS = 32
 
@@ -22,12 +23,14 @@ class NativeLibraryError(RuntimeError):
 
 
 def _load():
-  if not os.path.exists(SO_PATH):
-    # Build in-tree on first use when a toolchain is present; otherwise fail loudly.
-    try:
-      from bsuite_amd import build as _build  # pylint: disable=import-outside-toplevel
-      _build.build()
-    except Exception as e:  # pylint: disable=broad-except
+  # Build in-tree on first use, and rebuild when a kernel source is newer than the library (a
+  # stale .so silently running old kernels is worse than a slow import).  No toolchain and no
+  # library -> fail loudly.
+  try:
+    from bsuite_amd import build as _build  # pylint: disable=import-outside-toplevel
+    _build.build()
+  except Exception as e:  # pylint: disable=broad-except
+    if not os.path.exists(SO_PATH):
       raise NativeLibraryError(
           f'{SO_PATH} is missing and could not be built with hipcc ({e}). bsuite_amd has no CPU '
           'fallback: run `python -m bsuite_amd.build`.') from e
@@ -108,6 +111,7 @@ _SIGS = {
     'bsx_abi_version': ([], ctypes.c_int),
     'bsx_strerror': ([ctypes.c_int], ctypes.c_char_p),
     'bsx_calib_fill': ([_P, ctypes.c_int64, ctypes.c_int32, _P], ctypes.c_int),
+    'bsx_counter_add': ([_P, ctypes.c_uint64, _P], ctypes.c_int),
     'bsx_stream_dump': ([ctypes.c_uint64, ctypes.c_uint64, ctypes.c_int64, ctypes.c_uint64,
                          ctypes.c_int32, ctypes.c_int32, _P, _P, _P], ctypes.c_int),
     'bsx_deep_sea_step': ([ctypes.POINTER(DeepSeaCfg), ctypes.POINTER(Call), _P, _P, TimeStepPtrs, _P],

@@ -62,16 +62,29 @@ __device__ __forceinline__ void bsx_emit(const bsx_ctl& c, const bsx_timestep_t&
   out.step_type[i] = (int8_t)type;
 }
 
-// Termination / restart masks by wavefront ballot: one popcount + one atomic per wave, never per
-// lane.  Inactive lanes (beyond n_lanes) must pass type = -1.
-__device__ __forceinline__ void bsx_count_types(const bsx_ctl& c, int type) {
+// Termination / restart masks by wavefront ballot.  Each wave popcounts its LAST / FIRST masks
+// into two LDS words (s_cnt, zeroed by the caller before the phase); after the block's barrier one
+// thread flushes them with one global atomic per mask into the block's shard of the counter array
+// (bsx_flush_counts).  A single device-wide word would serialise ~16k same-address atomics on the
+// steps where every lane terminates (~200 us measured on catch at B=2^20).  Inactive lanes (beyond
+// n_lanes) must pass type = -1.
+__device__ __forceinline__ void bsx_count_types(const bsx_ctl& c, int type, unsigned int* s_cnt) {
   if (c.counters == nullptr) return;
   unsigned long long last = __ballot(type == BSX_LAST);
   unsigned long long first = __ballot(type == BSX_FIRST);
   if ((threadIdx.x & (BSX_WAVE - 1)) == 0) {
-    if (last) atomicAdd((unsigned long long*)&c.counters[0], (unsigned long long)__popcll(last));
-    if (first) atomicAdd((unsigned long long*)&c.counters[1], (unsigned long long)__popcll(first));
+    if (last) atomicAdd(&s_cnt[0], (unsigned int)__popcll(last));
+    if (first) atomicAdd(&s_cnt[1], (unsigned int)__popcll(first));
   }
+}
+
+// Call after a __syncthreads() that follows every wave's bsx_count_types.
+__device__ __forceinline__ void bsx_flush_counts(const bsx_ctl& c, const unsigned int* s_cnt) {
+  if (c.counters == nullptr || threadIdx.x != 0) return;
+  unsigned long long* shard = (unsigned long long*)c.counters +
+                              (size_t)(blockIdx.x & (BSX_COUNTER_SHARDS - 1)) * BSX_COUNTER_STRIDE;
+  if (s_cnt[0]) atomicAdd(&shard[0], (unsigned long long)s_cnt[0]);
+  if (s_cnt[1]) atomicAdd(&shard[1], (unsigned long long)s_cnt[1]);
 }
 
 // Cooperative one-/two-hot observation tile writer (deep_sea, catch).
@@ -79,60 +92,182 @@ __device__ __forceinline__ void bsx_count_types(const bsx_ctl& c, int type) {
 // The block owns `lanes_here` consecutive lanes, i.e. one contiguous run of lanes_here*cells floats
 // starting at `tile` (16-byte aligned because lanes-per-block is a multiple of 4).  Consecutive
 // threads own consecutive 16-byte chunks, so every wave store instruction covers 1 KiB of
-// contiguous HBM.  hot_a/hot_b (LDS) hold each lane's flat hot-cell index or -1.
+// contiguous HBM; UNROLL independent stores are in flight per thread (measured on MI355X:
+// lane-interleaved 16-B stores with 4-8 in flight reach 6.4-7.0 TB/s, per-thread-contiguous 64 B
+// only 3.6 TB/s — profiles/r01_store_calibration2.log).  hot_a/hot_b (LDS) hold each lane's flat
+// hot-cell index or -1.
+// n / cells for n < 2^20 via the host-built magic (bsx_div_magic); cells == 1 has no 32-bit magic.
+__device__ __forceinline__ uint32_t bsx_div_cells(uint32_t n, uint32_t cells, uint32_t cells_magic) {
+  return cells == 1u ? n : __umulhi(n, cells_magic);
+}
+
 template <bool TWO_HOT>
+__device__ __forceinline__ bsx_f4 bsx_hot_chunk(uint32_t ch, uint32_t cells, uint32_t cells_magic,
+                                                bool aligned, const int* hot_a, const int* hot_b) {
+  const uint32_t f0 = ch << 2;
+  if (cells < 4u) {   // degenerate boards: a chunk spans several lanes, resolve per element
+    float e[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const uint32_t f = f0 + j;
+      const uint32_t lj = bsx_div_cells(f, cells, cells_magic);
+      const int r = (int)(f - lj * cells);
+      e[j] = (hot_a[lj] == r || (TWO_HOT && hot_b[lj] == r)) ? 1.0f : 0.0f;
+    }
+    bsx_f4 t = {e[0], e[1], e[2], e[3]};
+    return t;
+  }
+  const uint32_t l = __umulhi(f0, cells_magic);
+  const int r0 = (int)(f0 - l * cells);
+  int a0 = hot_a[l] - r0;                       // position of the hot cell relative to this chunk
+  int b0 = TWO_HOT ? hot_b[l] - r0 : -1;
+  bsx_f4 v;
+  v.x = (a0 == 0 || (TWO_HOT && b0 == 0)) ? 1.0f : 0.0f;
+  v.y = (a0 == 1 || (TWO_HOT && b0 == 1)) ? 1.0f : 0.0f;
+  v.z = (a0 == 2 || (TWO_HOT && b0 == 2)) ? 1.0f : 0.0f;
+  v.w = (a0 == 3 || (TWO_HOT && b0 == 3)) ? 1.0f : 0.0f;
+  if (!aligned) {
+    // the chunk may straddle into lane l+1: elements j >= over belong to the next lane's row
+    const int over = (int)cells - r0;           // 1..3 when straddling, >= 4 otherwise
+    if (over < 4) {
+      // matches found beyond the row end were comparisons against this lane's (out-of-row) index
+      // space and cannot be real: a hot index is < cells.  Patch in the next lane's cells.
+      const int a1 = hot_a[l + 1] + over;       // relative position inside this chunk
+      const int b1 = TWO_HOT ? hot_b[l + 1] + over : -1;
+      const bool valid1 = hot_a[l + 1] >= 0;
+      const bool validb = TWO_HOT && hot_b[l + 1] >= 0;
+      if (over <= 1) v.y = ((valid1 && a1 == 1) || (validb && b1 == 1)) ? 1.0f : 0.0f;
+      if (over <= 2) v.z = ((valid1 && a1 == 2) || (validb && b1 == 2)) ? 1.0f : 0.0f;
+      v.w = ((valid1 && a1 == 3) || (validb && b1 == 3)) ? 1.0f : 0.0f;
+    }
+  }
+  return v;
+}
+
+template <bool TWO_HOT, int UNROLL>
 __device__ __forceinline__ void bsx_write_hot_tile(float* __restrict__ tile, int lanes_here,
                                                    uint32_t cells, uint32_t cells_magic,
                                                    const int* hot_a, const int* hot_b) {
   const uint32_t total = (uint32_t)lanes_here * cells;          // floats in this block's tile
   const uint32_t n_chunks = total >> 2;
+  const bool aligned = (cells & 3u) == 0;
   bsx_f4* __restrict__ t4 = reinterpret_cast<bsx_f4*>(tile);
-  if ((cells & 3u) == 0) {
-    // a chunk never straddles two lanes
-    for (uint32_t ch = threadIdx.x; ch < n_chunks; ch += BSX_BLOCK) {
-      uint32_t f0 = ch << 2;
-      uint32_t l = __umulhi(f0, cells_magic);
-      int r0 = (int)(f0 - l * cells);
-      int da = hot_a[l] - r0;
-      bsx_f4 v;
-      if (TWO_HOT) {
-        int db = hot_b[l] - r0;
-        v.x = (da == 0 || db == 0) ? 1.0f : 0.0f;
-        v.y = (da == 1 || db == 1) ? 1.0f : 0.0f;
-        v.z = (da == 2 || db == 2) ? 1.0f : 0.0f;
-        v.w = (da == 3 || db == 3) ? 1.0f : 0.0f;
-      } else {
-        v.x = (da == 0) ? 1.0f : 0.0f;
-        v.y = (da == 1) ? 1.0f : 0.0f;
-        v.z = (da == 2) ? 1.0f : 0.0f;
-        v.w = (da == 3) ? 1.0f : 0.0f;
-      }
-      t4[ch] = v;
+  uint32_t ch = threadIdx.x;
+  if (UNROLL > 1) {
+    for (; ch + (UNROLL - 1) * BSX_BLOCK < n_chunks; ch += UNROLL * BSX_BLOCK) {
+      bsx_f4 v[UNROLL];
+#pragma unroll
+      for (int u = 0; u < UNROLL; ++u)
+        v[u] = bsx_hot_chunk<TWO_HOT>(ch + u * BSX_BLOCK, cells, cells_magic, aligned, hot_a, hot_b);
+#pragma unroll
+      for (int u = 0; u < UNROLL; ++u) t4[ch + u * BSX_BLOCK] = v[u];
     }
-  } else {
-    for (uint32_t ch = threadIdx.x; ch < n_chunks; ch += BSX_BLOCK) {
-      uint32_t f0 = ch << 2;
+  }
+  for (; ch < n_chunks; ch += BSX_BLOCK)
+    t4[ch] = bsx_hot_chunk<TWO_HOT>(ch, cells, cells_magic, aligned, hot_a, hot_b);
+  // ragged tail (< 4 floats) of an odd-sized final tile
+  const uint32_t f = (n_chunks << 2) + threadIdx.x;
+  if (f < total) {
+    const uint32_t l = bsx_div_cells(f, cells, cells_magic);
+    const int r = (int)(f - l * cells);
+    bool on = hot_a[l] == r;
+    if (TWO_HOT) on = on || hot_b[l] == r;
+    tile[f] = on ? 1.0f : 0.0f;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Split-phase observation writer: a pure store stream over the whole [B x cells] observation
+// array, decoupled from the lane-advance kernel.  Every block writes one 16 KiB run (4 stores of
+// 16 B per thread, lane-interleaved), blocks are dispatched in address order, so at any instant
+// the chip writes one compact window of HBM — the access pattern that reached 6.8-7.1 TB/s in the
+// fill calibration (profiles/r01_store_calibration2.log), against ~5.5 TB/s for per-block tiles
+// spaced hundreds of KB apart.  The hot cells are recomputed from the packed state column the
+// advance kernel has just written (4 B per lane, L2-resident).
+//
+// Index space: lanes are grouped in super-tiles of 256 lanes so in-tile float offsets fit the
+// 32-bit magic division; blockIdx.x = super_tile * subs_per_super + sub.
+#define BSX_SUPER 256
+#define BSX_STREAM_CHUNKS 1024   // 16-B chunks per block = 16 KiB
+
+template <class HotFn>
+__global__ void __launch_bounds__(BSX_BLOCK) bsx_hot_stream_kernel(float* __restrict__ obs,
+                                                                   const int32_t* __restrict__ state,
+                                                                   int64_t n_lanes, uint32_t cells,
+                                                                   uint32_t cells_magic,
+                                                                   uint32_t subs_per_super, HotFn fn) {
+  const uint32_t super = blockIdx.x / subs_per_super;
+  const uint32_t sub = blockIdx.x - super * subs_per_super;
+  const int64_t lane0 = (int64_t)super * BSX_SUPER;
+  const int64_t remaining = n_lanes - lane0;
+  const uint32_t lanes_here = remaining < BSX_SUPER ? (uint32_t)remaining : BSX_SUPER;
+  const uint32_t total = lanes_here * cells;
+  const uint32_t n_chunks = total >> 2;
+  const bool aligned = (cells & 3u) == 0;
+  float* __restrict__ tile = obs + lane0 * (int64_t)cells;
+  bsx_f4* __restrict__ t4 = reinterpret_cast<bsx_f4*>(tile);
+  const int32_t* __restrict__ st = state + lane0;
+
+  uint32_t ch[4];
+  uint32_t l[4];
+  int32_t s0[4], s1[4];
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    ch[u] = sub * BSX_STREAM_CHUNKS + threadIdx.x + u * BSX_BLOCK;
+    const uint32_t f0 = ch[u] << 2;
+    l[u] = bsx_div_cells(f0, cells, cells_magic);
+    const bool live = ch[u] < n_chunks;
+    s0[u] = live ? st[l[u]] : 0;
+    s1[u] = (live && !aligned && l[u] + 1 < lanes_here) ? st[l[u] + 1] : 0;
+  }
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    if (ch[u] >= n_chunks) continue;
+    const uint32_t f0 = ch[u] << 2;
+    bsx_f4 v;
+    if (cells < 4u) {
       float e[4];
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        uint32_t f = f0 + j;
-        uint32_t l = __umulhi(f, cells_magic);
-        int r = (int)(f - l * cells);
-        bool on = hot_a[l] == r;
-        if (TWO_HOT) on = on || hot_b[l] == r;
-        e[j] = on ? 1.0f : 0.0f;
+        const uint32_t f = f0 + j;
+        const uint32_t lj = bsx_div_cells(f, cells, cells_magic);
+        const int r = (int)(f - lj * cells);
+        int ha, hb;
+        fn(st[lj], ha, hb);
+        e[j] = (ha == r || hb == r) ? 1.0f : 0.0f;
       }
-      bsx_f4 v = {e[0], e[1], e[2], e[3]};
-      t4[ch] = v;
+      bsx_f4 t = {e[0], e[1], e[2], e[3]};
+      v = t;
+    } else {
+      const int r0 = (int)(f0 - l[u] * cells);
+      int ha, hb;
+      fn(s0[u], ha, hb);
+      const int a0 = ha - r0, b0 = hb < 0 ? -1 : hb - r0;
+      v.x = (a0 == 0 || b0 == 0) ? 1.0f : 0.0f;
+      v.y = (a0 == 1 || b0 == 1) ? 1.0f : 0.0f;
+      v.z = (a0 == 2 || b0 == 2) ? 1.0f : 0.0f;
+      v.w = (a0 == 3 || b0 == 3) ? 1.0f : 0.0f;
+      const int over = (int)cells - r0;
+      if (!aligned && over < 4) {           // elements j >= over belong to lane l+1
+        int na, nb;
+        fn(s1[u], na, nb);
+        const int a1 = na < 0 ? -1 : na + over, b1 = nb < 0 ? -1 : nb + over;
+        if (over <= 1) v.y = (a1 == 1 || b1 == 1) ? 1.0f : 0.0f;
+        if (over <= 2) v.z = (a1 == 2 || b1 == 2) ? 1.0f : 0.0f;
+        v.w = (a1 == 3 || b1 == 3) ? 1.0f : 0.0f;
+      }
     }
-    // ragged tail (< 4 floats) of an odd-sized tile
-    uint32_t f = (n_chunks << 2) + threadIdx.x;
+    t4[ch[u]] = v;
+  }
+  // ragged tail (< 4 floats) of an odd-sized final super-tile: done by its last sub-block
+  if (sub == subs_per_super - 1) {
+    const uint32_t f = (n_chunks << 2) + threadIdx.x;
     if (f < total) {
-      uint32_t l = __umulhi(f, cells_magic);
-      int r = (int)(f - l * cells);
-      bool on = hot_a[l] == r;
-      if (TWO_HOT) on = on || hot_b[l] == r;
-      tile[f] = on ? 1.0f : 0.0f;
+      const uint32_t lj = bsx_div_cells(f, cells, cells_magic);
+      const int r = (int)(f - lj * cells);
+      int ha, hb;
+      fn(st[lj], ha, hb);
+      tile[f] = (ha == r || hb == r) ? 1.0f : 0.0f;
     }
   }
 }

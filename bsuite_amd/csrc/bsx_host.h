@@ -2,6 +2,8 @@
 #ifndef BSX_HOST_H_
 #define BSX_HOST_H_
 
+#include <stdlib.h>
+
 #include "bsx_device.h"
 
 static inline int bsx_check_call(const bsx_call_t* call, const void* action, const bsx_timestep_t& out) {
@@ -34,6 +36,20 @@ static inline bsx_ctl bsx_make_ctl(const bsx_call_t* call) {
 
 // magic for q = n / d via __umulhi(n, magic): exact for n < 2^20, d <= 4096
 static inline uint32_t bsx_div_magic(uint32_t d) { return (uint32_t)((0x100000000ull / d) + 1ull); }
+
+static inline int bsx_env_int(const char* name, int dflt) {
+  const char* v = getenv(name);
+  return (v != nullptr && *v != '\0') ? atoi(v) : dflt;
+}
+
+// Launch geometry of bsx_hot_stream_kernel for n_lanes lanes of `cells` floats.
+static inline int bsx_stream_grid(int64_t n_lanes, uint32_t cells, uint32_t* subs_per_super, int64_t* blocks) {
+  const uint32_t chunks_per_super = (BSX_SUPER * cells + 3u) >> 2;
+  *subs_per_super = (chunks_per_super + BSX_STREAM_CHUNKS - 1) / BSX_STREAM_CHUNKS;
+  const int64_t supers = (n_lanes + BSX_SUPER - 1) / BSX_SUPER;
+  *blocks = supers * (int64_t)(*subs_per_super);
+  return *blocks > 0x7FFFFFFF ? BSX_EINVAL : 0;
+}
 
 static inline int bsx_launch_status() { return (int)hipGetLastError(); }
 

@@ -20,10 +20,21 @@ struct catch_args {
 
 #define CATCH_RESET_BIT (1 << 24)
 
-template <int LPB>
+struct catch_hot {
+  int rows, cols;
+  __device__ __forceinline__ void operator()(int32_t st, int& a, int& b) const {
+    a = ((st >> 8) & 0xFF) * cols + (st & 0xFF);          // ball   (catch.py:111)
+    b = (rows - 1) * cols + ((st >> 16) & 0xFF);          // paddle (catch.py:112)
+  }
+};
+
+template <int LPB, bool FUSED>
 __global__ void __launch_bounds__(BSX_BLOCK) catch_step_kernel(const catch_args a) {
   __shared__ int s_ball[LPB];
   __shared__ int s_paddle[LPB];
+  __shared__ unsigned int s_cnt[2];
+  if (threadIdx.x < 2) s_cnt[threadIdx.x] = 0;
+  __syncthreads();
   const int64_t lane0 = (int64_t)blockIdx.x * LPB;
   const int64_t remaining = a.ctl.n_lanes - lane0;
   const int lanes_here = remaining < LPB ? (int)remaining : LPB;
@@ -63,10 +74,12 @@ __global__ void __launch_bounds__(BSX_BLOCK) catch_step_kernel(const catch_args 
       s_ball[threadIdx.x] = ball_y * cols + ball_x;             // :111
       s_paddle[threadIdx.x] = (rows - 1) * cols + paddle_x;     // :112
     }
-    bsx_count_types(a.ctl, type);
+    bsx_count_types(a.ctl, type, s_cnt);
   }
   __syncthreads();
-  bsx_write_hot_tile<true>(a.out.observation + lane0 * (int64_t)a.cells, lanes_here, a.cells,
+  bsx_flush_counts(a.ctl, s_cnt);
+  if (!FUSED) return;
+  bsx_write_hot_tile<true, 4>(a.out.observation + lane0 * (int64_t)a.cells, lanes_here, a.cells,
                            a.cells_magic, s_ball, s_paddle);
 }
 
@@ -87,6 +100,17 @@ extern "C" int bsx_catch_step(const bsx_catch_t* cfg, const bsx_call_t* call, co
   constexpr int LPB = 256;
   const int64_t blocks = (call->n_lanes + LPB - 1) / LPB;
   if (blocks > 0x7FFFFFFF) return BSX_EINVAL;
-  catch_step_kernel<LPB><<<dim3((unsigned)blocks), dim3(BSX_BLOCK), 0, (hipStream_t)call->hip_stream>>>(a);
+  hipStream_t st = (hipStream_t)call->hip_stream;
+  static const int split = bsx_env_int("BSX_CATCH_SPLIT", 0);
+  if (split) {
+    uint32_t subs; int64_t blocks_b;
+    if (bsx_stream_grid(call->n_lanes, a.cells, &subs, &blocks_b) != 0) return BSX_EINVAL;
+    catch_step_kernel<LPB, false><<<dim3((unsigned)blocks), dim3(BSX_BLOCK), 0, st>>>(a);
+    catch_hot fn{cfg->rows, cfg->columns};
+    bsx_hot_stream_kernel<catch_hot><<<dim3((unsigned)blocks_b), dim3(BSX_BLOCK), 0, st>>>(
+        out.observation, state, call->n_lanes, a.cells, a.cells_magic, subs, fn);
+    return bsx_launch_status();
+  }
+  catch_step_kernel<LPB, true><<<dim3((unsigned)blocks), dim3(BSX_BLOCK), 0, st>>>(a);
   return bsx_launch_status();
 }

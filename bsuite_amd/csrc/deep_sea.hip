@@ -29,10 +29,22 @@ struct deep_sea_args {
 #define DS_RESET_BIT (1 << 17)
 #define DS_BAD_BIT (1 << 16)
 
-template <int LPB>
+// hot cell of a lane from its packed state (split-phase writer)
+struct deep_sea_hot {
+  int N;
+  __device__ __forceinline__ void operator()(int32_t st, int& a, int& b) const {
+    const int row = st & 0xFF, col = (st >> 8) & 0xFF;
+    a = row < N ? row * N + col : -1;     // deep_sea.py:105-107
+    b = -1;
+  }
+};
+
+template <int LPB, int UNROLL, bool FUSED>
 __global__ void __launch_bounds__(BSX_BLOCK) deep_sea_step_kernel(const deep_sea_args a) {
   __shared__ uint32_t s_map[BSX_DEEP_SEA_MAX_SIZE * BSX_DEEP_SEA_MAX_SIZE / 32];
   __shared__ int s_hot[LPB];
+  __shared__ unsigned int s_cnt[2];
+  if (threadIdx.x < 2) s_cnt[threadIdx.x] = 0;
 
   const int N = a.size;
   const int map_words = (N * N + 31) >> 5;
@@ -89,11 +101,13 @@ __global__ void __launch_bounds__(BSX_BLOCK) deep_sea_step_kernel(const deep_sea
       bsx_emit(a.ctl, a.out, i, lane, step, type, reward);
       s_hot[threadIdx.x] = (row < N) ? row * N + col : -1;      // :105-107 (terminal obs all-zero)
     }
-    bsx_count_types(a.ctl, type);
+    bsx_count_types(a.ctl, type, s_cnt);
   }
   __syncthreads();
+  bsx_flush_counts(a.ctl, s_cnt);
+  if (!FUSED) return;
 
-  bsx_write_hot_tile<false>(a.out.observation + lane0 * (int64_t)a.cells, lanes_here, a.cells,
+  bsx_write_hot_tile<false, UNROLL>(a.out.observation + lane0 * (int64_t)a.cells, lanes_here, a.cells,
                             a.cells_magic, s_hot, nullptr);
 }
 
@@ -118,10 +132,39 @@ extern "C" int bsx_deep_sea_step(const bsx_deep_sea_t* cfg, const bsx_call_t* ca
 
   hipStream_t st = (hipStream_t)call->hip_stream;
   // Tile = LPB lanes: 64 lanes x 3600 B = 230 KB per block at N=30 -> 16384 blocks at B=2^20,
-  // enough to keep 256 CUs x 8 resident blocks busy with a short tail.
-  constexpr int LPB = 64;
-  const int64_t blocks = (call->n_lanes + LPB - 1) / LPB;
-  if (blocks > 0x7FFFFFFF) return BSX_EINVAL;
-  deep_sea_step_kernel<LPB><<<dim3((unsigned)blocks), dim3(BSX_BLOCK), 0, st>>>(a);
+  // enough to keep 256 CUs x 8 resident blocks busy with a short tail.  BSX_DS_LPB / BSX_DS_UNROLL
+  // are tuning knobs for the A/B sweeps recorded under profiles/ (defaults = measured best).
+  static const int split = bsx_env_int("BSX_DS_SPLIT", 0);
+  if (split) {
+    // advance kernel (all 256 threads own a lane) + pure streaming observation writer
+    const int64_t blocks_a = (call->n_lanes + 255) / 256;
+    uint32_t subs; int64_t blocks_b;
+    if (blocks_a > 0x7FFFFFFF || bsx_stream_grid(call->n_lanes, a.cells, &subs, &blocks_b) != 0) return BSX_EINVAL;
+    deep_sea_step_kernel<256, 1, false><<<dim3((unsigned)blocks_a), dim3(BSX_BLOCK), 0, st>>>(a);
+    deep_sea_hot fn{cfg->size};
+    bsx_hot_stream_kernel<deep_sea_hot><<<dim3((unsigned)blocks_b), dim3(BSX_BLOCK), 0, st>>>(
+        out.observation, state, call->n_lanes, a.cells, a.cells_magic, subs, fn);
+    return bsx_launch_status();
+  }
+  static const int lpb = bsx_env_int("BSX_DS_LPB", 64);
+  static const int unroll = bsx_env_int("BSX_DS_UNROLL", 4);
+#define DS_LAUNCH(L, U)                                                                     \
+  do {                                                                                      \
+    const int64_t blocks = (call->n_lanes + (L) - 1) / (L);                                 \
+    if (blocks > 0x7FFFFFFF) return BSX_EINVAL;                                             \
+    deep_sea_step_kernel<L, U, true><<<dim3((unsigned)blocks), dim3(BSX_BLOCK), 0, st>>>(a);      \
+  } while (0)
+#define DS_UNROLLS(L)                                              \
+  do {                                                             \
+    if (unroll >= 8) DS_LAUNCH(L, 8);                              \
+    else if (unroll >= 4) DS_LAUNCH(L, 4);                         \
+    else if (unroll >= 2) DS_LAUNCH(L, 2);                         \
+    else DS_LAUNCH(L, 1);                                          \
+  } while (0)
+  if (lpb >= 256) DS_UNROLLS(256);
+  else if (lpb >= 128) DS_UNROLLS(128);
+  else if (lpb >= 64) DS_UNROLLS(64);
+  else if (lpb >= 32) DS_UNROLLS(32);
+  else DS_UNROLLS(16);
   return bsx_launch_status();
 }

@@ -15,16 +15,21 @@ extern "C" const char* bsx_strerror(int code) {
   }
 }
 
-// Same store shape as the observation writers: each block owns a contiguous tile, consecutive
-// threads write consecutive 16-byte chunks.
+// Pure-store calibration.  Same store shape as the observation writers (consecutive threads write
+// consecutive 16-byte chunks, 4 independent stores per thread per iteration, 16 KiB per block
+// iteration, blocks in address order) with no other work: what this reaches is the practical
+// ceiling of a dense-observation step on the box it runs on.
 template <bool NT>
-__global__ void __launch_bounds__(BSX_BLOCK) calib_fill_kernel(bsx_f4* __restrict__ p, int64_t n16,
-                                                               int64_t tile16) {
+__global__ void __launch_bounds__(BSX_BLOCK) calib_fill_kernel(bsx_f4* __restrict__ p, int64_t n16) {
   const bsx_f4 z = {0.f, 0.f, 0.f, 0.f};
-  int64_t base = (int64_t)blockIdx.x * tile16;
-  int64_t end = base + tile16 < n16 ? base + tile16 : n16;
-  for (int64_t i = base + threadIdx.x; i < end; i += BSX_BLOCK) {
-    if (NT) __builtin_nontemporal_store(z, &p[i]); else p[i] = z;
+  const int64_t tile = 4 * BSX_BLOCK;
+  for (int64_t base = (int64_t)blockIdx.x * tile; base < n16; base += (int64_t)gridDim.x * tile) {
+    const int64_t i = base + threadIdx.x;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int64_t j = i + (int64_t)k * BSX_BLOCK;
+      if (j < n16) { if (NT) __builtin_nontemporal_store(z, &p[j]); else p[j] = z; }
+    }
   }
 }
 
@@ -34,11 +39,19 @@ extern "C" int bsx_calib_fill(void* dst, int64_t n_bytes, int32_t nontemporal, v
   if ((reinterpret_cast<uintptr_t>(dst) & 15u) != 0) return BSX_EALIGN;
   if (n_bytes == 0) return 0;
   const int64_t n16 = n_bytes / 16;
-  const int64_t tile16 = 64 * 3600 / 16;   // one deep_sea N=30 block tile
-  const int64_t blocks = (n16 + tile16 - 1) / tile16;
+  int64_t blocks = (n16 + 4 * BSX_BLOCK - 1) / (4 * BSX_BLOCK);
+  if (blocks > 65536) blocks = 65536;
   hipStream_t st = (hipStream_t)hip_stream;
-  if (nontemporal) calib_fill_kernel<true><<<dim3((unsigned)blocks), dim3(BSX_BLOCK), 0, st>>>((bsx_f4*)dst, n16, tile16);
-  else calib_fill_kernel<false><<<dim3((unsigned)blocks), dim3(BSX_BLOCK), 0, st>>>((bsx_f4*)dst, n16, tile16);
+  if (nontemporal) calib_fill_kernel<true><<<dim3((unsigned)blocks), dim3(BSX_BLOCK), 0, st>>>((bsx_f4*)dst, n16);
+  else calib_fill_kernel<false><<<dim3((unsigned)blocks), dim3(BSX_BLOCK), 0, st>>>((bsx_f4*)dst, n16);
+  return bsx_launch_status();
+}
+
+__global__ void counter_add_kernel(uint64_t* counter, uint64_t delta) { *counter += delta; }
+
+extern "C" int bsx_counter_add(uint64_t* counter, uint64_t delta, void* hip_stream) {
+  if (counter == nullptr) return BSX_ENULL;
+  counter_add_kernel<<<dim3(1), dim3(1), 0, (hipStream_t)hip_stream>>>(counter, delta);
   return bsx_launch_status();
 }
 

@@ -19,6 +19,9 @@
 template <class Env, int LPB>
 __global__ void __launch_bounds__(BSX_BLOCK) small_obs_kernel(const typename Env::args a) {
   extern __shared__ __attribute__((aligned(16))) float s_obs[];
+  __shared__ unsigned int s_cnt[2];
+  if (threadIdx.x < 2) s_cnt[threadIdx.x] = 0;
+  __syncthreads();
   const int numel = a.obs_numel;
   const int64_t lane0 = (int64_t)blockIdx.x * LPB;
   const int64_t remaining = a.ctl.n_lanes - lane0;
@@ -34,9 +37,10 @@ __global__ void __launch_bounds__(BSX_BLOCK) small_obs_kernel(const typename Env
       type = Env::step(a, i, lane, step, s_obs + (int)threadIdx.x * numel, reward);
       bsx_emit(a.ctl, a.out, i, lane, step, type, reward);
     }
-    bsx_count_types(a.ctl, type);
+    bsx_count_types(a.ctl, type, s_cnt);
   }
   __syncthreads();
+  bsx_flush_counts(a.ctl, s_cnt);
 
   // stream the tile: [lanes_here x numel] floats, contiguous in HBM, 16-byte aligned start
   float* __restrict__ tile = a.out.observation + lane0 * (int64_t)numel;

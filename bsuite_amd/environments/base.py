@@ -53,7 +53,7 @@ class Environment(dm_env.EnvironmentBase):
   _info_int_keys = ()      # keys the reference reports as Python ints
 
   def __init__(self, obs_shape, num_actions, *, seed=None, batch=None, device=None,
-               lane_offset=0, num_buffers=2):
+               lane_offset=0, num_buffers=2, device_step_counter=False):
     self._scalar = batch is None
     self._batch = 1 if batch is None else int(batch)
     if self._batch < 1:
@@ -64,6 +64,10 @@ class Environment(dm_env.EnvironmentBase):
     self._obs_shape = tuple(int(d) for d in obs_shape)
     self._num_actions = int(num_actions)
     self._num_buffers = max(1, int(num_buffers))
+    # device_step_counter=True keeps the draw-stream call index in device memory and bumps it
+    # with a one-thread kernel after every call, so step() carries no host-side state and can be
+    # captured into (and replayed from) a HIP graph.
+    self._device_step_counter = bool(device_step_counter)
     self._wrap = (_native.WRAP_NONE, 0.0, 0)
     self._step_index = 0
     self._buf = 0
@@ -90,8 +94,13 @@ class Environment(dm_env.EnvironmentBase):
 
   @property
   def step_index(self) -> int:
-    """Index the next reset()/step() call will use in the draw stream."""
+    """Index the next reset()/step() call will use in the draw stream (host-side count; with
+    device_step_counter=True and graph replays, `device_step_index()` is authoritative)."""
     return self._step_index
+
+  def device_step_index(self) -> int:
+    self._ensure_allocated()
+    return int(self._step_base.item()) if self._device_step_counter else self._step_index
 
   def _state_tensors(self) -> Dict[str, torch.Tensor]:
     """Subclass hook: allocate the family's SoA state columns with their initial values."""
@@ -113,34 +122,52 @@ class Environment(dm_env.EnvironmentBase):
       self._state = self._state_tensors()
       n_info = max(1, len(self._info_keys))
       self._info = torch.zeros((n_info, B), dtype=torch.float64, device=dev)
-      self._counters = torch.zeros(2, dtype=torch.int64, device=dev)
+      self._counters = torch.zeros((_native.COUNTER_SHARDS, _native.COUNTER_STRIDE),
+                                   dtype=torch.int64, device=dev)
+      self._step_base = torch.zeros(1, dtype=torch.int64, device=dev)
       self._out = []
+      self._out_ptrs = []
       for _ in range(self._num_buffers):
-        self._out.append(dict(
+        o = dict(
             reward=torch.empty(B, dtype=torch.float32, device=dev),
             discount=torch.empty(B, dtype=torch.float32, device=dev),
             step_type=torch.empty(B, dtype=torch.int8, device=dev),
-            observation=torch.empty((B,) + self._obs_shape, dtype=torch.float32, device=dev)))
+            observation=torch.empty((B,) + self._obs_shape, dtype=torch.float32, device=dev))
+        self._out.append(o)
+        self._out_ptrs.append(_native.TimeStepPtrs(
+            o['reward'].data_ptr(), o['discount'].data_ptr(), o['step_type'].data_ptr(),
+            o['observation'].data_ptr()))
       self._scalar_action = torch.zeros(1, dtype=torch.int32, device=dev)
+    # One persistent call descriptor: only step_index / force_reset / stream change per call.
+    self._call_desc = _native.Call(
+        n_lanes=B, force_reset=0,
+        stream=_native.Stream(self._seed, self._lane_offset, 0,
+                              self._step_base.data_ptr() if self._device_step_counter else None),
+        wrap=_native.RewardWrap(_native.WRAP_NONE, 0, 0.0, 0),
+        counters=self._counters.data_ptr(), hip_stream=None)
     self._allocated = True
 
   # ----------------------------------------------------------------------------------------
   # the hot path
-  def _call(self, action, force_reset: bool):
-    self._ensure_allocated()
+  def _call(self, action_ptr: int, force_reset: bool):
+    out_ptrs = self._out_ptrs[self._buf]
     out = self._out[self._buf]
     self._buf = (self._buf + 1) % self._num_buffers
+    call = self._call_desc
+    call.force_reset = 1 if force_reset else 0
     kind, param, wseed = self._wrap
-    call = _native.Call(
-        n_lanes=self._batch, force_reset=int(force_reset),
-        stream=_native.Stream(self._seed, self._lane_offset, self._step_index, None),
-        wrap=_native.RewardWrap(kind, 0, param, wseed),
-        counters=self._counters.data_ptr(),
-        hip_stream=torch.cuda.current_stream(self._device).cuda_stream)
-    ptrs = _native.TimeStepPtrs(out['reward'].data_ptr(), out['discount'].data_ptr(),
-                                out['step_type'].data_ptr(), out['observation'].data_ptr())
-    rc = self._launch(call, 0 if action is None else action.data_ptr(), ptrs)
-    _native.check(rc, f'{type(self).__name__} step')
+    call.wrap.kind, call.wrap.param, call.wrap.seed = kind, param, wseed
+    hip_stream = torch.cuda.current_stream(self._device).cuda_stream
+    call.hip_stream = hip_stream
+    if self._device_step_counter:
+      rc = self._launch(call, action_ptr, out_ptrs)
+      if rc == 0:
+        rc = _native.lib.bsx_counter_add(self._step_base.data_ptr(), 1, hip_stream)
+    else:
+      call.stream.step_index = self._step_index
+      rc = self._launch(call, action_ptr, out_ptrs)
+    if rc != 0:
+      _native.check(rc, f'{type(self).__name__} step')
     self._step_index += 1
     return out
 
@@ -181,13 +208,13 @@ class Environment(dm_env.EnvironmentBase):
     """Resets every lane (base.py:54-57) and returns the FIRST TimeStep."""
     self._reset_next_step = False
     self._ensure_allocated()
-    return self._wrap_output(self._call(None, force_reset=True))
+    return self._wrap_output(self._call(0, force_reset=True))
 
   def step(self, action) -> dm_env.TimeStep:
     """Steps every lane; lanes whose previous step was LAST (or that are fresh) reset instead and
     ignore their action (base.py:59-65)."""
     self._ensure_allocated()
-    return self._wrap_output(self._call(self._coerce_actions(action), force_reset=False))
+    return self._wrap_output(self._call(self._coerce_actions(action).data_ptr(), force_reset=False))
 
   def _step(self, action):
     raise NotImplementedError('The batched engine fuses _step/_reset into one kernel; call step().')
@@ -217,9 +244,10 @@ class Environment(dm_env.EnvironmentBase):
     return {k: self._info[j] for j, k in enumerate(self._info_keys) if not k.startswith('_')}
 
   def episode_counters(self) -> torch.Tensor:
-    """int64 [2] device tensor: lanes that emitted LAST, lanes that emitted FIRST (all calls)."""
+    """int64 [2] device tensor: lanes that emitted LAST, lanes that emitted FIRST (all calls so
+    far).  The kernels accumulate wave-ballot popcounts into 256 sharded counters; this sums them."""
     self._ensure_allocated()
-    return self._counters
+    return self._counters[:, :2].sum(dim=0)
 
   def state_dict(self) -> Dict[str, Any]:
     """Everything needed to resume this batch bit-exactly (device tensors are cloned)."""
@@ -227,7 +255,7 @@ class Environment(dm_env.EnvironmentBase):
     d = {k: v.clone() for k, v in self._state.items()}
     d['__info'] = self._info.clone()
     d['__counters'] = self._counters.clone()
-    d['__step_index'] = self._step_index
+    d['__step_index'] = self.device_step_index()
     d['__seed'] = self._seed
     return d
 
@@ -238,4 +266,6 @@ class Environment(dm_env.EnvironmentBase):
     self._info.copy_(d['__info'])
     self._counters.copy_(d['__counters'])
     self._step_index = int(d['__step_index'])
+    if self._device_step_counter:
+      self._step_base.fill_(self._step_index)
     self._seed = int(d['__seed'])

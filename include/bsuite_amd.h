@@ -70,6 +70,9 @@ typedef struct {
   float* observation;   /* [B, obs_numel], 16-byte aligned       */
 } bsx_timestep_t;
 
+#define BSX_COUNTER_SHARDS 256
+#define BSX_COUNTER_STRIDE 16   /* uint64 per shard = one 128-byte line */
+
 /* Per-call control shared by all families. */
 typedef struct {
   int64_t n_lanes;          /* B of this shard                                                   */
@@ -77,8 +80,11 @@ typedef struct {
   int32_t _pad;
   bsx_stream_t stream;
   bsx_reward_wrap_t wrap;
-  uint64_t* counters;       /* device, nullable: [0] += lanes that emitted LAST, [1] += lanes that
-                               emitted FIRST (wave-ballot popcount, one atomic per wavefront)     */
+  uint64_t* counters;       /* device, nullable: BSX_COUNTER_SHARDS x BSX_COUNTER_STRIDE uint64.
+                               shard s = block % SHARDS; [s*STRIDE+0] += lanes that emitted LAST,
+                               [s*STRIDE+1] += lanes that emitted FIRST.  Masks come from wavefront
+                               ballots; one global atomic per workgroup per mask, spread over 256
+                               cache lines (a single hot word serialises ~12 ns per arrival).      */
   void* hip_stream;         /* hipStream_t                                                       */
 } bsx_call_t;
 
@@ -194,6 +200,9 @@ const char* bsx_strerror(int code);
 /* Pure-store calibration: writes n_bytes of zeros with the same 16-B cooperative pattern the
  * observation writers use; the measured rate is the practical ceiling for store-bound families. */
 int bsx_calib_fill(void* dst, int64_t n_bytes, int32_t nontemporal, void* hip_stream);
+/* *counter += delta on the stream: advances a device-resident call counter (bsx_stream_t.step_base)
+ * so a captured hipGraph of step launches replays with fresh draw-stream coordinates. */
+int bsx_counter_add(uint64_t* counter, uint64_t delta, void* hip_stream);
 /* Fill words [0,n) of the draw stream for (seed, lane, step, stream_id) — used by tests to pin the
  * device Philox/normal implementation against the oracle's independent one. */
 int bsx_stream_dump(uint64_t seed, uint64_t lane0, int64_t n_lanes, uint64_t step, int32_t stream_id,

@@ -1,0 +1,99 @@
+"""GPU: the HIP kernels against the C oracle on seeded random-action rollouts at batch sizes the
+golden fixtures do not reach — ragged (not a multiple of the tile), one lane, several thousand
+lanes, long lane offsets — and through explicit reset() calls.  Integer / grid families bit-exact;
+physics families teacher-forced from the oracle's f64 state at 1e-6."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import coracle
+from tests import engine_util as eu
+
+pytestmark = pytest.mark.gpu
+
+CASES = [
+    ('deep_sea', dict(size=30, mapping_seed=42), None),
+    ('deep_sea', dict(size=10, mapping_seed=42), None),
+    ('deep_sea', dict(size=9, mapping_seed=1), None),                      # odd: straddling chunks
+    ('deep_sea', dict(size=13, deterministic=False, mapping_seed=42), None),
+    ('deep_sea', dict(size=1, mapping_seed=0), None),
+    ('deep_sea', dict(size=64, mapping_seed=5), None),
+    ('deep_sea', dict(size=10, deterministic=False, mapping_seed=42), ('noise', 0.5)),
+    ('catch', dict(), None),
+    ('catch', dict(rows=7, columns=3), None),
+    ('catch', dict(rows=2, columns=1), None),
+    ('catch', dict(rows=64, columns=64), None),
+    ('catch', dict(), ('scale', 30.0)),
+    ('bandit', dict(mapping_seed=3), None),
+    ('bandit', dict(mapping_seed=3), ('noise', 1.0)),
+    ('memory_chain', dict(memory_length=3, num_bits=5), None),
+    ('memory_chain', dict(memory_length=1, num_bits=62), None),
+    ('memory_chain', dict(memory_length=30, num_bits=1), None),
+    ('umbrella_chain', dict(chain_length=4, n_distractor=20), None),
+    ('umbrella_chain', dict(chain_length=2, n_distractor=253), None),
+    ('umbrella_chain', dict(chain_length=6, n_distractor=64), ('noise', 0.1)),
+    ('discounting_chain', dict(mapping_seed=2), None),
+]
+
+
+@pytest.mark.parametrize('family,kwargs,wrap', CASES)
+@pytest.mark.parametrize('batch,lane_offset', [(1, 0), (1000, 0), (4099, (1 << 32) - 17)])
+def test_random_rollout_bit_exact(family, kwargs, wrap, batch, lane_offset):
+  if family == 'catch' and kwargs.get('rows') == 64 and batch > 1000:
+    pytest.skip('big board at big batch adds nothing')
+  seed = 1234
+  env = eu.make_env(family, kwargs, batch=batch, lane_offset=lane_offset, seed=seed, wrap=wrap)
+  orc = coracle.OracleEnv(family, kwargs, np.arange(lane_offset, lane_offset + batch, dtype=np.uint64),
+                          seed=seed, wrap=wrap)
+  rng = np.random.default_rng(batch)
+  T = 45 if family != 'discounting_chain' else 105
+  for t in range(T):
+    a = rng.integers(0, orc.num_actions, size=batch).astype(np.int32)
+    force = t in (11, 12)
+    ts = env.reset() if force else env.step(torch.from_numpy(a).cuda())
+    st, r, d, o = orc.call(a, t, force_reset=force)
+    gst, gr, gd, go = eu.to_np(ts)
+    np.testing.assert_array_equal(gst, st, err_msg=f't={t}')
+    live = st != 0
+    np.testing.assert_array_equal(eu.f32_bits(gr[live]), eu.f32_bits(r[live].astype(np.float32)), err_msg=f'reward t={t}')
+    np.testing.assert_array_equal(gd[live], d[live].astype(np.float32))
+    assert (gr[~live] == 0).all() and (gd[~live] == 1).all()
+    np.testing.assert_array_equal(eu.f32_bits(go), eu.f32_bits(o), err_msg=f'obs t={t}')
+  info = env.bsuite_info()
+  for k, v in orc.bsuite_info().items():
+    np.testing.assert_array_equal(info[k].cpu().numpy(), v, err_msg=k)
+  c = eu.raw(env).episode_counters().cpu().numpy()
+  assert c[0] >= 0 and c[1] >= batch
+
+
+@pytest.mark.parametrize('family,kwargs', [
+    ('cartpole', dict()), ('cartpole_swingup', dict(height_threshold=0.25, x_reward_threshold=0.75)),
+    ('cartpole_swingup', dict(init_range=3.2)), ('mountain_car', dict()), ('mountain_car', dict(max_steps=30))])
+def test_physics_teacher_forced(family, kwargs):
+  batch, seed, T = 3001, 99, 120
+  env = eu.make_env(family, kwargs, batch=batch, lane_offset=5, seed=seed)
+  orc = coracle.OracleEnv(family, kwargs, np.arange(5, 5 + batch, dtype=np.uint64), seed=seed)
+  rng = np.random.default_rng(7)
+  r_env = eu.raw(env)
+  flips = 0
+  for t in range(T):
+    a = rng.integers(0, 3, size=batch).astype(np.int32)
+    if t > 0:   # teacher forcing: device f32 state := f32(reference-precision f64 state)
+      if family == 'mountain_car':
+        st32 = np.stack([orc.s['position'], orc.s['velocity']]).astype(np.float32)
+        k = orc.s['timestep'].astype(np.int32)
+      else:
+        st32 = orc.s['state'][:, :4].T.astype(np.float32)
+        k = np.rint(orc.s['state'][:, 4] / orc.cfg.timescale).astype(np.int32)
+      r_env._state['state'].copy_(torch.from_numpy(np.ascontiguousarray(st32)).cuda())
+      steps = k | (orc.reset_next.astype(np.int32) << 30)
+      r_env._state['steps'].copy_(torch.from_numpy(steps).cuda())
+    ts = env.step(torch.from_numpy(a).cuda())
+    st, r, d, o = orc.call(a, t)
+    gst, gr, gd, go = eu.to_np(ts)
+    same = gst == st
+    flips += int((~same).sum())          # threshold ties within tolerance may flip a LAST
+    live = (st != 0) & same
+    np.testing.assert_allclose(go[same], o[same], rtol=1e-6, atol=1e-6, err_msg=f'obs t={t}')
+    np.testing.assert_allclose(gr[live], r[live], rtol=1e-6, atol=1e-6, err_msg=f'reward t={t}')
+  assert flips <= 2, flips
