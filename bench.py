@@ -41,6 +41,18 @@ def algorithmic_bytes_per_step(obs_numel, state_bytes):
   return 4 + 4 + 4 + 1 + 4 * obs_numel + state_bytes
 
 
+def pmc_traffic(workload, lanes):
+  """HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/rNN/<w>_pmc_traffic.json:
+  WRITE_SIZE and FETCH_SIZE collected in separate runs, gfx950 corrections applied there)."""
+  import glob
+  hits = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*', f'{workload}_pmc_traffic.json')))
+  if not hits or lanes != (1 << 20):
+    return None, None
+  with open(hits[-1]) as f:
+    d = json.load(f)
+  return d['per_launch']['hbm_bytes'], os.path.relpath(hits[-1], ROOT)
+
+
 def cpu_baseline(family, kwargs, num_actions, budget_s=12.0):
   """The oracle (C restatement of the reference's numpy step) on ONE host core, bounded sample."""
   import numpy as np
@@ -142,8 +154,8 @@ def main():
   # Pure-store ceiling of THIS box (same 16-B cooperative store shape, no other work): context for
   # the roofline fraction of the store-bound families.  Not part of the timed region.
   from bsuite_amd import _native
-  scratch = env._out[0]['observation'] if hasattr(env, '_out') else env.raw_env._out[0]['observation']
-  nbytes = (scratch.numel() * 4) // 16 * 16
+  scratch = torch.empty(1 << 31, dtype=torch.uint8, device=dev)   # 2 GiB: far beyond L2 + Infinity Cache
+  nbytes = scratch.numel()
   stream_h = torch.cuda.current_stream(dev).cuda_stream
   for _ in range(3):
     _native.lib.bsx_calib_fill(scratch.data_ptr(), nbytes, 0, stream_h)
@@ -156,25 +168,21 @@ def main():
   torch.cuda.synchronize(dev)
   store_ceiling_gbps = nbytes * 10 / (c0.elapsed_time(c1) * 1e-3) / 1e9
 
-  # end-of-rollout summary: per-rank [episodes finished, episodes started, sum of info columns]
-  counters = env.episode_counters().to(torch.float64)
-  info_sums = torch.stack([v.sum() for v in env.bsuite_info().values()]) if env.bsuite_info() else counters[:0]
-  summary = torch.cat([counters, info_sums])
+  # end-of-rollout summary: the only collective on the path (RCCL all-gather over xGMI)
+  from bsuite_amd import distributed as bdist
+  vec, names = bdist.local_summary(env)
+  gathered = bdist.all_gather_summary(vec)
+  summary = bdist.reduce_summary(gathered, names)
   if world > 1:
-    gathered = torch.empty((world,) + summary.shape, dtype=summary.dtype, device=dev)
-    dist.all_gather_into_tensor(gathered, summary)       # RCCL all-gather over xGMI
-    t_wall = torch.tensor([wall], dtype=torch.float64, device=dev)
+    t_wall = torch.tensor([wall, kernel_ms], dtype=torch.float64, device=dev)
     dist.all_reduce(t_wall, op=dist.ReduceOp.MAX)
-    wall = float(t_wall.item())
-    k_ms = torch.tensor([kernel_ms], dtype=torch.float64, device=dev)
-    dist.all_reduce(k_ms, op=dist.ReduceOp.MAX)
-    kernel_ms = float(k_ms.item())
-    summary = gathered.sum(0)
+    wall, kernel_ms = float(t_wall[0].item()), float(t_wall[1].item())
 
   if rank == 0:
     total_steps = B * world * args.steps
     bytes_per_step = algorithmic_bytes_per_step(obs_numel, state_bytes)
     achieved = bytes_per_step * B / (kernel_ms * 1e-3) / 1e9
+    traffic, traffic_src = pmc_traffic(args.workload, B)
     line = {
         'metric': 'env-steps/sec', 'value': total_steps / wall, 'unit': 'env-steps/s',
         'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
@@ -185,12 +193,13 @@ def main():
                    'lanes_per_gpu': B, 'global_lanes': B * world, 'sharding': f'lanes x{world}',
                    'bytes_per_env_step': bytes_per_step},
         'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBPS, 'unit': 'GB/s',
-                     'frac': achieved / HBM_PEAK_GBPS, 'traffic': None,
+                     'frac': achieved / HBM_PEAK_GBPS, 'traffic': traffic,
+                     'traffic_source': traffic_src, 'algorithmic_bytes_per_launch': bytes_per_step * B,
                      'kernel_ms': kernel_ms,
                      'box_store_ceiling_GBps': store_ceiling_gbps,
                      'frac_of_box_store_ceiling': achieved / store_ceiling_gbps},
         'launch': f'hipGraph x{args.graph}' if args.graph else 'eager',
-        'episodes_finished': float(summary[0].item()),
+        'episodes_finished': summary['episodes_finished'],
     }
     if world == 1 and not args.no_cpu_baseline:
       line['cpu_baseline'] = cpu_baseline(family, okw, num_actions)

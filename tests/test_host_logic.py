@@ -1,0 +1,116 @@
+"""CPU: host-side logic of the drop-in surface — sweep tables, loader registry, specs, host-built
+constants (pinned to dumps of the reference under tests/golden/), sharding arithmetic."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import bsuite_amd
+from bsuite_amd import sweep
+from bsuite_amd.environments import bandit, cartpole, deep_sea, discounting_chain
+from tests import golden_util as gu
+
+
+def test_sweep_matches_reference_dump():
+  g = json.load(open(os.path.join(gu.GOLDEN_DIR, 'sweep.json')))
+  assert list(sweep.SWEEP) == g['SWEEP'] and len(sweep.SWEEP) == 468
+  assert list(sweep.TESTING) == g['TESTING']
+  assert {k: dict(v) for k, v in sweep.SETTINGS.items()} == g['SETTINGS']
+  assert dict(sweep.EPISODES) == g['EPISODES']
+  assert {k: list(v) for k, v in sweep.TAGS.items()} == g['TAGS']
+  assert sweep.DEEP_SEA[10] == 'deep_sea/10' and sweep.SETTINGS['deep_sea/10']['size'] == 30
+  with pytest.raises(TypeError):
+    sweep.SETTINGS['catch/0'] = {}     # immutable, like the reference's immutabledict
+
+
+def test_host_constants_match_reference():
+  c = np.load(os.path.join(gu.GOLDEN_DIR, 'host_constants.npz'))
+  import warnings
+  for n in list(range(10, 51, 2)) + [7]:
+    for ms in (42, 3):
+      env = deep_sea.DeepSea(n, mapping_seed=ms)
+      want = c[f'deep_sea_mapping_{n}_{ms}']
+      np.testing.assert_array_equal(np.asarray(env._action_mapping, np.uint8), want)
+      bits = np.array([(env._cfg.mapping_bits[i >> 5] >> (i & 31)) & 1 for i in range(n * n)])
+      np.testing.assert_array_equal(bits, want.reshape(-1))
+      assert env._cfg.move_cost == 0.01 / n and env._cfg.inv_size == 1 / n
+  assert deep_sea.DeepSea(30, mapping_seed=42).optimal_return == float(c['deep_sea_optimal_return_30_1'])
+  assert deep_sea.DeepSea(30, deterministic=False, mapping_seed=42).optimal_return == float(
+      c['deep_sea_optimal_return_30_0'])
+  for ms in range(20):
+    np.testing.assert_array_equal(bandit.SimpleBandit(ms)._rewards, c[f'bandit_rewards_{ms}'])
+    np.testing.assert_array_equal(discounting_chain.DiscountingChain(ms)._rewards, c[f'discounting_rewards_{ms}'])
+  with warnings.catch_warnings():
+    warnings.simplefilter('ignore')
+    assert (deep_sea.DeepSea(8, randomize_actions=False)._action_mapping == 1).all()
+
+
+def test_known_answers_from_the_survey():
+  m = deep_sea.DeepSea(30, mapping_seed=42)._action_mapping
+  assert m.sum() == 451 and list(m[0, :10]) == [0, 1, 1, 1, 0, 0, 0, 1, 1, 1]
+  assert list(bandit.SimpleBandit(0)._rewards) == [0.4, 0.9, 0.2, 1.0, 0.6000000000000001, 0.1,
+                                                   0.7000000000000001, 0.8, 0.30000000000000004, 0.0, 0.5]
+  assert list(discounting_chain.DiscountingChain(3)._rewards) == [1, 1, 1, 1.1, 1]
+
+
+def test_cartpole_time_table_replays_the_f64_running_sum():
+  env = cartpole.Cartpole()
+  assert env._last_step == 1001            # the reference times out at step 1001, not 1000
+  t = 0.0
+  for k in range(1, 1002):
+    t += 0.01
+    assert env._time_frac_host[k] == np.float32(t / 10.0)
+  assert cartpole.Cartpole(max_time=0.05)._last_step == 6   # f64 sum of five 0.01 steps is not > 0.05
+
+
+def test_loader_builds_every_non_mnist_id_with_reference_specs():
+  shapes = dict(bandit=(1, 1), catch=(10, 5), cartpole=(1, 6), cartpole_swingup=(1, 8),
+                discounting_chain=(1, 2), mountain_car=(1, 3))
+  actions = dict(bandit=11, catch=3, cartpole=3, cartpole_swingup=3, deep_sea=2, memory=2, umbrella=2,
+                 discounting_chain=5, mountain_car=3)
+  for bid in sweep.SWEEP:
+    name = bid.split('/')[0]
+    if name.startswith('mnist'):
+      with pytest.raises(NotImplementedError):
+        bsuite_amd.load_from_id(bid)
+      continue
+    env = bsuite_amd.load_from_id(bid)
+    assert env.bsuite_num_episodes == sweep.EPISODES[bid] > 0
+    spec = env.observation_spec()
+    base = name.replace('_noise', '').replace('_scale', '').replace('_stochastic', '')
+    if base in shapes:
+      assert spec.shape == shapes[base], bid
+    if base == 'deep_sea':
+      n = sweep.SETTINGS[bid]['size']
+      assert spec.shape == (n, n)
+    assert spec.dtype == np.float32
+    key = next(k for k in actions if base.startswith(k))
+    assert env.action_spec().num_values == actions[key], bid
+    if name.endswith(('_noise', '_scale')):
+      assert env.raw_env is not env and hasattr(env.raw_env, 'bsuite_info')
+  assert bsuite_amd.load_from_id('catch/0').action_spec().dtype == np.dtype(int)
+  assert bsuite_amd.load_from_id('cartpole_swingup/3').observation_spec().name == 'state'
+  with pytest.raises(KeyError):
+    bsuite_amd.load_from_id('nonexistent/0')
+  with pytest.raises(ValueError):
+    bsuite_amd.load_and_record('catch/0', '/tmp/x', logging_mode='sqlite')
+
+
+@pytest.mark.skipif(torch.cuda.is_available(), reason='only meaningful without a GPU')
+def test_no_cpu_fallback():
+  env = bsuite_amd.load_from_id('catch/0')
+  with pytest.raises(RuntimeError, match='no CPU fallback'):
+    env.reset()
+
+
+def test_shard_lanes_partitions_exactly():
+  from bsuite_amd.distributed import shard_lanes
+  for total in (0, 1, 7, 1 << 20, (1 << 20) + 5):
+    for world in (1, 2, 3, 8):
+      spans = [shard_lanes(total, r, world) for r in range(world)]
+      assert spans[0][0] == 0 and sum(n for _, n in spans) == total
+      for (o0, n0), (o1, _) in zip(spans, spans[1:]):
+        assert o0 + n0 == o1
+      assert max(n for _, n in spans) - min(n for _, n in spans) <= 1
