@@ -178,98 +178,99 @@ __device__ __forceinline__ void bsx_write_hot_tile(float* __restrict__ tile, int
 
 // ---------------------------------------------------------------------------------------------
 // Split-phase observation writer: a pure store stream over the whole [B x cells] observation
-// array, decoupled from the lane-advance kernel.  Every block writes one 16 KiB run (4 stores of
-// 16 B per thread, lane-interleaved), blocks are dispatched in address order, so at any instant
-// the chip writes one compact window of HBM — the access pattern that reached 6.8-7.1 TB/s in the
-// fill calibration (profiles/r01_store_calibration2.log), against ~5.5 TB/s for per-block tiles
-// spaced hundreds of KB apart.  The hot cells are recomputed from the packed state column the
-// advance kernel has just written (4 B per lane, L2-resident).
+// array, decoupled from the lane-advance kernel.  Block b writes the K*4 KiB run of floats
+// [b*K*1024, (b+1)*K*1024): K lane-interleaved 16-byte stores per thread, blocks in address order,
+// no loop — the shape of the fastest fill kernels measured on MI355X (profiles/r01/
+// store_calibration*.log).  The hot cells are recomputed from the packed state column the advance
+// kernel has just written (4 B per lane, L2-resident).
 //
-// Index space: lanes are grouped in super-tiles of 256 lanes so in-tile float offsets fit the
-// 32-bit magic division; blockIdx.x = super_tile * subs_per_super + sub.
-#define BSX_SUPER 256
-#define BSX_STREAM_CHUNKS 1024   // 16-B chunks per block = 16 KiB
+// Index math: the block's first float F0 = b*K*1024 is split once per block into (lane, offset)
+// with an exact 64-bit magic division on the scalar unit; per-thread offsets stay < 2^14 so a
+// 32-bit magic division is exact.
+struct bsx_div64 {            // n / d = __umul64hi(n, m) >> s, exact for n*d < 2^(64+s), d >= 4
+  uint64_t m;
+  uint32_t s;
+};
 
-template <class HotFn>
-__global__ void __launch_bounds__(BSX_BLOCK) bsx_hot_stream_kernel(float* __restrict__ obs,
+template <class HotFn, int K, int BS>
+__global__ void __launch_bounds__(BS) bsx_hot_stream_kernel(float* __restrict__ obs,
                                                                    const int32_t* __restrict__ state,
                                                                    int64_t n_lanes, uint32_t cells,
-                                                                   uint32_t cells_magic,
-                                                                   uint32_t subs_per_super, HotFn fn) {
-  const uint32_t super = blockIdx.x / subs_per_super;
-  const uint32_t sub = blockIdx.x - super * subs_per_super;
-  const int64_t lane0 = (int64_t)super * BSX_SUPER;
-  const int64_t remaining = n_lanes - lane0;
-  const uint32_t lanes_here = remaining < BSX_SUPER ? (uint32_t)remaining : BSX_SUPER;
-  const uint32_t total = lanes_here * cells;
-  const uint32_t n_chunks = total >> 2;
+                                                                   uint32_t cells_magic, bsx_div64 dv,
+                                                                   HotFn fn) {
+  const uint64_t total = (uint64_t)n_lanes * cells;                      // floats in the array
+  const uint64_t F0 = (uint64_t)blockIdx.x * (uint64_t)(K * 4 * BS);
+  const uint64_t lane_b = __umul64hi(F0, dv.m) >> dv.s;                  // uniform
+  const uint32_t r_b = (uint32_t)(F0 - lane_b * cells);                  // < cells
   const bool aligned = (cells & 3u) == 0;
-  float* __restrict__ tile = obs + lane0 * (int64_t)cells;
-  bsx_f4* __restrict__ t4 = reinterpret_cast<bsx_f4*>(tile);
-  const int32_t* __restrict__ st = state + lane0;
+  bsx_f4* __restrict__ o4 = reinterpret_cast<bsx_f4*>(obs + F0);
+  const int32_t* __restrict__ st = state + lane_b;
+  const uint64_t lanes_left = (uint64_t)n_lanes - lane_b;                // lanes at or after lane_b
 
-  uint32_t ch[4];
-  uint32_t l[4];
-  int32_t s0[4], s1[4];
+  uint32_t dl[K];
+  int r0[K];
+  int32_t s0[K], s1[K];
+  bool live[K];
 #pragma unroll
-  for (int u = 0; u < 4; ++u) {
-    ch[u] = sub * BSX_STREAM_CHUNKS + threadIdx.x + u * BSX_BLOCK;
-    const uint32_t f0 = ch[u] << 2;
-    l[u] = bsx_div_cells(f0, cells, cells_magic);
-    const bool live = ch[u] < n_chunks;
-    s0[u] = live ? st[l[u]] : 0;
-    s1[u] = (live && !aligned && l[u] + 1 < lanes_here) ? st[l[u] + 1] : 0;
+  for (int u = 0; u < K; ++u) {
+    const uint32_t c = threadIdx.x + u * BS;                      // chunk within the block
+    const uint32_t f = r_b + (c << 2);                                   // float offset from lane_b's row start
+    dl[u] = __umulhi(f, cells_magic);
+    r0[u] = (int)(f - dl[u] * cells);
+    live[u] = F0 + ((uint64_t)c << 2) + 3 < total;
+    s0[u] = live[u] ? st[dl[u]] : 0;
+    s1[u] = (live[u] && !aligned && (uint64_t)dl[u] + 1 < lanes_left) ? st[dl[u] + 1] : 0;
   }
 #pragma unroll
-  for (int u = 0; u < 4; ++u) {
-    if (ch[u] >= n_chunks) continue;
-    const uint32_t f0 = ch[u] << 2;
+  for (int u = 0; u < K; ++u) {
+    if (!live[u]) continue;
+    int ha, hb;
+    fn(s0[u], ha, hb);
+    const int a0 = ha < 0 ? -1 : ha - r0[u], b0 = hb < 0 ? -1 : hb - r0[u];
     bsx_f4 v;
-    if (cells < 4u) {
-      float e[4];
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const uint32_t f = f0 + j;
-        const uint32_t lj = bsx_div_cells(f, cells, cells_magic);
-        const int r = (int)(f - lj * cells);
-        int ha, hb;
-        fn(st[lj], ha, hb);
-        e[j] = (ha == r || hb == r) ? 1.0f : 0.0f;
-      }
-      bsx_f4 t = {e[0], e[1], e[2], e[3]};
-      v = t;
-    } else {
-      const int r0 = (int)(f0 - l[u] * cells);
-      int ha, hb;
-      fn(s0[u], ha, hb);
-      const int a0 = ha - r0, b0 = hb < 0 ? -1 : hb - r0;
-      v.x = (a0 == 0 || b0 == 0) ? 1.0f : 0.0f;
-      v.y = (a0 == 1 || b0 == 1) ? 1.0f : 0.0f;
-      v.z = (a0 == 2 || b0 == 2) ? 1.0f : 0.0f;
-      v.w = (a0 == 3 || b0 == 3) ? 1.0f : 0.0f;
-      const int over = (int)cells - r0;
-      if (!aligned && over < 4) {           // elements j >= over belong to lane l+1
-        int na, nb;
-        fn(s1[u], na, nb);
-        const int a1 = na < 0 ? -1 : na + over, b1 = nb < 0 ? -1 : nb + over;
-        if (over <= 1) v.y = (a1 == 1 || b1 == 1) ? 1.0f : 0.0f;
-        if (over <= 2) v.z = (a1 == 2 || b1 == 2) ? 1.0f : 0.0f;
-        v.w = (a1 == 3 || b1 == 3) ? 1.0f : 0.0f;
-      }
+    v.x = (a0 == 0 || b0 == 0) ? 1.0f : 0.0f;
+    v.y = (a0 == 1 || b0 == 1) ? 1.0f : 0.0f;
+    v.z = (a0 == 2 || b0 == 2) ? 1.0f : 0.0f;
+    v.w = (a0 == 3 || b0 == 3) ? 1.0f : 0.0f;
+    const int over = (int)cells - r0[u];
+    if (!aligned && over < 4) {             // elements j >= over belong to the next lane's row
+      int na, nb;
+      fn(s1[u], na, nb);
+      const int a1 = na < 0 ? -1 : na + over, b1 = nb < 0 ? -1 : nb + over;
+      if (over <= 1) v.y = (a1 == 1 || b1 == 1) ? 1.0f : 0.0f;
+      if (over <= 2) v.z = (a1 == 2 || b1 == 2) ? 1.0f : 0.0f;
+      v.w = (a1 == 3 || b1 == 3) ? 1.0f : 0.0f;
     }
-    t4[ch[u]] = v;
+    o4[threadIdx.x + u * BS] = v;
   }
-  // ragged tail (< 4 floats) of an odd-sized final super-tile: done by its last sub-block
-  if (sub == subs_per_super - 1) {
-    const uint32_t f = (n_chunks << 2) + threadIdx.x;
-    if (f < total) {
-      const uint32_t lj = bsx_div_cells(f, cells, cells_magic);
-      const int r = (int)(f - lj * cells);
+  // ragged tail (< 4 floats) of an odd-sized array: the block that contains the array's end
+  const uint64_t tail0 = total & ~3ull;
+  if (tail0 != total && tail0 >= F0 && tail0 < F0 + (uint64_t)(K * 4 * BS) && threadIdx.x < 3) {
+    const uint64_t F = tail0 + threadIdx.x;
+    if (F < total) {
+      const uint32_t f = r_b + (uint32_t)(F - F0);
+      const uint32_t d = __umulhi(f, cells_magic);
+      const int r = (int)(f - d * cells);
       int ha, hb;
-      fn(st[lj], ha, hb);
-      tile[f] = (ha == r || hb == r) ? 1.0f : 0.0f;
+      fn(st[d], ha, hb);
+      obs[F] = (ha == r || hb == r) ? 1.0f : 0.0f;
     }
   }
+}
+
+// Degenerate boards (cells < 4: a 16-byte chunk spans several lanes): one float per thread.
+template <class HotFn>
+__global__ void __launch_bounds__(BSX_BLOCK) bsx_hot_stream_tiny_kernel(float* __restrict__ obs,
+                                                                        const int32_t* __restrict__ state,
+                                                                        int64_t n_lanes, uint32_t cells,
+                                                                        HotFn fn) {
+  const uint64_t F = (uint64_t)blockIdx.x * BSX_BLOCK + threadIdx.x;
+  if (F >= (uint64_t)n_lanes * cells) return;
+  const uint64_t lane = F / cells;
+  const int r = (int)(F - lane * cells);
+  int ha, hb;
+  fn(state[lane], ha, hb);
+  obs[F] = (ha == r || hb == r) ? 1.0f : 0.0f;
 }
 
 #endif  // BSX_DEVICE_H_

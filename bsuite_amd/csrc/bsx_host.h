@@ -42,13 +42,50 @@ static inline int bsx_env_int(const char* name, int dflt) {
   return (v != nullptr && *v != '\0') ? atoi(v) : dflt;
 }
 
-// Launch geometry of bsx_hot_stream_kernel for n_lanes lanes of `cells` floats.
-static inline int bsx_stream_grid(int64_t n_lanes, uint32_t cells, uint32_t* subs_per_super, int64_t* blocks) {
-  const uint32_t chunks_per_super = (BSX_SUPER * cells + 3u) >> 2;
-  *subs_per_super = (chunks_per_super + BSX_STREAM_CHUNKS - 1) / BSX_STREAM_CHUNKS;
-  const int64_t supers = (n_lanes + BSX_SUPER - 1) / BSX_SUPER;
-  *blocks = supers * (int64_t)(*subs_per_super);
-  return *blocks > 0x7FFFFFFF ? BSX_EINVAL : 0;
+// Exact 64-bit magic for n / d (4 <= d <= 4096, n < 2^52): s = floor(log2 d) - 1.
+static inline bsx_div64 bsx_make_div64(uint32_t d) {
+  bsx_div64 r;
+  uint32_t lg = 0;
+  while ((2u << lg) <= d) ++lg;             // lg = floor(log2 d)
+  r.s = lg - 1;
+  const unsigned __int128 num = (unsigned __int128)1 << (64 + r.s);
+  r.m = (uint64_t)(num / d) + 1;
+  return r;
+}
+
+// Launches the split-phase observation writer with K stores per thread (BSX_STREAM_K).
+template <class HotFn>
+static inline int bsx_launch_hot_stream(float* obs, const int32_t* state, int64_t n_lanes, uint32_t cells,
+                                        uint32_t cells_magic, HotFn fn, hipStream_t st, int default_k) {
+  static const int k_env = bsx_env_int("BSX_STREAM_K", 0);
+  const int k = k_env > 0 ? k_env : default_k;
+  const uint64_t total = (uint64_t)n_lanes * cells;
+  if (cells < 4u) {
+    const uint64_t blocks = (total + BSX_BLOCK - 1) / BSX_BLOCK;
+    if (blocks > 0x7FFFFFFFull) return BSX_EINVAL;
+    bsx_hot_stream_tiny_kernel<HotFn><<<dim3((unsigned)blocks), dim3(BSX_BLOCK), 0, st>>>(obs, state, n_lanes, cells, fn);
+    return 0;
+  }
+  static const int bs_env = bsx_env_int("BSX_STREAM_BS", 256);
+  static const int ks[] = {1, 2, 3, 4, 5, 6, 8, 12, 16};
+  int kk = 1;
+  for (int i = 0; i < 9; ++i) if (ks[i] <= k) kk = ks[i];
+  const int bs = bs_env >= 1024 ? 1024 : bs_env >= 512 ? 512 : bs_env >= 256 ? 256 : bs_env >= 128 ? 128 : 64;
+  const uint64_t per_block = (uint64_t)kk * 4 * bs;
+  const uint64_t blocks = (total + per_block - 1) / per_block;
+  if (blocks > 0x7FFFFFFFull) return BSX_EINVAL;
+  const bsx_div64 dv = bsx_make_div64(cells);
+  const dim3 g((unsigned)blocks);
+#define BSX_HS(KK, BS) case KK: bsx_hot_stream_kernel<HotFn, KK, BS><<<g, dim3(BS), 0, st>>>(obs, state, n_lanes, cells, cells_magic, dv, fn); break
+#define BSX_HS_ALL(BS) switch (kk) { BSX_HS(1, BS); BSX_HS(2, BS); BSX_HS(3, BS); BSX_HS(4, BS); BSX_HS(5, BS); BSX_HS(6, BS); BSX_HS(8, BS); BSX_HS(12, BS); BSX_HS(16, BS); default: return BSX_EINVAL; }
+  if (bs == 256) { BSX_HS_ALL(256) }
+  else if (bs == 128) { BSX_HS_ALL(128) }
+  else if (bs == 512) { BSX_HS_ALL(512) }
+  else if (bs == 1024) { BSX_HS_ALL(1024) }
+  else { BSX_HS_ALL(64) }
+#undef BSX_HS_ALL
+#undef BSX_HS
+  return 0;
 }
 
 static inline int bsx_launch_status() { return (int)hipGetLastError(); }

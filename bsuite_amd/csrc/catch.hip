@@ -101,14 +101,12 @@ extern "C" int bsx_catch_step(const bsx_catch_t* cfg, const bsx_call_t* call, co
   const int64_t blocks = (call->n_lanes + LPB - 1) / LPB;
   if (blocks > 0x7FFFFFFF) return BSX_EINVAL;
   hipStream_t st = (hipStream_t)call->hip_stream;
-  static const int split = bsx_env_int("BSX_CATCH_SPLIT", 0);
+  static const int split = bsx_env_int("BSX_CATCH_SPLIT", 1);
   if (split) {
-    uint32_t subs; int64_t blocks_b;
-    if (bsx_stream_grid(call->n_lanes, a.cells, &subs, &blocks_b) != 0) return BSX_EINVAL;
     catch_step_kernel<LPB, false><<<dim3((unsigned)blocks), dim3(BSX_BLOCK), 0, st>>>(a);
     catch_hot fn{cfg->rows, cfg->columns};
-    bsx_hot_stream_kernel<catch_hot><<<dim3((unsigned)blocks_b), dim3(BSX_BLOCK), 0, st>>>(
-        out.observation, state, call->n_lanes, a.cells, a.cells_magic, subs, fn);
+    rc = bsx_launch_hot_stream(out.observation, state, call->n_lanes, a.cells, a.cells_magic, fn, st, 2);
+    if (rc != 0) return rc;
     return bsx_launch_status();
   }
   catch_step_kernel<LPB, true><<<dim3((unsigned)blocks), dim3(BSX_BLOCK), 0, st>>>(a);

@@ -2,13 +2,18 @@
 // (`_get_observation`, `_reset`, `_step`) plus the auto-reset of bsuite/environments/base.py:54-65.
 //
 // Shape of the work at the headline config (N=30, B=2^20): 21 B of scalar traffic and 3600 B of
-// observation stores per lane per call — a pure store stream.  So:
-//   phase 0  the N*N-bit action mapping goes kernarg -> LDS once per block (lane-divergent lookup);
-//   phase 1  one wavefront-sized group of threads advances LPB lanes (coalesced column loads and
-//            stores of action / packed state / reward / discount / step_type), publishes each
-//            lane's hot cell to LDS and ballots the LAST/FIRST masks;
-//   phase 2  all 256 threads stream the block's contiguous [LPB x N*N] f32 tile with 16-byte
-//            stores, consecutive threads on consecutive chunks (bsx_write_hot_tile).
+// observation stores per lane per call — a pure store stream.  Two launches per call (default):
+//   advance  deep_sea_step_kernel<256,1,false>: the N*N-bit action mapping goes kernarg -> LDS once
+//            per block (lane-divergent lookup); every thread advances one lane (coalesced column
+//            loads/stores of action / packed state / reward / discount / step_type), LAST/FIRST
+//            masks by wavefront ballot;
+//   observe  bsx_hot_stream_kernel<deep_sea_hot,4,256>: a pure store stream over [B x N*N] f32 —
+//            block b writes floats [b*4096,(b+1)*4096) as 4 lane-interleaved 16-byte stores per
+//            thread, hot cells recomputed from the packed state column (4 B/lane, L2-resident).
+//            Measured 6.2-6.3 TB/s at N=30, B=2^20 against 5.3-5.5 TB/s for the fused per-block
+//            tile writer (profiles/r01/sweep_stream_k.log, ab_fused_vs_split*.log).
+// BSX_DS_SPLIT=0 selects the fused single-kernel variant (phase 1 on LPB lanes, then all 256
+// threads stream the block's contiguous [LPB x N*N] tile, bsx_write_hot_tile), kept for A/B.
 #include "bsx_host.h"
 
 struct deep_sea_args {
@@ -134,16 +139,15 @@ extern "C" int bsx_deep_sea_step(const bsx_deep_sea_t* cfg, const bsx_call_t* ca
   // Tile = LPB lanes: 64 lanes x 3600 B = 230 KB per block at N=30 -> 16384 blocks at B=2^20,
   // enough to keep 256 CUs x 8 resident blocks busy with a short tail.  BSX_DS_LPB / BSX_DS_UNROLL
   // are tuning knobs for the A/B sweeps recorded under profiles/ (defaults = measured best).
-  static const int split = bsx_env_int("BSX_DS_SPLIT", 0);
+  static const int split = bsx_env_int("BSX_DS_SPLIT", 1);
   if (split) {
     // advance kernel (all 256 threads own a lane) + pure streaming observation writer
     const int64_t blocks_a = (call->n_lanes + 255) / 256;
-    uint32_t subs; int64_t blocks_b;
-    if (blocks_a > 0x7FFFFFFF || bsx_stream_grid(call->n_lanes, a.cells, &subs, &blocks_b) != 0) return BSX_EINVAL;
+    if (blocks_a > 0x7FFFFFFF) return BSX_EINVAL;
     deep_sea_step_kernel<256, 1, false><<<dim3((unsigned)blocks_a), dim3(BSX_BLOCK), 0, st>>>(a);
     deep_sea_hot fn{cfg->size};
-    bsx_hot_stream_kernel<deep_sea_hot><<<dim3((unsigned)blocks_b), dim3(BSX_BLOCK), 0, st>>>(
-        out.observation, state, call->n_lanes, a.cells, a.cells_magic, subs, fn);
+    rc = bsx_launch_hot_stream(out.observation, state, call->n_lanes, a.cells, a.cells_magic, fn, st, 4);
+    if (rc != 0) return rc;
     return bsx_launch_status();
   }
   static const int lpb = bsx_env_int("BSX_DS_LPB", 64);

@@ -15,22 +15,16 @@ extern "C" const char* bsx_strerror(int code) {
   }
 }
 
-// Pure-store calibration.  Same store shape as the observation writers (consecutive threads write
-// consecutive 16-byte chunks, 4 independent stores per thread per iteration, 16 KiB per block
-// iteration, blocks in address order) with no other work: what this reaches is the practical
-// ceiling of a dense-observation step on the box it runs on.
+// Pure-store calibration: one 16-byte store per thread, block b writes the 4 KiB run b, no loop —
+// the fastest plain fill shape found on MI355X (it matches torch's fill kernel at ~6.8-6.9 TB/s on
+// boxes where a 4-stores-per-thread grid-stride fill reaches 5.8-6.0; profiles/r01/
+// store_calibration4_noloop.log).  What this reaches is the practical ceiling for a dense
+// observation stream on the box it runs on.
 template <bool NT>
 __global__ void __launch_bounds__(BSX_BLOCK) calib_fill_kernel(bsx_f4* __restrict__ p, int64_t n16) {
   const bsx_f4 z = {0.f, 0.f, 0.f, 0.f};
-  const int64_t tile = 4 * BSX_BLOCK;
-  for (int64_t base = (int64_t)blockIdx.x * tile; base < n16; base += (int64_t)gridDim.x * tile) {
-    const int64_t i = base + threadIdx.x;
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      const int64_t j = i + (int64_t)k * BSX_BLOCK;
-      if (j < n16) { if (NT) __builtin_nontemporal_store(z, &p[j]); else p[j] = z; }
-    }
-  }
+  const int64_t i = (int64_t)blockIdx.x * BSX_BLOCK + threadIdx.x;
+  if (i < n16) { if (NT) __builtin_nontemporal_store(z, &p[i]); else p[i] = z; }
 }
 
 extern "C" int bsx_calib_fill(void* dst, int64_t n_bytes, int32_t nontemporal, void* hip_stream) {
@@ -39,8 +33,8 @@ extern "C" int bsx_calib_fill(void* dst, int64_t n_bytes, int32_t nontemporal, v
   if ((reinterpret_cast<uintptr_t>(dst) & 15u) != 0) return BSX_EALIGN;
   if (n_bytes == 0) return 0;
   const int64_t n16 = n_bytes / 16;
-  int64_t blocks = (n16 + 4 * BSX_BLOCK - 1) / (4 * BSX_BLOCK);
-  if (blocks > 65536) blocks = 65536;
+  const int64_t blocks = (n16 + BSX_BLOCK - 1) / BSX_BLOCK;
+  if (blocks > 0x7FFFFFFF) return BSX_EINVAL;
   hipStream_t st = (hipStream_t)hip_stream;
   if (nontemporal) calib_fill_kernel<true><<<dim3((unsigned)blocks), dim3(BSX_BLOCK), 0, st>>>((bsx_f4*)dst, n16);
   else calib_fill_kernel<false><<<dim3((unsigned)blocks), dim3(BSX_BLOCK), 0, st>>>((bsx_f4*)dst, n16);
