@@ -44,7 +44,7 @@ struct deep_sea_hot {
   }
 };
 
-template <int LPB, int UNROLL, bool FUSED>
+template <int LPB, int UNROLL, int FUSED>
 __global__ void __launch_bounds__(BSX_BLOCK) deep_sea_step_kernel(const deep_sea_args a) {
   __shared__ uint32_t s_map[BSX_DEEP_SEA_MAX_SIZE * BSX_DEEP_SEA_MAX_SIZE / 32];
   __shared__ int s_hot[LPB];
@@ -110,7 +110,7 @@ __global__ void __launch_bounds__(BSX_BLOCK) deep_sea_step_kernel(const deep_sea
   }
   __syncthreads();
   bsx_flush_counts(a.ctl, s_cnt);
-  if (!FUSED) return;
+  if (FUSED != 1) return;
 
   bsx_write_hot_tile<false, UNROLL>(a.out.observation + lane0 * (int64_t)a.cells, lanes_here, a.cells,
                             a.cells_magic, s_hot, nullptr);
@@ -144,7 +144,7 @@ extern "C" int bsx_deep_sea_step(const bsx_deep_sea_t* cfg, const bsx_call_t* ca
     // advance kernel (all 256 threads own a lane) + pure streaming observation writer
     const int64_t blocks_a = (call->n_lanes + 255) / 256;
     if (blocks_a > 0x7FFFFFFF) return BSX_EINVAL;
-    deep_sea_step_kernel<256, 1, false><<<dim3((unsigned)blocks_a), dim3(BSX_BLOCK), 0, st>>>(a);
+    deep_sea_step_kernel<256, 1, 0><<<dim3((unsigned)blocks_a), dim3(BSX_BLOCK), 0, st>>>(a);
     deep_sea_hot fn{cfg->size};
     rc = bsx_launch_hot_stream(out.observation, state, call->n_lanes, a.cells, a.cells_magic, fn, st, 4);
     if (rc != 0) return rc;
@@ -156,7 +156,7 @@ extern "C" int bsx_deep_sea_step(const bsx_deep_sea_t* cfg, const bsx_call_t* ca
   do {                                                                                      \
     const int64_t blocks = (call->n_lanes + (L) - 1) / (L);                                 \
     if (blocks > 0x7FFFFFFF) return BSX_EINVAL;                                             \
-    deep_sea_step_kernel<L, U, true><<<dim3((unsigned)blocks), dim3(BSX_BLOCK), 0, st>>>(a);      \
+    deep_sea_step_kernel<L, U, 1><<<dim3((unsigned)blocks), dim3(BSX_BLOCK), 0, st>>>(a);      \
   } while (0)
 #define DS_UNROLLS(L)                                              \
   do {                                                             \
