@@ -269,3 +269,4 @@ class Environment(dm_env.EnvironmentBase):
     if self._device_step_counter:
       self._step_base.fill_(self._step_index)
     self._seed = int(d['__seed'])
+    self._call_desc.stream.seed = self._seed

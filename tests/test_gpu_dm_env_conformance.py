@@ -1,0 +1,126 @@
+"""GPU: the scalar (batch=None) view against the dm_env interface contract.
+
+Restates the checks of dm_env.test_utils.EnvironmentTestMixin that every reference
+`bsuite/environments/*_test.py` / `bsuite/experiments/*/*_test.py` runs, on
+the same constructor arguments and the same 100-action sequence recipe
+(`np.random.RandomState(42).choice(valid_actions)`, e.g. environments/catch_test.py:25-35)."""
+import warnings
+
+import numpy as np
+import pytest
+
+import bsuite_amd
+from bsuite_amd import dm_env_compat as dm_env
+from bsuite_amd.environments import (bandit, cartpole, catch, deep_sea, discounting_chain,
+                                     memory_chain, mountain_car, umbrella_chain)
+
+pytestmark = pytest.mark.gpu
+
+
+def _envs():
+  with warnings.catch_warnings():
+    warnings.simplefilter('ignore')
+    return {
+        'deep_sea_10': lambda: deep_sea.DeepSea(10),                                  # deep_sea_test.py:27
+        'deep_sea_5_stochastic': lambda: deep_sea.DeepSea(5, deterministic=False),    # deep_sea_test.py:40
+        'catch': lambda: catch.Catch(rows=10, columns=5),                             # catch_test.py:28
+        'cartpole': lambda: cartpole.Cartpole(seed=22),                               # cartpole_test.py:28
+        'mountain_car': lambda: mountain_car.MountainCar(2),                          # mountain_car_test.py:27
+        'memory_chain': lambda: memory_chain.MemoryChain(memory_length=10, num_bits=3),
+        'umbrella_chain': lambda: umbrella_chain.UmbrellaChain(chain_length=20, n_distractor=22),
+        'bandit': lambda: bandit.SimpleBandit(5),                                     # bandit_test.py:27
+        'discounting_chain': lambda: discounting_chain.DiscountingChain(10),
+        'bandit_noise': lambda: bsuite_amd.load('bandit_noise', dict(noise_scale=1., seed=42, mapping_seed=42)),
+        'catch_scale': lambda: bsuite_amd.load('catch_scale', dict(reward_scale=10., seed=22)),
+        'deep_sea_stochastic': lambda: bsuite_amd.load('deep_sea_stochastic', dict(size=22)),
+        'cartpole_swingup': lambda: cartpole.CartpoleSwingup(seed=42),
+        'catch/0': lambda: bsuite_amd.load_from_id('catch/0'),
+    }
+
+
+@pytest.mark.parametrize('name', sorted(_envs()))
+def test_dm_env_interface(name):
+  env = _envs()[name]()
+  obs_spec, act_spec = env.observation_spec(), env.action_spec()
+  reward_spec, discount_spec = env.reward_spec(), env.discount_spec()
+  valid = list(range(act_spec.num_values))
+  actions = np.random.RandomState(42).choice(valid, 100)
+
+  def check(ts, must_be_first=False):
+    assert isinstance(ts, dm_env.TimeStep)
+    if must_be_first:
+      assert ts.first()
+    obs_spec.validate(ts.observation)
+    assert isinstance(ts.observation, np.ndarray)
+    if ts.first():
+      assert ts.reward is None and ts.discount is None
+    else:
+      reward_spec.validate(np.asarray(ts.reward, dtype=float))
+      discount_spec.validate(np.asarray(ts.discount, dtype=float))
+      assert isinstance(ts.reward, float) and ts.discount in (0.0, 1.0)
+      if ts.last():
+        assert ts.discount == 0.0
+    return ts
+
+  ts = check(env.step(int(actions[0])), must_be_first=True)      # step on a fresh env == reset
+  check(env.reset(), must_be_first=True)
+  was_last, n_last = False, 0
+  for a in actions:
+    ts = check(env.step(int(a)), must_be_first=was_last)          # step after LAST restarts
+    was_last = ts.last()
+    n_last += was_last
+  check(env.reset(), must_be_first=True)
+  info = env.bsuite_info()
+  assert isinstance(info, dict) and all(isinstance(v, (int, float)) for v in info.values())
+  assert env.bsuite_num_episodes > 0
+  if name in ('bandit', 'bandit_noise', 'deep_sea_5_stochastic', 'mountain_car', 'catch'):
+    assert n_last > 0
+
+
+def test_invalid_actions_raise_like_the_reference():
+  with pytest.raises(IndexError):
+    c = catch.Catch()
+    c.reset()
+    c.step(3)                              # catch.py:84 `_ACTIONS[action]`
+  with pytest.raises(IndexError):
+    b = bandit.SimpleBandit(0)
+    b.reset()
+    b.step(11)                             # bandit.py:61 `self._rewards[action]`
+  d = deep_sea.DeepSea(6, mapping_seed=1)
+  d.reset()
+  assert d.step(7).mid()                   # deep_sea accepts any int: != mapping => left (:118)
+  with pytest.raises(NotImplementedError):
+    d._step(0)
+
+
+def test_scalar_view_is_lane_zero_of_the_batched_view():
+  import torch
+  seed, T = 77, 60
+  one = catch.Catch(seed=seed)
+  many = catch.Catch(seed=seed, batch=64)
+  acts = np.random.RandomState(1).choice(3, T)
+  for a in acts:
+    ts1 = one.step(int(a))
+    tsb = many.step(torch.full((64,), int(a), dtype=torch.int32, device='cuda'))
+    assert int(ts1.step_type) == int(tsb.step_type[0].item())
+    np.testing.assert_array_equal(ts1.observation, tsb.observation[0].cpu().numpy())
+    if not ts1.first():
+      assert np.float32(ts1.reward) == tsb.reward[0].item()
+  assert one.bsuite_info()['total_regret'] == many.bsuite_info()['total_regret'][0].item()
+
+
+def test_wrappers_keep_the_reference_surface():
+  env = bsuite_amd.load_from_id('catch_noise/3', seed=5)
+  assert env.raw_env is not env and type(env.raw_env).__name__ == 'Catch'
+  assert env.bsuite_info() == env.raw_env.bsuite_info()
+  assert env._rows == 10                                     # attribute delegation (wrappers.py:308-310)
+  with pytest.raises(NotImplementedError):
+    env._step(0)
+  ts = env.reset()
+  assert ts.first() and ts.reward is None
+  rewards = []
+  for _ in range(30):
+    ts = env.step(1)
+    if not ts.first():
+      rewards.append(ts.reward)
+  assert len(set(rewards)) > 5                               # noise_scale 0.1 perturbs every reward

@@ -1,0 +1,88 @@
+"""GPU: engine-level behaviours around the kernels — output ring buffers, state_dict round trip,
+device-resident call counter and HIP-graph replay, episode counters."""
+import numpy as np
+import pytest
+import torch
+
+from bsuite_amd.environments import catch, deep_sea, umbrella_chain
+from tests import engine_util as eu
+
+pytestmark = pytest.mark.gpu
+
+
+def _acts(n, b, seed=0, na=3):
+  g = torch.Generator(device='cuda')
+  g.manual_seed(seed)
+  return torch.randint(na, (n, b), generator=g, device='cuda', dtype=torch.int32)
+
+
+def test_output_ring_keeps_previous_timestep_valid():
+  env = catch.Catch(seed=1, batch=512, num_buffers=2)
+  a = _acts(3, 512)
+  ts0 = env.step(a[0])
+  snap = ts0.observation.clone()
+  ts1 = env.step(a[1])
+  assert ts1.observation.data_ptr() != ts0.observation.data_ptr()
+  torch.testing.assert_close(ts0.observation, snap, rtol=0, atol=0)      # still intact
+  ts2 = env.step(a[2])
+  assert ts2.observation.data_ptr() == ts0.observation.data_ptr()        # depth-2 ring wraps
+
+
+def test_state_dict_round_trip_resumes_bit_exactly():
+  a = _acts(40, 777, na=2)
+  env = umbrella_chain.UmbrellaChain(chain_length=7, n_distractor=20, seed=3, batch=777)
+  for t in range(13):
+    env.step(a[t])
+  saved = env.state_dict()
+  want = [eu.to_np(env.step(a[t])) for t in range(13, 40)]
+  info_want = {k: v.clone() for k, v in env.bsuite_info().items()}
+  env2 = umbrella_chain.UmbrellaChain(chain_length=7, n_distractor=20, seed=999, batch=777)
+  env2.load_state_dict(saved)
+  for t, w in zip(range(13, 40), want):
+    got = eu.to_np(env2.step(a[t]))
+    for x, y in zip(got, w):
+      np.testing.assert_array_equal(x, y)
+  for k, v in env2.bsuite_info().items():
+    torch.testing.assert_close(v, info_want[k], rtol=0, atol=0)
+
+
+def test_hip_graph_replay_equals_eager():
+  B, T, reps, seed = 4096, 8, 5, 11
+  a = _acts(T, B, na=2)
+  eager = deep_sea.DeepSea(12, deterministic=False, mapping_seed=42, seed=seed, batch=B, num_buffers=1)
+  graphed = deep_sea.DeepSea(12, deterministic=False, mapping_seed=42, seed=seed, batch=B, num_buffers=1,
+                             device_step_counter=True)
+  graphed.step(a[0])                              # allocate + call 0 outside capture
+  eager.step(a[0])
+  side = torch.cuda.Stream()
+  side.wait_stream(torch.cuda.current_stream())
+  g = torch.cuda.CUDAGraph()
+  with torch.cuda.stream(side):
+    with torch.cuda.graph(g, stream=side):
+      for t in range(T):
+        last = graphed.step(a[t])
+  torch.cuda.current_stream().wait_stream(side)
+  for _ in range(reps):
+    g.replay()
+    for t in range(T):
+      ref = eager.step(a[t])
+  torch.cuda.synchronize()
+  for x, y in zip(eu.to_np(last), eu.to_np(ref)):
+    np.testing.assert_array_equal(x, y)
+  assert graphed.device_step_index() == 1 + T * reps == eager.step_index
+  for k, v in graphed.bsuite_info().items():
+    torch.testing.assert_close(v, eager.bsuite_info()[k], rtol=0, atol=0)
+  torch.testing.assert_close(graphed.episode_counters(), eager.episode_counters(), rtol=0, atol=0)
+
+
+def test_episode_counters_count_ballots_exactly():
+  B, N = 10007, 9
+  env = deep_sea.DeepSea(N, mapping_seed=1, seed=0, batch=B)
+  a = _acts(2 * (N + 1), B, na=2)
+  n_last = n_first = 0
+  for t in range(2 * (N + 1)):
+    ts = env.step(a[t])
+    n_last += int((ts.step_type == 2).sum().item())
+    n_first += int((ts.step_type == 0).sum().item())
+  c = env.episode_counters().cpu().numpy()
+  assert (c[0], c[1]) == (n_last, n_first) == (2 * B, 2 * B)
