@@ -100,6 +100,12 @@ class CartpoleCfg(ctypes.Structure):
               ('theta_offset', ctypes.c_double), ('time_frac', ctypes.c_void_p)]
 
 
+class MnistCfg(ctypes.Structure):
+  _fields_ = [('num_data', ctypes.c_int32), ('num_pixels', ctypes.c_int32),
+              ('images', ctypes.c_void_p), ('labels', ctypes.c_void_p),
+              ('pixel_lut', ctypes.c_float * 256)]
+
+
 class MountainCarCfg(ctypes.Structure):
   _fields_ = [('max_steps', ctypes.c_int32), ('_pad', ctypes.c_int32)]
 
@@ -128,6 +134,8 @@ _SIGS = {
                                     TimeStepPtrs], ctypes.c_int),
     'bsx_cartpole_step': ([ctypes.POINTER(CartpoleCfg), ctypes.POINTER(Call), _P, _P, _P,
                            TimeStepPtrs, _P], ctypes.c_int),
+    'bsx_mnist_step': ([ctypes.POINTER(MnistCfg), ctypes.POINTER(Call), _P, _P, TimeStepPtrs, _P],
+                       ctypes.c_int),
     'bsx_mountain_car_step': ([ctypes.POINTER(MountainCarCfg), ctypes.POINTER(Call), _P, _P, _P,
                                TimeStepPtrs, _P], ctypes.c_int),
 }

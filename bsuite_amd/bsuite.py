@@ -19,6 +19,7 @@ from bsuite_amd.environments import catch as _catch
 from bsuite_amd.environments import deep_sea as _deep_sea
 from bsuite_amd.environments import discounting_chain as _discounting_chain
 from bsuite_amd.environments import memory_chain as _memory_chain
+from bsuite_amd.environments import mnist as _mnist_env
 from bsuite_amd.environments import mountain_car as _mountain_car
 from bsuite_amd.environments import umbrella_chain as _umbrella_chain
 from bsuite_amd.utils import wrappers
@@ -67,13 +68,6 @@ def _umbrella_distract(n_distractor: int, seed=0, **kw):
   return _umbrella_chain.UmbrellaChain(chain_length=20, n_distractor=n_distractor, seed=seed, **kw)
 
 
-def _mnist(*args, **kwargs):
-  raise NotImplementedError(
-      'mnist / mnist_noise / mnist_scale (bsuite/environments/mnist.py) need the MNIST dataset '
-      'files; there is no network here and the family is outside the eight kernel families of the '
-      'hot path (SURVEY §8 a14).')
-
-
 # Mapping from experiment name to environment constructor or load function (bsuite.py:57-81).
 EXPERIMENT_NAME_TO_ENVIRONMENT = dict(
     bandit=_bandit.SimpleBandit,
@@ -91,9 +85,9 @@ EXPERIMENT_NAME_TO_ENVIRONMENT = dict(
     discounting_chain=_discounting_chain.DiscountingChain,
     memory_len=_memory_len,
     memory_size=_memory_size,
-    mnist=_mnist,
-    mnist_noise=_mnist,
-    mnist_scale=_mnist,
+    mnist=_mnist_env.MNISTBandit,
+    mnist_noise=_noisy(_mnist_env.MNISTBandit),
+    mnist_scale=_scaled(_mnist_env.MNISTBandit),
     mountain_car=_mountain_car.MountainCar,
     mountain_car_noise=_noisy(_mountain_car.MountainCar),
     mountain_car_scale=_scaled(_mountain_car.MountainCar),

@@ -1,0 +1,149 @@
+// mnist.hip — batched MNIST contextual bandit for gfx950.  Replaces
+// bsuite/environments/mnist.py:61-75 (`_reset`, `_step`) + base.py:54-65 auto-reset.
+//
+// Episode = reset (show image idx = randint(num_data), obs = int8 pixels / 255 in f32) + one step
+// (reward +-1 by action == label, LAST, obs = zeros).  Per call and lane: 3136 B of observation
+// stores, on FIRST calls plus a 784 B gather from the L2/Infinity-cache resident image table.
+//   advance  mnist_advance_kernel: one lane per thread, packed state = idx | label | flags
+//   observe  mnist_observe_kernel: pure 16-byte store stream over [B x 784] f32; a chunk is four
+//            table bytes mapped through the 256-entry LUT (LDS) or zero.
+// The LUT holds np.float32(int8(b)) / 255 evaluated by numpy on the host, so the int8 parsing quirk
+// of the reference (datasets.py:55-56) and its f32 division are reproduced bit for bit.
+#include "bsx_host.h"
+
+struct mnist_args {
+  bsx_ctl ctl;
+  const int32_t* action;
+  int32_t* state;
+  bsx_timestep_t out;
+  double* info;
+  const int8_t* images;
+  const uint8_t* labels;
+  int32_t num_data;
+  int32_t num_pixels;
+};
+
+#define MN_RESET_BIT (1 << 28)
+#define MN_SHOW_BIT (1 << 29)
+
+__global__ void __launch_bounds__(BSX_BLOCK) mnist_advance_kernel(const mnist_args a) {
+  __shared__ unsigned int s_cnt[2];
+  if (threadIdx.x < 2) s_cnt[threadIdx.x] = 0;
+  __syncthreads();
+  const int64_t i = (int64_t)blockIdx.x * BSX_BLOCK + threadIdx.x;
+  int type = -1;
+  if (i < a.ctl.n_lanes) {
+    const uint64_t lane = a.ctl.lane_offset + (uint64_t)i;
+    const uint64_t step = bsx_step_of(a.ctl);
+    const int32_t st = a.state[i];
+    double reward = 0.0;
+    int32_t nst;
+    if (a.ctl.force_reset || (st & MN_RESET_BIT)) {             // mnist.py:61-67
+      bsx_draws d;
+      bsx_draws_init(&d, a.ctl.seed, lane, step, BSX_STREAM_ENV);
+      const uint32_t idx = bsx_randint(&d, (uint32_t)a.num_data);
+      nst = (int32_t)idx | ((int32_t)a.labels[idx] << 24) | MN_SHOW_BIT;
+      type = BSX_FIRST;
+    } else {                                                    // mnist.py:69-75
+      const int label = (st >> 24) & 0xF;
+      reward = (a.action[i] == label) ? 1.0 : -1.0;
+      a.info[i] += 1.0 - reward;
+      nst = (st & 0x0FFFFFFF) | MN_RESET_BIT;                   // SHOW bit cleared: obs = zeros
+      type = BSX_LAST;
+    }
+    a.state[i] = nst;
+    bsx_emit(a.ctl, a.out, i, lane, step, type, reward);
+  }
+  bsx_count_types(a.ctl, type, s_cnt);
+  __syncthreads();
+  bsx_flush_counts(a.ctl, s_cnt);
+}
+
+struct mnist_observe_args {
+  float* obs;
+  const int32_t* state;
+  const int8_t* images;
+  int64_t n_lanes;
+  uint32_t cells;
+  uint32_t cells_magic;
+  bsx_div64 dv;
+  float lut[256];
+};
+
+// Block b writes floats [b*K*1024, (b+1)*K*1024) of the [B x num_pixels] observation array
+// (num_pixels % 4 == 0, so a 16-byte chunk never straddles two lanes).
+template <int K>
+__global__ void __launch_bounds__(BSX_BLOCK) mnist_observe_kernel(const mnist_observe_args a) {
+  __shared__ float s_lut[256];
+  s_lut[threadIdx.x] = a.lut[threadIdx.x];
+  __syncthreads();
+  const uint32_t cells = a.cells;
+  const uint64_t total = (uint64_t)a.n_lanes * cells;
+  const uint64_t F0 = (uint64_t)blockIdx.x * (uint64_t)(K * 4 * BSX_BLOCK);
+  const uint64_t lane_b = __umul64hi(F0, a.dv.m) >> a.dv.s;
+  const uint32_t r_b = (uint32_t)(F0 - lane_b * cells);
+  bsx_f4* __restrict__ o4 = reinterpret_cast<bsx_f4*>(a.obs + F0);
+  const int32_t* __restrict__ st = a.state + lane_b;
+  uint32_t px[K];
+  bool live[K], show[K];
+#pragma unroll
+  for (int u = 0; u < K; ++u) {
+    const uint32_t c = threadIdx.x + u * BSX_BLOCK;
+    const uint32_t f = r_b + (c << 2);
+    const uint32_t dl = __umulhi(f, a.cells_magic);
+    const uint32_t r0 = f - dl * cells;
+    live[u] = F0 + ((uint64_t)c << 2) + 3 < total;
+    show[u] = false;
+    px[u] = 0;
+    if (live[u]) {
+      const int32_t s = st[dl];
+      show[u] = (s & MN_SHOW_BIT) != 0;
+      if (show[u])    // four int8 pixels of image idx: one aligned dword of the table
+        px[u] = *reinterpret_cast<const uint32_t*>(a.images + (uint64_t)(s & 0x00FFFFFF) * cells + r0);
+    }
+  }
+#pragma unroll
+  for (int u = 0; u < K; ++u) {
+    if (!live[u]) continue;
+    bsx_f4 v = {0.f, 0.f, 0.f, 0.f};                            // mnist.py:73 zeros after the guess
+    if (show[u]) {                                              // mnist.py:64 astype(f32) / 255
+      const uint32_t p = px[u];
+      v.x = s_lut[p & 0xFF]; v.y = s_lut[(p >> 8) & 0xFF]; v.z = s_lut[(p >> 16) & 0xFF]; v.w = s_lut[p >> 24];
+    }
+    o4[threadIdx.x + u * BSX_BLOCK] = v;
+  }
+}
+
+extern "C" int bsx_mnist_step(const bsx_mnist_t* cfg, const bsx_call_t* call, const int32_t* action,
+                              int32_t* state, bsx_timestep_t out, double* info) {
+  if (cfg == nullptr) return BSX_ENULL;
+  int rc = bsx_check_call(call, action, out);
+  if (rc != 0) return rc;
+  if (cfg->num_data < 1 || cfg->num_data > (1 << 24) || cfg->num_pixels < 4 || cfg->num_pixels > 4096 ||
+      (cfg->num_pixels & 3) != 0)
+    return BSX_ERANGE;
+  if (call->n_lanes == 0) return 0;
+  if (state == nullptr || info == nullptr || cfg->images == nullptr || cfg->labels == nullptr) return BSX_ENULL;
+  if ((reinterpret_cast<uintptr_t>(cfg->images) & 3u) != 0) return BSX_EALIGN;
+  hipStream_t st = (hipStream_t)call->hip_stream;
+
+  mnist_args a;
+  a.ctl = bsx_make_ctl(call);
+  a.action = action; a.state = state; a.out = out; a.info = info;
+  a.images = cfg->images; a.labels = cfg->labels; a.num_data = cfg->num_data; a.num_pixels = cfg->num_pixels;
+  const int64_t blocks_a = (call->n_lanes + BSX_BLOCK - 1) / BSX_BLOCK;
+  if (blocks_a > 0x7FFFFFFF) return BSX_EINVAL;
+  mnist_advance_kernel<<<dim3((unsigned)blocks_a), dim3(BSX_BLOCK), 0, st>>>(a);
+
+  mnist_observe_args o;
+  o.obs = out.observation; o.state = state; o.images = cfg->images; o.n_lanes = call->n_lanes;
+  o.cells = (uint32_t)cfg->num_pixels; o.cells_magic = bsx_div_magic(o.cells); o.dv = bsx_make_div64(o.cells);
+  for (int k = 0; k < 256; ++k) o.lut[k] = cfg->pixel_lut[k];
+  constexpr int K = 4;
+  const uint64_t total = (uint64_t)call->n_lanes * o.cells;
+  const uint64_t per_block = (uint64_t)K * 4 * BSX_BLOCK;
+  const uint64_t blocks_o = (total + per_block - 1) / per_block;
+  if (blocks_o > 0x7FFFFFFFull) return BSX_EINVAL;
+  mnist_observe_kernel<K><<<dim3((unsigned)blocks_o), dim3(BSX_BLOCK), 0, st>>>(o);
+  return bsx_launch_status();
+}

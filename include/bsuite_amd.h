@@ -194,6 +194,20 @@ int bsx_mountain_car_step(const bsx_mountain_car_t* cfg, const bsx_call_t* call,
                           const int32_t* action, float* state, int32_t* steps,
                           bsx_timestep_t out, double* info);
 
+/* ---- mnist bandit : bsuite/environments/mnist.py:33-89, bsuite/utils/datasets.py:42-69 -------- */
+typedef struct {
+  int32_t num_data;        /* int(fraction * len(labels)) (mnist.py:46-48); 1..2^24               */
+  int32_t num_pixels;      /* rows*cols of one image, multiple of 4 (28*28 = 784)                   */
+  const int8_t* images;    /* device [num_data, num_pixels]: the idx bytes as int8, exactly as
+                              datasets.py:55-56 parses them (bright pixels are negative)            */
+  const uint8_t* labels;   /* device [num_data]                                                     */
+  float pixel_lut[256];    /* host-built np.float32(int8 value) / 255 for byte b (index = b as u8)  */
+} bsx_mnist_t;
+/* state: int32 [B] = image_index | label<<24 | reset_next<<28 | showing_image<<29 (init 1<<28)
+ * info : double [1,B] = total_regret; obs float [B, rows, cols] */
+int bsx_mnist_step(const bsx_mnist_t* cfg, const bsx_call_t* call, const int32_t* action,
+                   int32_t* state, bsx_timestep_t out, double* info);
+
 /* ---- misc ---------------------------------------------------------------------------------- */
 int bsx_abi_version(void);
 const char* bsx_strerror(int code);

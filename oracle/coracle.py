@@ -191,6 +191,18 @@ class OracleEnv:
       self._fn = lambda c: L.orc_mountain_car(
           c, ctypes.c_int(ms), _p(self.s['position']), _p(self.s['velocity']),
           _p(self.s['timestep']), _p(self.reset_next), _p(self.info['raw_return']))
+    elif family == 'mnist':
+      self.images = np.ascontiguousarray(kw['images'], np.int8)
+      self.labels = np.ascontiguousarray(kw['labels'], np.uint8)
+      nd = int(kw.get('fraction', 1.) * len(self.labels))
+      self.obs_shape = tuple(self.images.shape[1:])
+      npix = int(np.prod(self.obs_shape))
+      self.num_actions = 10
+      self.s = dict(correct_label=i32())
+      self.info = dict(total_regret=f64())
+      self._fn = lambda c: L.orc_mnist(
+          c, ctypes.c_int(nd), ctypes.c_int(npix), _p(self.images), _p(self.labels),
+          _p(self.s['correct_label']), _p(self.reset_next), _p(self.info['total_regret']))
     else:
       raise KeyError(family)
     self.obs_numel = int(np.prod(self.obs_shape))

@@ -25,14 +25,28 @@ BIG_LANE = (1 << 33) + 5        # exercises counter word 1
 BIG_STEP = (1 << 34) + 77       # exercises the step[47:32] counter bits
 
 
+MNIST_DIR = '/tmp/mnist'   # the reference's hard-wired default (bsuite/utils/datasets.py:42)
+
+
+def synthetic_mnist(n=96, seed=7):
+  """Deterministic stand-in dataset (no network): uint8 images incl. bright (>127) pixels."""
+  rng = np.random.default_rng(seed)
+  images = rng.integers(0, 256, size=(n, 28, 28), dtype=np.uint8)
+  images[:, :4, :] = 0
+  images[::3, 10:14, 10:14] = 255
+  labels = rng.integers(0, 10, size=n).astype(np.uint8)
+  return images, labels
+
+
 def _make_env(bs, family, kwargs, wrap):
   from bsuite.environments import (bandit, cartpole, catch, deep_sea, discounting_chain,  # pylint: disable=import-outside-toplevel
                                    memory_chain, mountain_car, umbrella_chain)
   from bsuite.experiments.cartpole_swingup import cartpole_swingup  # pylint: disable=import-outside-toplevel
   from bsuite.utils import wrappers  # pylint: disable=import-outside-toplevel
   import warnings  # pylint: disable=import-outside-toplevel
+  from bsuite.environments import mnist  # pylint: disable=import-outside-toplevel
   ctor = dict(
-      deep_sea=deep_sea.DeepSea, catch=catch.Catch, bandit=bandit.SimpleBandit,
+      mnist=mnist.MNISTBandit, deep_sea=deep_sea.DeepSea, catch=catch.Catch, bandit=bandit.SimpleBandit,
       memory_chain=memory_chain.MemoryChain, umbrella_chain=umbrella_chain.UmbrellaChain,
       discounting_chain=discounting_chain.DiscountingChain, cartpole=cartpole.Cartpole,
       cartpole_swingup=cartpole_swingup.CartpoleSwingup, mountain_car=mountain_car.MountainCar,
@@ -75,6 +89,8 @@ def _policy_action(family, raw, policy, rnd, num_actions):
     return 2 if u > 0 else 0
   if family == 'mountain_car':
     return 2 if raw._velocity >= 0 else 0  # pylint: disable=protected-access
+  if family == 'mnist':
+    return int(raw._correct_label) if raw._correct_label is not None else 0
   if family == 'memory_chain':
     return int(raw._context[raw._query])  # pylint: disable=protected-access
   if family == 'umbrella_chain':
@@ -219,6 +235,13 @@ def cases():
     add(f'swingup_{n}', 'cartpole_swingup',
         dict(height_threshold=n / 20, x_reward_threshold=1 - n / 20), LANES[:4], 1100,
         policies=['optimal'])
+  # mnist bandit (mnist.py) on the synthetic idx files staged in /tmp/mnist by main()
+  add('mnist_synthetic', 'mnist', dict(), LANES, 40, policies=['optimal'], reset_at=(7,))
+  add('mnist_fraction', 'mnist', dict(fraction=0.25), LANES[:4], 30, policies=['optimal'], step0=BIG_STEP)
+  add('mnist_noise', 'mnist', dict(), LANES[:4], 30, wrap=('noise', 0.3))
+  # swing-up started near upright so the `is_upright` reward branch (swingup:104-112) is exercised
+  add('swingup_upright', 'cartpole_swingup', dict(init_range=3.3, height_threshold=0.2), LANES, 400,
+      policies=['optimal'] * 8)
   # mountain_car (mountain_car.py)
   add('mountain_car_default', 'mountain_car', dict(), LANES[:4], 1300, policies=['optimal'])
   add('mountain_car_max20', 'mountain_car', dict(max_steps=20), LANES, 70, policies=['optimal'],
@@ -232,6 +255,10 @@ def cases():
 
 def main():
   bs = replay.import_reference()
+  from bsuite_amd.utils import datasets as _ds  # only the idx *writer* (wire format), not the engine
+  imgs, labs = synthetic_mnist()
+  _ds.write_idx_files(MNIST_DIR, imgs, labs)
+  np.savez_compressed(os.path.join(OUT_DIR, 'mnist_synthetic_dataset.npz'), images_u8=imgs, labels=labs)
   for i, (a, k) in enumerate(cases()):
     run_case(bs, *a, case_seed=1000 + i, **k)
   # Host-side constant tables of the reference (numpy RandomState on the host): pins for the

@@ -14,6 +14,7 @@
  *   bsuite/environments/cartpole.py:37-177       step_cartpole + Cartpole
  *   bsuite/experiments/cartpole_swingup/cartpole_swingup.py:81-150  CartpoleSwingup
  *   bsuite/environments/mountain_car.py:62-90    MountainCar
+ *   bsuite/environments/mnist.py:61-75           MNISTBandit
  *   bsuite/utils/wrappers.py:275-283,338-346     RewardNoise / RewardScale
  * All state and rewards are f64 as in the reference (Python floats); observations are cast to
  * f32 exactly where the reference casts (np.zeros(dtype=float32) assignment).
@@ -497,5 +498,28 @@ void orc_mountain_car(const orc_call* c, int max_steps, double* position, double
     o[1] = (float)velocity[i];
     o[2] = (float)((double)timestep[i] / (double)max_steps);
     emit(c, i, type, reward);
+  }
+}
+
+/* ------------------------------------------------------------------ mnist.py */
+void orc_mnist(const orc_call* c, int num_data, int num_pixels, const int8_t* images /* [num_data, num_pixels] */,
+               const uint8_t* labels, int32_t* correct_label, int32_t* reset_next, double* total_regret) {
+  for (int64_t i = 0; i < c->n_lanes; i++) {
+    float* o = c->obs + i * (int64_t)num_pixels;
+    if (c->force_reset || reset_next[i]) {                             /* :61-67 */
+      draws_t d; draws_begin(&d, c->seed, c->lane_ids[i], c->step, 0);
+      reset_next[i] = 0;
+      uint32_t idx = draw_randint(&d, (uint32_t)num_data);
+      for (int p = 0; p < num_pixels; p++)                             /* astype(float32) / 255 */
+        o[p] = (float)images[(int64_t)idx * num_pixels + p] / 255.0f;
+      correct_label[i] = labels[idx];
+      emit(c, i, FIRST, 0.0);
+      continue;
+    }
+    double reward = (c->action[i] == correct_label[i]) ? 1.0 : -1.0;   /* :71-72 */
+    total_regret[i] += 1.0 - reward;                                   /* :73 */
+    memset(o, 0, sizeof(float) * num_pixels);                          /* :74 */
+    reset_next[i] = 1;
+    emit(c, i, LAST, reward);
   }
 }

@@ -3,14 +3,15 @@ import numpy as np
 import torch
 
 from bsuite_amd.environments import (bandit, cartpole, catch, deep_sea, discounting_chain,
-                                     memory_chain, mountain_car, umbrella_chain)
+                                     memory_chain, mnist, mountain_car, umbrella_chain)
 from bsuite_amd.utils import wrappers
 
 CTORS = dict(
     deep_sea=deep_sea.DeepSea, catch=catch.Catch, bandit=bandit.SimpleBandit,
     memory_chain=memory_chain.MemoryChain, umbrella_chain=umbrella_chain.UmbrellaChain,
     discounting_chain=discounting_chain.DiscountingChain, cartpole=cartpole.Cartpole,
-    cartpole_swingup=cartpole.CartpoleSwingup, mountain_car=mountain_car.MountainCar)
+    cartpole_swingup=cartpole.CartpoleSwingup, mountain_car=mountain_car.MountainCar,
+    mnist=mnist.MNISTBandit)
 
 
 def make_env(family, kwargs, batch, lane_offset, seed, wrap=None, num_buffers=1):

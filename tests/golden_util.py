@@ -11,7 +11,13 @@ PHYSICS = ('cartpole', 'cartpole_swingup', 'mountain_car')
 
 def case_names():
   names = [os.path.basename(p)[:-4] for p in sorted(glob.glob(os.path.join(GOLDEN_DIR, '*.npz')))]
-  return [n for n in names if n != 'host_constants']
+  return [n for n in names if n not in ('host_constants', 'mnist_synthetic_dataset')]
+
+
+def mnist_dataset():
+  """The synthetic dataset the mnist fixtures were generated on (int8 view, as the reference parses)."""
+  d = np.load(os.path.join(GOLDEN_DIR, 'mnist_synthetic_dataset.npz'))
+  return d['images_u8'].view(np.int8), d['labels']
 
 
 def load_case(name):

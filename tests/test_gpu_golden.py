@@ -29,9 +29,12 @@ def test_engine_matches_reference(name):
   phys = fam in gu.PHYSICS
   wrap = tuple(meta['wrap']) if meta['wrap'] else None
   T = g['actions'].shape[0]
+  kwargs = dict(meta['kwargs'])
+  if fam == 'mnist':
+    kwargs['images'], kwargs['labels'] = gu.mnist_dataset()
   for (i0, lane0, n) in gu.contiguous_runs(g['lanes']):
     idx = slice(i0, i0 + n)
-    env = eu.make_env(fam, meta['kwargs'], batch=n, lane_offset=lane0, seed=meta['seed'], wrap=wrap)
+    env = eu.make_env(fam, kwargs, batch=n, lane_offset=lane0, seed=meta['seed'], wrap=wrap)
     eu.raw(env)._step_index = meta['step0']
     for t in range(T):
       if phys and t > 0:

@@ -65,7 +65,15 @@ def test_cartpole_time_table_replays_the_f64_running_sum():
   assert cartpole.Cartpole(max_time=0.05)._last_step == 6   # f64 sum of five 0.01 steps is not > 0.05
 
 
-def test_loader_builds_every_non_mnist_id_with_reference_specs():
+def test_loader_builds_every_id_with_reference_specs(tmp_path):
+  from bsuite_amd.utils import datasets
+  imgs_i8, labels = gu.mnist_dataset()
+  datasets.write_idx_files(str(tmp_path), imgs_i8.view(np.uint8), labels)
+  (tr_i, tr_l), (te_i, te_l) = datasets.load_mnist(str(tmp_path))
+  assert tr_i.dtype == np.int8 and tr_i.shape == imgs_i8.shape and (tr_i == imgs_i8).all()
+  assert (tr_l == labels).all() and te_i.shape[0] == 1
+  with pytest.raises(FileNotFoundError):
+    datasets.load_mnist(str(tmp_path / 'nowhere'))
   shapes = dict(bandit=(1, 1), catch=(10, 5), cartpole=(1, 6), cartpole_swingup=(1, 8),
                 discounting_chain=(1, 2), mountain_car=(1, 3))
   actions = dict(bandit=11, catch=3, cartpole=3, cartpole_swingup=3, deep_sea=2, memory=2, umbrella=2,
@@ -73,8 +81,9 @@ def test_loader_builds_every_non_mnist_id_with_reference_specs():
   for bid in sweep.SWEEP:
     name = bid.split('/')[0]
     if name.startswith('mnist'):
-      with pytest.raises(NotImplementedError):
-        bsuite_amd.load_from_id(bid)
+      env = bsuite_amd.load_from_id(bid, data_dir=str(tmp_path))
+      assert env.observation_spec().shape == (28, 28) and env.action_spec().num_values == 10
+      assert env.bsuite_num_episodes == sweep.EPISODES[bid]
       continue
     env = bsuite_amd.load_from_id(bid)
     assert env.bsuite_num_episodes == sweep.EPISODES[bid] > 0

@@ -12,7 +12,10 @@ from tests import golden_util as gu
 def test_oracle_matches_reference(name):
   meta, g = gu.load_case(name)
   fam = meta['family']
-  env = coracle.OracleEnv(fam, meta['kwargs'], g['lanes'], seed=meta['seed'],
+  kwargs = dict(meta['kwargs'])
+  if fam == 'mnist':
+    kwargs['images'], kwargs['labels'] = gu.mnist_dataset()
+  env = coracle.OracleEnv(fam, kwargs, g['lanes'], seed=meta['seed'],
                           wrap=tuple(meta['wrap']) if meta['wrap'] else None)
   assert list(env.obs_shape) == meta['obs_shape']
   assert env.num_actions == meta['num_actions']
@@ -37,7 +40,7 @@ def test_oracle_matches_reference(name):
       else:
         np.testing.assert_array_equal(info[k], g['info'][t, :, j], err_msg=f'{k} t={t}')
     if phys and fam != 'mountain_car':
-      np.testing.assert_allclose(env.s['state'], g['phys'][t], rtol=1e-9, atol=1e-12)
+      np.testing.assert_allclose(env.s['state'], g['phys'][t], rtol=1e-9, atol=1e-9)
 
 
 def test_fixtures_reach_rare_branches():
@@ -49,3 +52,7 @@ def test_fixtures_reach_rare_branches():
   _, g = gu.load_case('mountain_car_default')
   assert ((g['step_type'] == 2) & (g['obs'][..., 0, 0] >= 0.5)).any()        # goal reached
   assert ((g['step_type'] == 2) & (g['obs'][..., 0, 2] == 1.0)).any()        # timeout
+  meta, g = gu.load_case('swingup_upright')
+  assert g['info'][-1, :, meta['info_keys'].index('total_upright')].max() > 50   # upright reward branch
+  _, g = gu.load_case('mnist_synthetic')
+  assert (g['obs'] < 0).any()                                                # int8 pixel quirk present
