@@ -75,12 +75,76 @@ def cpu_baseline(family, kwargs, num_actions, budget_s=12.0):
                      f'(gcc -O2, single thread, {dt:.1f} s)')
 
 
+def bench_sweep(args, torch, dist, dev, rank, world):
+  """BASELINE config 5: all 468 bsuite_ids as lane segments (2^20 lanes in total, split evenly per id,
+  whole segments bin-packed over the ranks), one captured HIP graph per sweep step."""
+  import tempfile
+  import numpy as np
+  from bsuite_amd import sweep_batch as sb
+  from bsuite_amd.utils import datasets
+  d = np.load(os.path.join(ROOT, 'tests', 'golden', 'mnist_synthetic_dataset.npz'))
+  tmp = tempfile.mkdtemp(prefix='bsx_mnist_')
+  datasets.write_idx_files(tmp, d['images_u8'], d['labels'])      # synthetic stand-in (no network)
+  mn = dict(data_dir=tmp)
+  batch = sb.SweepBatch(None, args.lanes, device=dev, seed=42, rank=rank, world_size=world,
+                        env_kwargs=dict(mnist=mn, mnist_noise=mn, mnist_scale=mn))
+  acts = batch.random_actions(seed=1 + rank)
+  batch.capture(acts)
+
+  def sync_all():
+    torch.cuda.synchronize(dev)
+    if world > 1:
+      dist.barrier()
+      torch.cuda.synchronize(dev)
+
+  for _ in range(args.warmup):
+    batch.replay()
+  sync_all()
+  ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+  t0 = time.perf_counter()
+  ev0.record()
+  for _ in range(args.steps):
+    batch.replay()
+  ev1.record()
+  torch.cuda.synchronize(dev)
+  wall = time.perf_counter() - t0
+  sync_all()
+  step_ms = ev0.elapsed_time(ev1) / args.steps
+  local_bytes = sum(l * sb.bytes_per_step(int(np.prod(e.observation_spec().shape)))
+                    for e, (_, _, l) in zip(batch.envs, batch.segments))
+  if world > 1:
+    t = torch.tensor([wall, step_ms, float(local_bytes)], dtype=torch.float64, device=dev)
+    mx = t.clone()
+    dist.all_reduce(mx, op=dist.ReduceOp.MAX)
+    dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    wall, step_ms, total_bytes = float(mx[0]), float(mx[1]), float(t[2])
+  else:
+    total_bytes = float(local_bytes)
+  if rank == 0:
+    achieved = total_bytes / world / (step_ms * 1e-3) / 1e9
+    print(json.dumps({
+        'metric': 'env-steps/sec', 'value': args.lanes * args.steps / wall, 'unit': 'env-steps/s',
+        'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': wall / args.steps * 1e3,
+        'higher_is_better': True, 'scaling': 'strong', 'vs_baseline': None, 'dtype': 'int32+f32',
+        'data': 'synthetic (MNIST ids on a synthetic stand-in dataset)',
+        'config': {'workload': 'sweep.SWEEP: 468 bsuite_ids as lane segments, random-action rollout, dense TimeStep',
+                   'global_lanes': args.lanes, 'segments_on_rank0': len(batch.envs),
+                   'sharding': f'whole segments bin-packed over {world} rank(s)'},
+        'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBPS, 'unit': 'GB/s',
+                     'frac': achieved / HBM_PEAK_GBPS, 'traffic': None, 'kernel_ms': step_ms,
+                     'algorithmic_bytes_per_launch': total_bytes / world},
+        'launch': f'one hipGraph per sweep step ({len(batch.envs)} segments over {batch.num_streams} streams)'}),
+          flush=True)
+  if world > 1:
+    dist.destroy_process_group()
+
+
 def main():
   ap = argparse.ArgumentParser()
   ap.add_argument('--gpus', type=int, default=1)
   ap.add_argument('--steps', type=int, default=200)
   ap.add_argument('--warmup', type=int, default=20)
-  ap.add_argument('--workload', default='deep_sea', choices=sorted(WORKLOADS))
+  ap.add_argument('--workload', default='deep_sea', choices=sorted(WORKLOADS) + ['sweep'])
   ap.add_argument('--lanes', type=int, default=1 << 20, help='lanes per GPU')
   ap.add_argument('--no-cpu-baseline', action='store_true')
   ap.add_argument('--graph', type=int, default=0,
@@ -102,6 +166,8 @@ def main():
   torch.cuda.set_device(local_rank)
   dev = torch.device('cuda', local_rank)
 
+  if args.workload == 'sweep':
+    return bench_sweep(args, torch, dist, dev, rank, world)
   bsuite_id, family, okw, obs_numel, state_bytes = WORKLOADS[args.workload]
   B = args.lanes
   env = bsuite_amd.load_from_id(bsuite_id, batch=B, device=dev, seed=42, lane_offset=rank * B,

@@ -53,7 +53,7 @@ class Environment(dm_env.EnvironmentBase):
   _info_int_keys = ()      # keys the reference reports as Python ints
 
   def __init__(self, obs_shape, num_actions, *, seed=None, batch=None, device=None,
-               lane_offset=0, num_buffers=2, device_step_counter=False):
+               lane_offset=0, num_buffers=2, device_step_counter=False, shared_step_counter=None):
     self._scalar = batch is None
     self._batch = 1 if batch is None else int(batch)
     if self._batch < 1:
@@ -67,7 +67,10 @@ class Environment(dm_env.EnvironmentBase):
     # device_step_counter=True keeps the draw-stream call index in device memory and bumps it
     # with a one-thread kernel after every call, so step() carries no host-side state and can be
     # captured into (and replayed from) a HIP graph.
-    self._device_step_counter = bool(device_step_counter)
+    self._device_step_counter = bool(device_step_counter) or shared_step_counter is not None
+    # shared_step_counter: an int64[1] device tensor owned by the caller (e.g. SweepBatch) who bumps
+    # it once per sweep step for all its segments instead of one bump kernel per environment.
+    self._shared_step_counter = shared_step_counter
     self._wrap = (_native.WRAP_NONE, 0.0, 0)
     self._step_index = 0
     self._buf = 0
@@ -124,7 +127,8 @@ class Environment(dm_env.EnvironmentBase):
       self._info = torch.zeros((n_info, B), dtype=torch.float64, device=dev)
       self._counters = torch.zeros((_native.COUNTER_SHARDS, _native.COUNTER_STRIDE),
                                    dtype=torch.int64, device=dev)
-      self._step_base = torch.zeros(1, dtype=torch.int64, device=dev)
+      self._step_base = (self._shared_step_counter if self._shared_step_counter is not None
+                         else torch.zeros(1, dtype=torch.int64, device=dev))
       self._out = []
       self._out_ptrs = []
       for _ in range(self._num_buffers):
@@ -161,7 +165,7 @@ class Environment(dm_env.EnvironmentBase):
     call.hip_stream = hip_stream
     if self._device_step_counter:
       rc = self._launch(call, action_ptr, out_ptrs)
-      if rc == 0:
+      if rc == 0 and self._shared_step_counter is None:
         rc = _native.lib.bsx_counter_add(self._step_base.data_ptr(), 1, hip_stream)
     else:
       call.stream.step_index = self._step_index

@@ -1,0 +1,125 @@
+"""GPU: BASELINE.json's full sizes (B = 2^20 lanes).  The C oracle cannot restate 2^20 x 3600-byte
+observations per step in seconds, so at full size the check is (a) size-independent invariants over
+ALL lanes, evaluated on the device, and (b) bit-exact comparison of a random 4096-lane subsample
+(arbitrary global lane ids) against the oracle on every step."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import coracle
+from tests import engine_util as eu
+
+pytestmark = pytest.mark.gpu
+B = 1 << 20
+
+
+def _subsample(rng, n=4096):
+  idx = np.unique(np.concatenate([rng.integers(0, B, size=n), [0, 1, 63, 64, 255, 256, B - 1]]))
+  return idx.astype(np.int64)
+
+
+def test_deep_sea_n30_full_batch():
+  N, T, seed = 30, 34, 42
+  env = eu.make_env('deep_sea', dict(size=N, mapping_seed=42), batch=B, lane_offset=0, seed=seed, num_buffers=1)
+  rng = np.random.default_rng(0)
+  idx = _subsample(rng)
+  idx_t = torch.from_numpy(idx).cuda()
+  orc = coracle.OracleEnv('deep_sea', dict(size=N, mapping_seed=42), idx.astype(np.uint64), seed=seed)
+  g = torch.Generator(device='cuda'); g.manual_seed(1)
+  goal_reward = np.float32(0.0 + 1.0 - 0.01 / N)
+  total_last = 0
+  for t in range(T):
+    a = torch.randint(2, (B,), generator=g, device='cuda', dtype=torch.int32)
+    ts = env.step(a)
+    obs = ts.observation.view(B, N * N)
+    s = obs.sum(dim=1)
+    last = ts.step_type == 2
+    # one-hot everywhere except the all-zero terminal observation (deep_sea.py:105-107)
+    assert bool(((s == 1) ^ last).all()) and bool((s[last] == 0).all())
+    assert bool(((obs == 0) | (obs == 1)).all())
+    st = eu.raw(env)._state['state']
+    row, col = st & 0xFF, (st >> 8) & 0xFF
+    hot = obs.argmax(dim=1)
+    assert bool((hot[~last] == (row * N + col)[~last]).all())            # hot cell == packed state
+    r = ts.reward
+    allowed = torch.tensor([0.0, np.float32(0.0 - 0.01 / N), goal_reward], device='cuda')
+    assert bool(torch.isin(r, allowed).all())
+    assert bool((ts.discount == (~last).float()).all())
+    total_last += int(last.sum())
+    # subsample vs oracle, bit exact
+    ost, orr, od, oo = orc.call(a[idx_t].cpu().numpy(), t)
+    np.testing.assert_array_equal(ts.step_type[idx_t].cpu().numpy(), ost)
+    live = ost != 0
+    np.testing.assert_array_equal(eu.f32_bits(r[idx_t].cpu().numpy()[live]), eu.f32_bits(orr[live].astype(np.float32)))
+    np.testing.assert_array_equal(ts.observation[idx_t].cpu().numpy(), oo)
+  assert total_last == B                                                   # every lane finished exactly one episode
+  c = env.episode_counters().cpu().numpy()
+  assert c[0] == B and c[1] == 2 * B
+  for k, v in orc.bsuite_info().items():
+    np.testing.assert_array_equal(env.bsuite_info()[k][idx_t].cpu().numpy(), v)
+  bad = env.bsuite_info()['total_bad_episodes']
+  assert float(bad.sum()) + float(env.bsuite_info()['denoised_return'].sum()) <= B + 1e-9
+
+
+def test_catch_full_batch():
+  T, seed = 25, 7
+  env = eu.make_env('catch', dict(), batch=B, lane_offset=0, seed=seed, num_buffers=1)
+  rng = np.random.default_rng(1)
+  idx = _subsample(rng)
+  idx_t = torch.from_numpy(idx).cuda()
+  orc = coracle.OracleEnv('catch', dict(), idx.astype(np.uint64), seed=seed)
+  g = torch.Generator(device='cuda'); g.manual_seed(2)
+  for t in range(T):
+    a = torch.randint(3, (B,), generator=g, device='cuda', dtype=torch.int32)
+    ts = env.step(a)
+    obs = ts.observation.view(B, 50)
+    s = obs.sum(dim=1)
+    assert bool(((s == 1) | (s == 2)).all()) and bool(((obs == 0) | (obs == 1)).all())
+    assert bool((obs[:, 45:].sum(dim=1) >= 1).all())                       # paddle always on the bottom row
+    last = ts.step_type == 2
+    assert bool((ts.reward[~last] == 0).all()) and bool((ts.reward[last].abs() == 1).all())
+    assert bool((s[last & (ts.reward > 0)] == 1).all())                    # caught: ball and paddle coincide
+    ost, orr, od, oo = orc.call(a[idx_t].cpu().numpy(), t)
+    np.testing.assert_array_equal(ts.step_type[idx_t].cpu().numpy(), ost)
+    np.testing.assert_array_equal(ts.observation[idx_t].cpu().numpy(), oo)
+    live = ost != 0
+    np.testing.assert_array_equal(ts.reward[idx_t].cpu().numpy()[live], orr[live].astype(np.float32))
+  regret = env.bsuite_info()['total_regret']
+  np.testing.assert_array_equal(regret[idx_t].cpu().numpy(), orc.bsuite_info()['total_regret'])
+  ball_cols = torch.bincount((eu.raw(env)._state['state'] & 0xFF), minlength=5).float() / B
+  assert float((ball_cols - 0.2).abs().max()) < 0.005                      # randint(5) is uniform
+
+
+def test_physics_full_batch_one_step_teacher_forced():
+  """cartpole + mountain_car at B=2^20 (BASELINE config 4): one teacher-forced step on all lanes vs the oracle."""
+  for family, kwargs in (('cartpole', {}), ('mountain_car', {})):
+    n = 1 << 16                                                           # oracle lanes (f64 C loop)
+    env = eu.make_env(family, kwargs, batch=B, lane_offset=0, seed=3, num_buffers=1)
+    g = torch.Generator(device='cuda'); g.manual_seed(5)
+    for t in range(60):
+      a = torch.randint(3, (B,), generator=g, device='cuda', dtype=torch.int32)
+      ts = env.step(a)
+    obs = ts.observation
+    assert bool(torch.isfinite(obs).all())
+    if family == 'cartpole':
+      assert float((obs[:, 0, 2] ** 2 + obs[:, 0, 3] ** 2 - 1).abs().max()) < 1e-5   # sin^2 + cos^2
+    else:
+      assert bool((obs[:, 0, 0] >= -1.2).all()) and bool((obs[:, 0, 0] <= 0.6).all())
+      assert bool((obs[:, 0, 1].abs() <= 0.07 + 1e-7).all())
+    orc = coracle.OracleEnv(family, kwargs, np.arange(n, dtype=np.uint64), seed=3)
+    r_env = eu.raw(env)
+    st = r_env._state['state'][:, :n].double().cpu().numpy()
+    steps = r_env._state['steps'][:n].cpu().numpy()
+    if family == 'cartpole':
+      orc.s['state'][:, :4] = st.T
+      orc.s['state'][:, 4] = (steps & 0x3FFFFFFF) * 0.01
+    else:
+      orc.s['position'][:] = st[0]; orc.s['velocity'][:] = st[1]; orc.s['timestep'][:] = steps & 0x3FFFFFFF
+    orc.reset_next[:] = (steps >> 30) & 1
+    a = torch.randint(3, (B,), generator=g, device='cuda', dtype=torch.int32)
+    ts = env.step(a)
+    ost, orr, od, oo = orc.call(a[:n].cpu().numpy(), 60)
+    gst = ts.step_type[:n].cpu().numpy()
+    same = gst == ost
+    assert (~same).sum() <= 2
+    np.testing.assert_allclose(ts.observation[:n].cpu().numpy()[same], oo[same], rtol=1e-6, atol=1e-6)

@@ -1,0 +1,72 @@
+"""GPU: the heterogeneous sweep (BASELINE config 5) — segments of different families advanced by one
+captured HIP graph reproduce, lane for lane, standalone environments stepped eagerly; plus the
+host-side segment table / bin packing."""
+import numpy as np
+import pytest
+import torch
+
+import bsuite_amd
+from bsuite_amd import sweep
+from bsuite_amd import sweep_batch as sb
+from tests import engine_util as eu
+from tests import golden_util as gu
+
+IDS = ['bandit/3', 'bandit_noise/7', 'catch/0', 'catch_scale/5', 'deep_sea/2', 'deep_sea_stochastic/1',
+       'discounting_chain/4', 'memory_len/6', 'memory_size/9', 'umbrella_length/3', 'umbrella_distract/12',
+       'cartpole/0', 'cartpole_noise/4', 'cartpole_swingup/7', 'mountain_car/0', 'mountain_car_scale/9',
+       'mnist/0', 'mnist_noise/2']
+
+
+def test_segment_table_and_bin_packing():
+  table = sb.segment_table(sweep.SWEEP, 1 << 20)
+  assert len(table) == 468 and table[0] == ('bandit/0', 0, 2240)
+  assert table[-1][2] == 2240 + (1 << 20) - 2240 * 468 and table[-1][1] + table[-1][2] == 1 << 20
+  for (_, b0, n0), (_, b1, _) in zip(table, table[1:]):
+    assert b0 + n0 == b1
+  costs = [5.0, 1.0, 1.0, 1.0, 4.0, 3.0, 2.0, 2.0]
+  ranks = sb.assign_segments(costs, 3)
+  loads = [sum(c for c, r in zip(costs, ranks) if r == k) for k in range(3)]
+  assert max(loads) - min(loads) <= 2.0 and sorted(set(ranks)) == [0, 1, 2]
+
+
+@pytest.mark.gpu
+def test_graph_replayed_sweep_equals_standalone_envs(tmp_path):
+  from bsuite_amd.utils import datasets
+  imgs, labels = gu.mnist_dataset()
+  datasets.write_idx_files(str(tmp_path), imgs.view(np.uint8), labels)
+  mn = dict(data_dir=str(tmp_path))
+  kw = dict(mnist=mn, mnist_noise=mn, mnist_scale=mn)
+  total, seed, reps = 18 * 300 + 7, 123, 25
+  batch = sb.SweepBatch(IDS, total, seed=seed, env_kwargs=kw, num_streams=4)
+  assert batch.lanes() == total and len(batch.envs) == len(IDS)
+  acts = batch.random_actions(seed=1)
+  batch.capture(acts)                                    # call 0 eager + capture
+  for _ in range(reps):
+    outs = batch.replay()
+  torch.cuda.synchronize()
+  for (bid, begin, lanes), a, out in zip(batch.segments, acts, outs):
+    name = bid.split('/')[0]
+    ekw = dict(kw.get(name, {}))
+    if sweep.SETTINGS[bid].get('seed', 0) is None or 'seed' not in sweep.SETTINGS[bid]:
+      ekw['seed'] = seed
+    ref = bsuite_amd.load_from_id(bid, batch=lanes, lane_offset=begin, num_buffers=1, **ekw)
+    for _ in range(reps + 1):
+      ts = ref.step(a)
+    physics = name.startswith(('cartpole', 'mountain_car'))
+    for x, y in zip(eu.to_np(out), eu.to_np(ts)):
+      np.testing.assert_array_equal(x, y, err_msg=bid)   # same kernels, same draws: identical even for f32 physics
+    for k, v in ref.bsuite_info().items():
+      torch.testing.assert_close(batch.envs[batch.segments.index((bid, begin, lanes))].bsuite_info()[k], v,
+                                 rtol=0, atol=0)
+    del physics
+  s = batch.summary()
+  assert set(s) == set(IDS) and s['bandit/3']['episodes_started'] >= 300
+
+
+@pytest.mark.gpu
+def test_sweep_rank_assignment_is_a_partition():
+  a = sb.SweepBatch(IDS[:8], 8 * 64, rank=0, world_size=2, seed=1)
+  b = sb.SweepBatch(IDS[:8], 8 * 64, rank=1, world_size=2, seed=1)
+  ids_a = [s[0] for s in a.segments]
+  ids_b = [s[0] for s in b.segments]
+  assert sorted(ids_a + ids_b) == sorted(IDS[:8]) and not set(ids_a) & set(ids_b)
