@@ -55,10 +55,21 @@ class TimeStepPtrs(ctypes.Structure):
               ('step_type', ctypes.c_void_p), ('observation', ctypes.c_void_p)]
 
 
+class Logging(ctypes.Structure):
+  _fields_ = [('steps', ctypes.c_void_p), ('episode', ctypes.c_void_p),
+              ('total_return', ctypes.c_void_p), ('episode_len', ctypes.c_void_p),
+              ('episode_return', ctypes.c_void_p), ('rows', ctypes.c_void_p),
+              ('n_rows', ctypes.c_void_p), ('info', ctypes.c_void_p),
+              ('log_points', ctypes.c_void_p), ('n_log_points', ctypes.c_int32),
+              ('max_rows', ctypes.c_int32), ('n_info', ctypes.c_int32),
+              ('log_by_step', ctypes.c_int32), ('log_every', ctypes.c_int32),
+              ('_pad', ctypes.c_int32)]
+
+
 class Call(ctypes.Structure):
   _fields_ = [('n_lanes', ctypes.c_int64), ('force_reset', ctypes.c_int32), ('_pad', ctypes.c_int32),
               ('stream', Stream), ('wrap', RewardWrap), ('counters', ctypes.c_void_p),
-              ('hip_stream', ctypes.c_void_p)]
+              ('hip_stream', ctypes.c_void_p), ('logging', ctypes.POINTER(Logging))]
 
 
 class DeepSeaCfg(ctypes.Structure):
@@ -151,7 +162,8 @@ for _name, (_args, _res) in _SIGS.items():
   _fn.restype = _res
 if MISSING:
   raise NativeLibraryError(f'{SO_PATH} does not export {MISSING}; rebuild with `python -m bsuite_amd.build --force`')
-if lib.bsx_abi_version() != 1:
+ABI_VERSION = 2
+if lib.bsx_abi_version() != ABI_VERSION:
   raise NativeLibraryError('ABI version mismatch between bsuite_amd/_native.py and libbsuite_amd.so')
 
 

@@ -5,9 +5,9 @@ Every loader accepts the reference's keyword arguments (the sweep settings) plus
 keyword-only extras: `batch` (None = scalar dm_env view, B = vectorised), `device`, `lane_offset`,
 `num_buffers`, and — where the reference setting has `seed: None` — an optional `seed` override.
 
-`load_and_record*` (bsuite.py:111-167) wrap the env in CSV/terminal loggers; logging is out of
-scope of the hot path and those entry points raise NotImplementedError naming
-the reference function they would replace.
+`load_and_record*` (bsuite.py:111-167) wrap the env in the batched `Logging` wrapper with a CSV or
+terminal logger: the per-step bookkeeping runs inside the kernels, the CSV
+files use bsuite's wire format.
 """
 from typing import Any, Mapping, Tuple
 
@@ -128,17 +128,29 @@ def load_from_id(bsuite_id: str, **engine_kwargs) -> base.Environment:
 
 
 def load_and_record(bsuite_id: str, save_path: str, logging_mode: str = 'csv',
-                    overwrite: bool = False):
-  if logging_mode not in ('csv', 'terminal'):
+                    overwrite: bool = False, **engine_kwargs):
+  """Returns a bsuite environment wrapped with CSV or terminal logging (bsuite.py:111-122)."""
+  if logging_mode == 'csv':
+    return load_and_record_to_csv(bsuite_id, save_path, overwrite, **engine_kwargs)
+  elif logging_mode == 'terminal':
+    return load_and_record_to_terminal(bsuite_id, **engine_kwargs)
+  else:
     raise ValueError((f'Unrecognised logging_mode "{logging_mode}". '
                       'Must be "csv" or "terminal".'))
-  raise NotImplementedError('bsuite.load_and_record (bsuite.py:111-122): logging wrappers are outside '
-                            'the env-step hot path (SURVEY §8 f-1/f-2).')
 
 
-def load_and_record_to_csv(bsuite_id: str, results_dir: str, overwrite: bool = False):
-  raise NotImplementedError('bsuite.load_and_record_to_csv (bsuite.py:125-159) is outside the hot path.')
+def load_and_record_to_csv(bsuite_id: str, results_dir: str, overwrite: bool = False,
+                           **engine_kwargs):
+  """Returns a bsuite environment that saves results to CSV (bsuite.py:125-159); the files load
+  with the reference's `bsuite.logging.csv_load.load_bsuite(results_dir)`."""
+  from bsuite_amd.logging import csv_logging  # pylint: disable=import-outside-toplevel
+  raw_env = load_from_id(bsuite_id, **engine_kwargs)
+  return csv_logging.wrap_environment(env=raw_env, bsuite_id=bsuite_id, results_dir=results_dir,
+                                      overwrite=overwrite)
 
 
-def load_and_record_to_terminal(bsuite_id: str):
-  raise NotImplementedError('bsuite.load_and_record_to_terminal (bsuite.py:162-167) is outside the hot path.')
+def load_and_record_to_terminal(bsuite_id: str, **engine_kwargs):
+  """Returns a bsuite environment that logs to terminal (bsuite.py:162-167)."""
+  from bsuite_amd.logging import terminal_logging  # pylint: disable=import-outside-toplevel
+  raw_env = load_from_id(bsuite_id, **engine_kwargs)
+  return terminal_logging.wrap_environment(raw_env)

@@ -29,6 +29,7 @@ struct bsx_ctl {
   uint64_t wrap_seed;
   int32_t wrap_kind;
   int32_t force_reset;
+  bsx_logging_t log;        // log.steps == nullptr: logging off
 };
 
 __device__ __forceinline__ uint64_t bsx_step_of(const bsx_ctl& c) {
@@ -49,14 +50,58 @@ __device__ __forceinline__ double bsx_wrap_reward(const bsx_ctl& c, uint64_t lan
   return reward;
 }
 
+// `Logging._track` + `_log_bsuite_data` of bsuite/utils/wrappers.py:85-125 for one lane.  `reward`
+// is the f64 reward the outermost wrapper returned (0.0 on FIRST, where the reference adds
+// `timestep.reward or 0.0`).  The family's step function has already applied this call's updates
+// to its info columns, so the snapshot sees the same bsuite_info() the reference logs.
+__device__ __forceinline__ void bsx_track(const bsx_ctl& c, int64_t i, int type, double reward) {
+  BSX_NO_CONTRACT
+  const bsx_logging_t& g = c.log;
+  int64_t steps = g.steps[i], episode = g.episode[i], ep_len = g.episode_len[i];
+  double total = g.total_return[i], ep_ret = g.episode_return[i];
+  if (type != BSX_FIRST) { steps += 1; ep_len += 1; }                    // :87-89
+  if (type == BSX_LAST) episode += 1;                                     // :90-91
+  ep_ret += reward;                                                       // :92
+  total += reward;                                                        // :93
+  bool log = false;
+  const int64_t key = g.log_by_step ? steps : episode;
+  if (g.log_by_step || type == BSX_LAST) {                                // :96-102
+    log = g.log_every != 0;
+    int lo = 0, hi = g.n_log_points;                                      // _logarithmic_logging :140-147
+    while (lo < hi) {
+      const int mid = (lo + hi) >> 1;
+      const int64_t v = g.log_points[mid];
+      if (v == key) { log = true; break; }
+      if (v < key) lo = mid + 1; else hi = mid;
+    }
+  }
+  if (log) {                                                              // _log_bsuite_data :112-125
+    const int n = g.n_rows[i];
+    g.n_rows[i] = n + 1;
+    if (n < g.max_rows) {
+      const int w = 5 + g.n_info;
+      double* row = g.rows + ((int64_t)i * g.max_rows + n) * w;
+      row[0] = (double)steps; row[1] = (double)episode; row[2] = total;
+      row[3] = (double)ep_len; row[4] = ep_ret;
+      for (int k = 0; k < g.n_info; ++k) row[5 + k] = g.info[(int64_t)k * c.n_lanes + i];
+    }
+  }
+  if (type == BSX_LAST) { ep_len = 0; ep_ret = 0.0; }                     // :105-107
+  g.steps[i] = steps; g.episode[i] = episode; g.episode_len[i] = ep_len;
+  g.total_return[i] = total; g.episode_return[i] = ep_ret;
+}
+
 // Writes the scalar TimeStep fields of one lane (coalesced: lane i -> element i of each column).
 __device__ __forceinline__ void bsx_emit(const bsx_ctl& c, const bsx_timestep_t& out, int64_t i,
                                          uint64_t lane, uint64_t step, int type, double reward) {
   float r = 0.0f, d = 1.0f;   // FIRST: dm_env.restart has reward/discount None -> 0 / 1 in a batch
+  double wrapped = 0.0;
   if (type != BSX_FIRST) {
-    r = (float)bsx_wrap_reward(c, lane, step, reward);
+    wrapped = bsx_wrap_reward(c, lane, step, reward);
+    r = (float)wrapped;
     d = (type == BSX_LAST) ? 0.0f : 1.0f;
   }
+  if (c.log.steps != nullptr) bsx_track(c, i, type, wrapped);
   out.reward[i] = r;
   out.discount[i] = d;
   out.step_type[i] = (int8_t)type;

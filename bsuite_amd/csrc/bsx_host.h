@@ -16,6 +16,15 @@ static inline int bsx_check_call(const bsx_call_t* call, const void* action, con
   if (action == nullptr && !call->force_reset) return BSX_ENULL;
   if ((reinterpret_cast<uintptr_t>(out.observation) & 15u) != 0) return BSX_EALIGN;
   if (call->wrap.kind < BSX_WRAP_NONE || call->wrap.kind > BSX_WRAP_NOISE) return BSX_EINVAL;
+  if (call->logging != nullptr) {
+    const bsx_logging_t* g = call->logging;
+    if (g->steps == nullptr || g->episode == nullptr || g->total_return == nullptr || g->episode_len == nullptr ||
+        g->episode_return == nullptr || g->rows == nullptr || g->n_rows == nullptr)
+      return BSX_ENULL;
+    if (g->n_info < 0 || g->max_rows < 0 || g->n_log_points < 0) return BSX_EINVAL;
+    if (g->n_info > 0 && g->info == nullptr) return BSX_ENULL;
+    if (g->n_log_points > 0 && g->log_points == nullptr) return BSX_ENULL;
+  }
   return 0;
 }
 
@@ -31,6 +40,8 @@ static inline bsx_ctl bsx_make_ctl(const bsx_call_t* call) {
   c.wrap_seed = call->wrap.seed;
   c.wrap_kind = call->wrap.kind;
   c.force_reset = call->force_reset;
+  if (call->logging != nullptr) c.log = *call->logging;
+  else c.log = bsx_logging_t{};
   return c;
 }
 

@@ -175,6 +175,49 @@ class Environment(dm_env.EnvironmentBase):
     self._step_index += 1
     return out
 
+  # ----------------------------------------------------------------------------------------
+  # batched `Logging` bookkeeping (bsuite/utils/wrappers.py:34-147), fused into the kernels
+  def enable_logging(self, log_by_step: bool = False, log_every: bool = False,
+                     max_rows: Optional[int] = None, max_count: Optional[int] = None):
+    """Turns on per-lane steps/episode/return tracking and log-spaced snapshot rows.
+
+    max_count: largest episode (or step) count to tabulate log points for (default: 100 x
+    bsuite_num_episodes, at least 10^6).  max_rows: snapshot rows kept per lane (default: number of
+    log points up to max_count, or 4096 with log_every)."""
+    from bsuite_amd.utils import wrappers as _w  # pylint: disable=import-outside-toplevel
+    self._ensure_allocated()
+    if max_count is None:
+      max_count = max(10 ** 6, 100 * int(getattr(self, 'bsuite_num_episodes', 0) or 0))
+    points = _w.logarithmic_logging_points(max_count)
+    if max_rows is None:
+      max_rows = 4096 if log_every else len(points) + 2
+    B, dev = self._batch, self._device
+    n_info = len(self._info_keys)
+    lg = dict(
+        steps=torch.zeros(B, dtype=torch.int64, device=dev),
+        episode=torch.zeros(B, dtype=torch.int64, device=dev),
+        total_return=torch.zeros(B, dtype=torch.float64, device=dev),
+        episode_len=torch.zeros(B, dtype=torch.int64, device=dev),
+        episode_return=torch.zeros(B, dtype=torch.float64, device=dev),
+        rows=torch.zeros((B, max_rows, 5 + n_info), dtype=torch.float64, device=dev),
+        n_rows=torch.zeros(B, dtype=torch.int32, device=dev),
+        log_points=torch.tensor(points, dtype=torch.int64, device=dev))
+    self._logging = lg
+    self._logging_desc = _native.Logging(
+        steps=lg['steps'].data_ptr(), episode=lg['episode'].data_ptr(),
+        total_return=lg['total_return'].data_ptr(), episode_len=lg['episode_len'].data_ptr(),
+        episode_return=lg['episode_return'].data_ptr(), rows=lg['rows'].data_ptr(),
+        n_rows=lg['n_rows'].data_ptr(), info=self._info.data_ptr() if n_info else None,
+        log_points=lg['log_points'].data_ptr(), n_log_points=len(points), max_rows=max_rows,
+        n_info=n_info, log_by_step=int(bool(log_by_step)), log_every=int(bool(log_every)))
+    import ctypes  # pylint: disable=import-outside-toplevel
+    self._call_desc.logging = ctypes.pointer(self._logging_desc)
+    return lg
+
+  def logging_columns(self):
+    """Column names of a snapshot row, in row order (STANDARD_KEYS first, wrappers.py:30-31)."""
+    return ('steps', 'episode', 'total_return', 'episode_len', 'episode_return') + tuple(self._info_keys)
+
   def _coerce_actions(self, action) -> torch.Tensor:
     if self._scalar:
       a = int(action)

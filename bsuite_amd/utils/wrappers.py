@@ -8,10 +8,15 @@ the reference; step_type / discount / observation are untouched and `bsuite_info
 un-perturbed (wrappers.py:305-306, :368-369).  The wrapper classes keep the reference's surface:
 `reset/step/observation_spec/action_spec/raw_env/bsuite_info` and attribute delegation.
 
-`Logging` and `ImageObservation` (wrappers.py:34-247) are host-side bookkeeping / adapters and are
-out of scope of the hot path.
+`Logging` (wrappers.py:34-137) is the first "next" row: its per-step bookkeeping is
+fused into the kernels' emit epilogue (bsx_logging_t) so that every lane accumulates exactly what
+the reference wrapper would and snapshots a row at the same log-spaced counts; the Python class
+below keeps the reference constructor and forwards rows to a `logger.write(dict)` object.
+`ImageObservation` (wrappers.py:150-247) is an adapter and out of scope (§8 f-4).
 """
-from typing import Any, Dict, Optional
+from typing import Any, Dict, List, Optional, Sequence
+
+import numpy as np
 
 from bsuite_amd import _native
 from bsuite_amd import dm_env_compat as dm_env
@@ -81,3 +86,110 @@ class RewardScale(_RewardWrapper):
     self._reward_scale = reward_scale
     del seed  # the reference builds an unused RandomState (wrappers.py:330)
     env._wrap = (_native.WRAP_SCALE, float(reward_scale), 0)  # pylint: disable=protected-access
+
+
+# Keys that are present for all experiments (wrappers.py:30-31).
+STANDARD_KEYS = frozenset(['steps', 'episode', 'total_return', 'episode_len', 'episode_return'])
+
+
+def _logarithmic_logging(episode: int, ratios: Optional[Sequence[float]] = None) -> bool:
+  """Returns `True` only at specific ratios of 10**exponent (restated from wrappers.py:140-147)."""
+  if ratios is None:
+    ratios = [1., 1.2, 1.4, 1.7, 2., 2.5, 3., 4., 5., 6., 7., 8., 9., 10.]
+  exponent = np.floor(np.log10(np.maximum(1, episode)))
+  special_vals = [10**exponent * ratio for ratio in ratios]
+  return any(episode == val for val in special_vals)
+
+
+def logarithmic_logging_points(max_count: int) -> List[int]:
+  """All counts in [0, max_count] at which `_logarithmic_logging` is true, ascending.  Candidates
+  are the rounded ratio multiples of each decade; each is confirmed with the float test itself so
+  the device table is exactly the reference predicate."""
+  ratios = [1., 1.2, 1.4, 1.7, 2., 2.5, 3., 4., 5., 6., 7., 8., 9., 10.]
+  cands = {0, 1}
+  decade = 1
+  while decade <= max_count:
+    cands.update(int(round(decade * r)) for r in ratios)
+    decade *= 10
+  return sorted(c for c in cands if c <= max_count and _logarithmic_logging(c))
+
+
+class Logging(_RewardWrapper):
+  """Environment wrapper to track and log bsuite stats (batched counterpart of wrappers.py:34-137).
+
+  Scalar view (`batch=None` env): every row the reference would write is passed to
+  `logger.write(dict)` right after the step that produced it — a drop-in for
+  `bsuite.utils.wrappers.Logging`.  Batched view: rows accumulate on the device per lane; read them
+  with `rows(lane)` / `dataframe(lane)` (or all lanes with `all_rows()`); `logger` may be None.
+  """
+
+  def __init__(self, env, logger=None, log_by_step: bool = False, log_every: bool = False,
+               max_rows: Optional[int] = None):
+    raw = env.raw_env if hasattr(env, 'raw_env') else env
+    super().__init__(raw)
+    self._env = env
+    self._raw = raw
+    self._logger = logger
+    self._log_by_step = log_by_step
+    self._log_every = log_every
+    self._lg = raw.enable_logging(log_by_step=log_by_step, log_every=log_every, max_rows=max_rows)
+    self._columns = raw.logging_columns()
+    self._written = 0
+
+  def flush(self):
+    if hasattr(self._logger, 'flush'):
+      self._logger.flush()
+
+  def _forward_new_rows(self):
+    if self._logger is None or not self._raw._scalar:  # pylint: disable=protected-access
+      return
+    n = int(self._lg['n_rows'][0].item())
+    if n > self._written:
+      rows = self._lg['rows'][0, self._written:n].cpu().numpy()
+      for r in rows:
+        self._logger.write(self._row_dict(r))
+      self._written = n
+    if int(self._lg['episode'][0].item()) == self._raw.bsuite_num_episodes:
+      self.flush()
+
+  def _row_dict(self, r):
+    out = {}
+    for k, v in zip(self._columns, r):
+      if k.startswith('_'):
+        continue
+      if k in ('steps', 'episode', 'episode_len') or k in self._raw._info_int_keys:  # pylint: disable=protected-access
+        out[k] = int(v)
+      else:
+        out[k] = float(v)
+    return out
+
+  def reset(self):
+    timestep = self._env.reset()
+    self._forward_new_rows()
+    return timestep
+
+  def step(self, action):
+    timestep = self._env.step(action)
+    self._forward_new_rows()
+    return timestep
+
+  @property
+  def raw_env(self):
+    return self._raw
+
+  # -- batched access ---------------------------------------------------------------------
+  def num_rows(self):
+    """int32 [B] device tensor: rows each lane has logged so far."""
+    return self._lg['n_rows']
+
+  def rows(self, lane: int = 0) -> List[Dict[str, Any]]:
+    n = min(int(self._lg['n_rows'][lane].item()), self._lg['rows'].shape[1])
+    return [self._row_dict(r) for r in self._lg['rows'][lane, :n].cpu().numpy()]
+
+  def dataframe(self, lane: int = 0):
+    import pandas as pd  # pylint: disable=import-outside-toplevel
+    return pd.DataFrame(self.rows(lane))
+
+  def counters(self) -> Dict[str, Any]:
+    """The live per-lane accumulators as device tensors [B] (steps, episode, total_return, ...)."""
+    return {k: self._lg[k] for k in ('steps', 'episode', 'total_return', 'episode_len', 'episode_return')}

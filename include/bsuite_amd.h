@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define BSX_ABI_VERSION 1
+#define BSX_ABI_VERSION 2
 
 #define BSX_FIRST 0
 #define BSX_MID 1
@@ -70,6 +70,32 @@ typedef struct {
   float* observation;   /* [B, obs_numel], 16-byte aligned       */
 } bsx_timestep_t;
 
+/* Batched form of the `Logging` wrapper's bookkeeping (bsuite/utils/wrappers.py:85-125): per-lane
+ * steps / episode / total_return / episode_len / episode_return, updated from every emitted
+ * TimeStep with the f64 (wrapped) reward, and a per-lane buffer of snapshot rows
+ *   [steps, episode, total_return, episode_len, episode_return, info_0 .. info_{n_info-1}]
+ * appended whenever the reference would call `logger.write` — at the log-spaced episode (or step)
+ * counts of `_logarithmic_logging` (:140-147), supplied as a sorted device table.  Optional: a NULL
+ * `logging` pointer in bsx_call_t costs nothing. */
+typedef struct {
+  int64_t* steps;             /* [B]                                                              */
+  int64_t* episode;           /* [B]                                                              */
+  double* total_return;       /* [B]                                                              */
+  int64_t* episode_len;       /* [B]                                                              */
+  double* episode_return;     /* [B]                                                              */
+  double* rows;               /* [B, max_rows, 5 + n_info]                                        */
+  int32_t* n_rows;            /* [B] rows the reference would have written (may exceed max_rows;
+                                 rows beyond max_rows are dropped, the count keeps running)       */
+  const double* info;         /* the family's info columns [n_info, B], or NULL when n_info == 0   */
+  const int64_t* log_points;  /* device, ascending: the counts at which a row is written           */
+  int32_t n_log_points;
+  int32_t max_rows;
+  int32_t n_info;
+  int32_t log_by_step;        /* wrappers.py:44 */
+  int32_t log_every;          /* wrappers.py:45 */
+  int32_t _pad;
+} bsx_logging_t;
+
 #define BSX_COUNTER_SHARDS 256
 #define BSX_COUNTER_STRIDE 16   /* uint64 per shard = one 128-byte line */
 
@@ -86,6 +112,7 @@ typedef struct {
                                ballots; one global atomic per workgroup per mask, spread over 256
                                cache lines (a single hot word serialises ~12 ns per arrival).      */
   void* hip_stream;         /* hipStream_t                                                       */
+  const bsx_logging_t* logging; /* host pointer or NULL (ABI v2)                                     */
 } bsx_call_t;
 
 /* ---- deep_sea : bsuite/environments/deep_sea.py:51-155 ------------------------------------ */

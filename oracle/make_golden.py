@@ -64,7 +64,9 @@ def _make_env(bs, family, kwargs, wrap):
 
 
 def _raw(env):
-  return env._env if hasattr(env, '_env') else env  # pylint: disable=protected-access
+  while hasattr(env, '_env'):
+    env = env._env  # pylint: disable=protected-access
+  return env
 
 
 def _policy_action(family, raw, policy, rnd, num_actions):
@@ -107,15 +109,30 @@ def _phys_state(family, raw):
   return None
 
 
+class _RowCollector:
+  """A `logger` for the reference Logging wrapper: keeps every row it is asked to write."""
+
+  def __init__(self):
+    self.rows = []
+
+  def write(self, data):
+    self.rows.append(dict(data))
+
+
 def run_case(bs, name, family, kwargs, lanes, T, seed=42, step0=0, wrap=None, policies=None,
-             reset_at=(), case_seed=0):
+             reset_at=(), case_seed=0, log=None):
   lanes = [int(x) for x in lanes]
   L = len(lanes)
   policies = list(policies or []) + ['random'] * L
-  envs, rngs = [], []
+  envs, rngs, collectors = [], [], []
   for lane in lanes:
     env = _make_env(bs, family, kwargs, wrap)
     rngs.append(replay.attach_replay(env, seed, lane))
+    if log is not None:   # the UNMODIFIED reference Logging wrapper (utils/wrappers.py:34-137)
+      from bsuite.utils import wrappers as ref_wrappers  # pylint: disable=import-outside-toplevel
+      col = _RowCollector()
+      collectors.append(col)
+      env = ref_wrappers.Logging(env, col, log_by_step=(log == 'by_step'), log_every=(log == 'every'))
     envs.append(env)
   num_actions = envs[0].action_spec().num_values
   obs_shape = tuple(envs[0].observation_spec().shape)
@@ -158,6 +175,18 @@ def run_case(bs, name, family, kwargs, lanes, T, seed=42, step0=0, wrap=None, po
              step_type=step_type, reward=reward, discount=discount, obs=obs, info=info)
   if phys is not None:
     out['phys'] = phys
+  if log is not None:
+    cols = ['steps', 'episode', 'total_return', 'episode_len', 'episode_return'] + info_keys
+    n_rows = np.array([len(c.rows) for c in collectors], np.int32)
+    rows = np.zeros((L, max(1, int(n_rows.max())), len(cols)), np.float64)
+    for l, c in enumerate(collectors):
+      for j, r in enumerate(c.rows):
+        assert sorted(r) == sorted(cols), (sorted(r), cols)
+        rows[l, j] = [float(r[k]) for k in cols]
+    out['log_rows'], out['log_n_rows'] = rows, n_rows
+    meta['log'] = log
+    meta['log_columns'] = cols
+    out['meta'] = np.array(json.dumps(meta))
   os.makedirs(OUT_DIR, exist_ok=True)
   path = os.path.join(OUT_DIR, name + '.npz')
   np.savez_compressed(path, **out)
@@ -235,6 +264,18 @@ def cases():
     add(f'swingup_{n}', 'cartpole_swingup',
         dict(height_threshold=n / 20, x_reward_threshold=1 - n / 20), LANES[:4], 1100,
         policies=['optimal'])
+  # Logging wrapper (utils/wrappers.py:34-137) around the environments: rows at log-spaced counts
+  add('logging_bandit', 'bandit', dict(mapping_seed=4), LANES, 130, log='by_episode')
+  add('logging_bandit_by_step', 'bandit', dict(mapping_seed=4), LANES[:4], 70, log='by_step')
+  add('logging_catch', 'catch', dict(), LANES[:6], 360, policies=['optimal'], log='by_episode', reset_at=(45,))
+  add('logging_catch_noise_by_step', 'catch', dict(), LANES[:4], 130, wrap=('noise', 0.5), log='by_step')
+  add('logging_deep_sea', 'deep_sea', dict(size=6, mapping_seed=2), LANES[:6], 260, policies=ds_pol,
+      log='by_episode')
+  add('logging_deep_sea_stochastic_every', 'deep_sea', dict(size=5, deterministic=False, mapping_seed=2),
+      LANES[:4], 60, policies=ds_pol, log='every')
+  add('logging_cartpole', 'cartpole', dict(), LANES[:4], 1500, log='by_episode')
+  add('logging_umbrella_scale', 'umbrella_chain', dict(chain_length=3, n_distractor=4), LANES[:4], 200,
+      wrap=('scale', 30.0), log='by_episode')
   # mnist bandit (mnist.py) on the synthetic idx files staged in /tmp/mnist by main()
   add('mnist_synthetic', 'mnist', dict(), LANES, 40, policies=['optimal'], reset_at=(7,))
   add('mnist_fraction', 'mnist', dict(fraction=0.25), LANES[:4], 30, policies=['optimal'], step0=BIG_STEP)

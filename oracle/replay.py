@@ -74,7 +74,7 @@ def attach_replay(env, seed, lane, wrap_seed=None):
   """Swap the reference env's RandomState(s) for replays; returns the list to `begin_step` on."""
   rngs = []
   inner = env
-  if hasattr(env, '_env'):  # RewardNoise / RewardScale wrapper (utils/wrappers.py:250,313)
+  if hasattr(env, '_env') and hasattr(env, '_rng'):  # RewardNoise / RewardScale wrapper (utils/wrappers.py:250,313)
     w = ReplayRNG(seed if wrap_seed is None else wrap_seed, lane, S.STREAM_WRAP)
     env._rng = w  # pylint: disable=protected-access
     rngs.append(w)

@@ -36,6 +36,11 @@ def test_engine_matches_reference(name):
     idx = slice(i0, i0 + n)
     env = eu.make_env(fam, kwargs, batch=n, lane_offset=lane0, seed=meta['seed'], wrap=wrap)
     eu.raw(env)._step_index = meta['step0']
+    logged = None
+    if meta.get('log'):
+      from bsuite_amd.utils import wrappers
+      env = logged = wrappers.Logging(env, None, log_by_step=meta['log'] == 'by_step',
+                                      log_every=meta['log'] == 'every', max_rows=g['log_rows'].shape[1] + 3)
     for t in range(T):
       if phys and t > 0:
         _force_physics_state(env, fam, g['phys'][t - 1], idx)
@@ -63,3 +68,17 @@ def test_engine_matches_reference(name):
           np.testing.assert_allclose(got, g['info'][t, idx, j], rtol=1e-9, atol=1e-9, err_msg=f'{k} t={t}')
         else:
           np.testing.assert_array_equal(got, g['info'][t, idx, j], err_msg=f'{name} {k} t={t}')
+    if logged is not None:   # rows the unmodified reference Logging wrapper wrote, per lane
+      assert list(eu.raw(env).logging_columns()[:5]) == meta['log_columns'][:5]
+      cols = [meta['log_columns'].index(c) for c in eu.raw(env).logging_columns() if not c.startswith('_')]
+      keep = [j for j, c in enumerate(eu.raw(env).logging_columns()) if not c.startswith('_')]
+      n_rows = logged.num_rows().cpu().numpy()
+      np.testing.assert_array_equal(n_rows, g['log_n_rows'][idx], err_msg=f'{name} n_rows')
+      rows = logged._lg['rows'].cpu().numpy()
+      for l in range(n):
+        want = g['log_rows'][i0 + l, :n_rows[l]][:, cols]
+        got = rows[l, :n_rows[l]][:, keep]
+        if phys:
+          np.testing.assert_allclose(got, want, rtol=1e-9, atol=1e-9, err_msg=f'{name} lane {l}')
+        else:
+          np.testing.assert_array_equal(got, want, err_msg=f'{name} lane {l}')
