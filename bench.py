@@ -113,7 +113,8 @@ def bench_sweep(args, torch, dist, dev, rank, world):
   local_bytes = sum(l * sb.bytes_per_step(int(np.prod(e.observation_spec().shape)))
                     for e, (_, _, l) in zip(batch.envs, batch.segments))
   if world > 1:
-    t = torch.tensor([wall, step_ms, float(local_bytes)], dtype=torch.float64, device=dev)
+    t = torch.tensor([wall, step_ms, float(local_bytes)], dtype=torch.float64,
+                     device=dev if dist.get_backend() == 'nccl' else 'cpu')
     mx = t.clone()
     dist.all_reduce(mx, op=dist.ReduceOp.MAX)
     dist.all_reduce(t, op=dist.ReduceOp.SUM)
@@ -159,9 +160,14 @@ def main():
   world = int(os.environ.get('WORLD_SIZE', '1'))
   rank = int(os.environ.get('RANK', '0'))
   local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+  # Test hooks (single-GPU boxes): BSX_BENCH_BACKEND=gloo + BSX_BENCH_SINGLE_DEVICE=1 run all ranks
+  # on cuda:0 so the multi-rank control flow can be exercised without a multi-GPU node.
+  backend = os.environ.get('BSX_BENCH_BACKEND', 'nccl')
+  if os.environ.get('BSX_BENCH_SINGLE_DEVICE'):
+    local_rank = 0
   if world > 1:
     os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-    dist.init_process_group('nccl')
+    dist.init_process_group(backend)
   assert args.gpus == world, f'--gpus {args.gpus} but WORLD_SIZE={world}'
   torch.cuda.set_device(local_rank)
   dev = torch.device('cuda', local_rank)
@@ -240,7 +246,8 @@ def main():
   gathered = bdist.all_gather_summary(vec)
   summary = bdist.reduce_summary(gathered, names)
   if world > 1:
-    t_wall = torch.tensor([wall, kernel_ms], dtype=torch.float64, device=dev)
+    t_wall = torch.tensor([wall, kernel_ms], dtype=torch.float64,
+                          device=dev if dist.get_backend() == 'nccl' else 'cpu')
     dist.all_reduce(t_wall, op=dist.ReduceOp.MAX)
     wall, kernel_ms = float(t_wall[0].item()), float(t_wall[1].item())
 

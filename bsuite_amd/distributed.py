@@ -45,9 +45,12 @@ def all_gather_summary(vec: torch.Tensor, group: Optional[dist.ProcessGroup] = N
   if not (dist.is_available() and dist.is_initialized()):
     return vec.unsqueeze(0)
   world = dist.get_world_size(group)
-  out = [torch.empty_like(vec) for _ in range(world)]
-  dist.all_gather(out, vec, group=group)
-  return torch.stack(out)
+  src = vec
+  if vec.is_cuda and dist.get_backend(group) != 'nccl':   # gloo (tests): gather through host memory
+    src = vec.cpu()
+  out = [torch.empty_like(src) for _ in range(world)]
+  dist.all_gather(out, src, group=group)
+  return torch.stack(out).to(vec.device)
 
 
 def reduce_summary(gathered: torch.Tensor, names: Tuple[str, ...]) -> Dict[str, float]:
