@@ -91,10 +91,10 @@ __device__ __forceinline__ void bsx_track(const bsx_ctl& c, int64_t i, int type,
   g.total_return[i] = total; g.episode_return[i] = ep_ret;
 }
 
-// Writes the scalar TimeStep fields of one lane (coalesced: lane i -> element i of each column).
-__device__ __forceinline__ void bsx_emit(const bsx_ctl& c, const bsx_timestep_t& out, int64_t i,
-                                         uint64_t lane, uint64_t step, int type, double reward) {
-  float r = 0.0f, d = 1.0f;   // FIRST: dm_env.restart has reward/discount None -> 0 / 1 in a batch
+// The scalar TimeStep fields of one lane: wrapper epilogue + Logging bookkeeping, values only.
+__device__ __forceinline__ void bsx_emit_values(const bsx_ctl& c, int64_t i, uint64_t lane, uint64_t step,
+                                                int type, double reward, float& r, float& d) {
+  r = 0.0f; d = 1.0f;         // FIRST: dm_env.restart has reward/discount None -> 0 / 1 in a batch
   double wrapped = 0.0;
   if (type != BSX_FIRST) {
     wrapped = bsx_wrap_reward(c, lane, step, reward);
@@ -102,6 +102,13 @@ __device__ __forceinline__ void bsx_emit(const bsx_ctl& c, const bsx_timestep_t&
     d = (type == BSX_LAST) ? 0.0f : 1.0f;
   }
   if (c.log.steps != nullptr) bsx_track(c, i, type, wrapped);
+}
+
+// Writes the scalar TimeStep fields of one lane (coalesced: lane i -> element i of each column).
+__device__ __forceinline__ void bsx_emit(const bsx_ctl& c, const bsx_timestep_t& out, int64_t i,
+                                         uint64_t lane, uint64_t step, int type, double reward) {
+  float r, d;
+  bsx_emit_values(c, i, lane, step, type, reward, r, d);
   out.reward[i] = r;
   out.discount[i] = d;
   out.step_type[i] = (int8_t)type;
@@ -132,98 +139,92 @@ __device__ __forceinline__ void bsx_flush_counts(const bsx_ctl& c, const unsigne
   if (s_cnt[1]) atomicAdd(&shard[1], (unsigned long long)s_cnt[1]);
 }
 
-// Cooperative one-/two-hot observation tile writer (deep_sea, catch).
+// Advance kernel of the two-kernel families (deep_sea, catch): every thread advances FOUR
+// consecutive lanes with 16-byte column loads/stores (action, packed state, reward, discount) and
+// one 4-byte step_type store — a quarter of the memory instructions and workgroups of a
+// lane-per-thread kernel, which matters because at B=2^20 this kernel is latency/launch-bound
+// (~8-12 us for 22 MB).  The vector path requires 16-byte aligned columns (checked on the host,
+// `vec_ok`); otherwise every thread takes the scalar branch.
 //
-// The block owns `lanes_here` consecutive lanes, i.e. one contiguous run of lanes_here*cells floats
-// starting at `tile` (16-byte aligned because lanes-per-block is a multiple of 4).  Consecutive
-// threads own consecutive 16-byte chunks, so every wave store instruction covers 1 KiB of
-// contiguous HBM; UNROLL independent stores are in flight per thread (measured on MI355X:
-// lane-interleaved 16-B stores with 4-8 in flight reach 6.4-7.0 TB/s, per-thread-contiguous 64 B
-// only 3.6 TB/s — profiles/r01_store_calibration2.log).  hot_a/hot_b (LDS) hold each lane's flat
-// hot-cell index or -1.
+// Fam provides: struct args { bsx_ctl ctl; const int32_t* action; int32_t* state; bsx_timestep_t out;
+//                             double* info; ... };  struct shared;  static stage(args, shared&);
+//   static int advance(args, shared, i, lane, step, st, act, nst&, reward&)
+typedef int bsx_i4 __attribute__((ext_vector_type(4)));
+
+template <class Fam>
+__global__ void __launch_bounds__(BSX_BLOCK) bsx_advance4_kernel(const typename Fam::args a, const int vec_ok) {
+  __shared__ typename Fam::shared s_fam;
+  __shared__ unsigned int s_cnt[2];
+  if (threadIdx.x < 2) s_cnt[threadIdx.x] = 0;
+  Fam::stage(a, s_fam);
+  __syncthreads();
+  const int64_t i0 = ((int64_t)blockIdx.x * BSX_BLOCK + threadIdx.x) * 4;
+  const uint64_t step = bsx_step_of(a.ctl);
+  int types[4] = {-1, -1, -1, -1};
+  if (vec_ok && i0 + 3 < a.ctl.n_lanes) {
+    const bsx_i4 st4 = *reinterpret_cast<const bsx_i4*>(a.state + i0);
+    bsx_i4 act4 = {0, 0, 0, 0};
+    if (!a.ctl.force_reset) act4 = *reinterpret_cast<const bsx_i4*>(a.action + i0);
+    bsx_i4 nst4;
+    bsx_f4 r4, d4;
+    uint32_t packed_types = 0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int64_t i = i0 + j;
+      const uint64_t lane = a.ctl.lane_offset + (uint64_t)i;
+      int32_t nst; double reward;
+      const int t = Fam::advance(a, s_fam, i, lane, step, st4[j], act4[j], nst, reward);
+      float r, d;
+      bsx_emit_values(a.ctl, i, lane, step, t, reward, r, d);
+      nst4[j] = nst; r4[j] = r; d4[j] = d; types[j] = t;
+      packed_types |= (uint32_t)(t & 0xFF) << (8 * j);
+    }
+    *reinterpret_cast<bsx_i4*>(a.state + i0) = nst4;
+    *reinterpret_cast<bsx_f4*>(a.out.reward + i0) = r4;
+    *reinterpret_cast<bsx_f4*>(a.out.discount + i0) = d4;
+    *reinterpret_cast<uint32_t*>(a.out.step_type + i0) = packed_types;
+  } else if (vec_ok) {
+    // the last (< 4 lane) ragged group of the vector mapping
+    for (int j = 0; j < 4; ++j) {
+      const int64_t i = i0 + j;
+      if (i >= a.ctl.n_lanes) break;
+      const uint64_t lane = a.ctl.lane_offset + (uint64_t)i;
+      int32_t nst; double reward;
+      const int act = a.ctl.force_reset ? 0 : a.action[i];
+      const int t = Fam::advance(a, s_fam, i, lane, step, a.state[i], act, nst, reward);
+      a.state[i] = nst;
+      bsx_emit(a.ctl, a.out, i, lane, step, t, reward);
+      types[j] = t;
+    }
+  } else {
+    // unaligned columns: same four lanes per thread, but lane = block_base + j*256 + tid so that
+    // every scalar access is still coalesced across the wavefront
+    for (int j = 0; j < 4; ++j) {
+      const int64_t i = (int64_t)blockIdx.x * (4 * BSX_BLOCK) + j * BSX_BLOCK + threadIdx.x;
+      if (i >= a.ctl.n_lanes) break;
+      const uint64_t lane = a.ctl.lane_offset + (uint64_t)i;
+      int32_t nst; double reward;
+      const int act = a.ctl.force_reset ? 0 : a.action[i];
+      const int t = Fam::advance(a, s_fam, i, lane, step, a.state[i], act, nst, reward);
+      a.state[i] = nst;
+      bsx_emit(a.ctl, a.out, i, lane, step, t, reward);
+      types[j] = t;
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < 4; ++j) bsx_count_types(a.ctl, types[j], s_cnt);
+  __syncthreads();
+  bsx_flush_counts(a.ctl, s_cnt);
+}
+
 // n / cells for n < 2^20 via the host-built magic (bsx_div_magic); cells == 1 has no 32-bit magic.
 __device__ __forceinline__ uint32_t bsx_div_cells(uint32_t n, uint32_t cells, uint32_t cells_magic) {
   return cells == 1u ? n : __umulhi(n, cells_magic);
 }
 
-template <bool TWO_HOT>
-__device__ __forceinline__ bsx_f4 bsx_hot_chunk(uint32_t ch, uint32_t cells, uint32_t cells_magic,
-                                                bool aligned, const int* hot_a, const int* hot_b) {
-  const uint32_t f0 = ch << 2;
-  if (cells < 4u) {   // degenerate boards: a chunk spans several lanes, resolve per element
-    float e[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const uint32_t f = f0 + j;
-      const uint32_t lj = bsx_div_cells(f, cells, cells_magic);
-      const int r = (int)(f - lj * cells);
-      e[j] = (hot_a[lj] == r || (TWO_HOT && hot_b[lj] == r)) ? 1.0f : 0.0f;
-    }
-    bsx_f4 t = {e[0], e[1], e[2], e[3]};
-    return t;
-  }
-  const uint32_t l = __umulhi(f0, cells_magic);
-  const int r0 = (int)(f0 - l * cells);
-  int a0 = hot_a[l] - r0;                       // position of the hot cell relative to this chunk
-  int b0 = TWO_HOT ? hot_b[l] - r0 : -1;
-  bsx_f4 v;
-  v.x = (a0 == 0 || (TWO_HOT && b0 == 0)) ? 1.0f : 0.0f;
-  v.y = (a0 == 1 || (TWO_HOT && b0 == 1)) ? 1.0f : 0.0f;
-  v.z = (a0 == 2 || (TWO_HOT && b0 == 2)) ? 1.0f : 0.0f;
-  v.w = (a0 == 3 || (TWO_HOT && b0 == 3)) ? 1.0f : 0.0f;
-  if (!aligned) {
-    // the chunk may straddle into lane l+1: elements j >= over belong to the next lane's row
-    const int over = (int)cells - r0;           // 1..3 when straddling, >= 4 otherwise
-    if (over < 4) {
-      // matches found beyond the row end were comparisons against this lane's (out-of-row) index
-      // space and cannot be real: a hot index is < cells.  Patch in the next lane's cells.
-      const int a1 = hot_a[l + 1] + over;       // relative position inside this chunk
-      const int b1 = TWO_HOT ? hot_b[l + 1] + over : -1;
-      const bool valid1 = hot_a[l + 1] >= 0;
-      const bool validb = TWO_HOT && hot_b[l + 1] >= 0;
-      if (over <= 1) v.y = ((valid1 && a1 == 1) || (validb && b1 == 1)) ? 1.0f : 0.0f;
-      if (over <= 2) v.z = ((valid1 && a1 == 2) || (validb && b1 == 2)) ? 1.0f : 0.0f;
-      v.w = ((valid1 && a1 == 3) || (validb && b1 == 3)) ? 1.0f : 0.0f;
-    }
-  }
-  return v;
-}
-
-template <bool TWO_HOT, int UNROLL>
-__device__ __forceinline__ void bsx_write_hot_tile(float* __restrict__ tile, int lanes_here,
-                                                   uint32_t cells, uint32_t cells_magic,
-                                                   const int* hot_a, const int* hot_b) {
-  const uint32_t total = (uint32_t)lanes_here * cells;          // floats in this block's tile
-  const uint32_t n_chunks = total >> 2;
-  const bool aligned = (cells & 3u) == 0;
-  bsx_f4* __restrict__ t4 = reinterpret_cast<bsx_f4*>(tile);
-  uint32_t ch = threadIdx.x;
-  if (UNROLL > 1) {
-    for (; ch + (UNROLL - 1) * BSX_BLOCK < n_chunks; ch += UNROLL * BSX_BLOCK) {
-      bsx_f4 v[UNROLL];
-#pragma unroll
-      for (int u = 0; u < UNROLL; ++u)
-        v[u] = bsx_hot_chunk<TWO_HOT>(ch + u * BSX_BLOCK, cells, cells_magic, aligned, hot_a, hot_b);
-#pragma unroll
-      for (int u = 0; u < UNROLL; ++u) t4[ch + u * BSX_BLOCK] = v[u];
-    }
-  }
-  for (; ch < n_chunks; ch += BSX_BLOCK)
-    t4[ch] = bsx_hot_chunk<TWO_HOT>(ch, cells, cells_magic, aligned, hot_a, hot_b);
-  // ragged tail (< 4 floats) of an odd-sized final tile
-  const uint32_t f = (n_chunks << 2) + threadIdx.x;
-  if (f < total) {
-    const uint32_t l = bsx_div_cells(f, cells, cells_magic);
-    const int r = (int)(f - l * cells);
-    bool on = hot_a[l] == r;
-    if (TWO_HOT) on = on || hot_b[l] == r;
-    tile[f] = on ? 1.0f : 0.0f;
-  }
-}
-
 // ---------------------------------------------------------------------------------------------
-// Split-phase observation writer: a pure store stream over the whole [B x cells] observation
-// array, decoupled from the lane-advance kernel.  Block b writes the K*4 KiB run of floats
+// Observation stream kernel: a pure store stream over the whole [B x cells] observation array,
+// decoupled from the lane-advance kernel.  Block b writes the K*4 KiB run of floats
 // [b*K*1024, (b+1)*K*1024): K lane-interleaved 16-byte stores per thread, blocks in address order,
 // no loop — the shape of the fastest fill kernels measured on MI355X (profiles/r01/
 // store_calibration*.log).  The hot cells are recomputed from the packed state column the advance

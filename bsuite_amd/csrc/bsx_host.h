@@ -53,6 +53,23 @@ static inline int bsx_env_int(const char* name, int dflt) {
   return (v != nullptr && *v != '\0') ? atoi(v) : dflt;
 }
 
+// Launches the four-lanes-per-thread advance kernel; the 16-byte vector path needs every column
+// 16-byte aligned (torch allocations are), otherwise all threads take its scalar branch.
+template <class Fam>
+static inline int bsx_launch_advance(const typename Fam::args& a, const int32_t* action, const int32_t* state,
+                                     const bsx_timestep_t& out, hipStream_t st) {
+  const uintptr_t bits = reinterpret_cast<uintptr_t>(action) | reinterpret_cast<uintptr_t>(state) |
+                         reinterpret_cast<uintptr_t>(out.reward) | reinterpret_cast<uintptr_t>(out.discount) |
+                         reinterpret_cast<uintptr_t>(out.step_type);
+  static const int vec_env = bsx_env_int("BSX_ADVANCE_VEC", 1);
+  const int vec_ok = vec_env && (bits & 15u) == 0;
+  const int64_t threads = (a.ctl.n_lanes + 3) / 4;
+  const int64_t blocks = (threads + BSX_BLOCK - 1) / BSX_BLOCK;
+  if (blocks > 0x7FFFFFFF) return BSX_EINVAL;
+  bsx_advance4_kernel<Fam><<<dim3((unsigned)blocks), dim3(BSX_BLOCK), 0, st>>>(a, vec_ok);
+  return 0;
+}
+
 // Exact 64-bit magic for n / d (4 <= d <= 4096, n < 2^52): s = floor(log2 d) - 1.
 static inline bsx_div64 bsx_make_div64(uint32_t d) {
   bsx_div64 r;
