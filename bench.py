@@ -148,6 +148,9 @@ def main():
   ap.add_argument('--workload', default='deep_sea', choices=sorted(WORKLOADS) + ['sweep'])
   ap.add_argument('--lanes', type=int, default=1 << 20, help='lanes per GPU')
   ap.add_argument('--no-cpu-baseline', action='store_true')
+  ap.add_argument('--rollout', type=int, default=0,
+                  help='advance this many steps per entry-point call with env.rollout(actions[T,B]) '
+                       '(fused T-step kernel for the small-observation families)')
   ap.add_argument('--graph', type=int, default=0,
                   help='capture this many consecutive step() launches into one HIP graph and replay it '
                        '(for the tiny families whose per-step kernel is shorter than a host launch)')
@@ -181,7 +184,7 @@ def main():
   num_actions = env.action_spec().num_values
   gen = torch.Generator(device=dev)
   gen.manual_seed(1234 + rank)
-  n_act = max(32, args.graph)
+  n_act = max(32, args.graph, args.rollout)
   actions = torch.randint(num_actions, (n_act, B), generator=gen, device=dev, dtype=torch.int32)
 
   def sync_all():
@@ -205,6 +208,12 @@ def main():
     def run(n_steps):
       for _ in range(n_steps // args.graph):
         graph.replay()
+  elif args.rollout:
+    assert args.steps % args.rollout == 0 and args.warmup % args.rollout == 0, '--steps/--warmup must be multiples of --rollout'
+
+    def run(n_steps):
+      for _ in range(n_steps // args.rollout):
+        env.rollout(actions[:args.rollout])
   else:
     def run(n_steps):
       for t in range(n_steps):
@@ -271,7 +280,8 @@ def main():
                      'kernel_ms': kernel_ms,
                      'box_store_ceiling_GBps': store_ceiling_gbps,
                      'frac_of_box_store_ceiling': achieved / store_ceiling_gbps},
-        'launch': f'hipGraph x{args.graph}' if args.graph else 'eager',
+        'launch': (f'hipGraph x{args.graph}' if args.graph else
+                   f'rollout x{args.rollout} per call' if args.rollout else 'eager'),
         'episodes_finished': summary['episodes_finished'],
     }
     if world == 1 and not args.no_cpu_baseline:

@@ -38,11 +38,14 @@ __device__ __forceinline__ uint64_t bsx_step_of(const bsx_ctl& c) {
 
 // Reward epilogue of utils/wrappers.py:275-283 (RewardNoise) and :338-346 (RewardScale): non-FIRST
 // lanes only, evaluated in f64 like the reference, result cast to f32 once.
+// NOISE = 0 compiles the RewardNoise branch out: its ~100 f64 polynomial constants are otherwise
+// hoisted into VGPRs ahead of the T-step rollout loop and cost two thirds of the occupancy.
+template <int NOISE = -1>
 __device__ __forceinline__ double bsx_wrap_reward(const bsx_ctl& c, uint64_t lane, uint64_t step,
                                                   double reward) {
   BSX_NO_CONTRACT
   if (c.wrap_kind == BSX_WRAP_SCALE) return reward * c.wrap_param;
-  if (c.wrap_kind == BSX_WRAP_NOISE) {
+  if (NOISE != 0 && c.wrap_kind == BSX_WRAP_NOISE) {
     bsx_draws w;
     bsx_draws_init(&w, c.wrap_seed, lane, step, BSX_STREAM_WRAP);
     return reward + c.wrap_param * bsx_normal(&w);
@@ -92,26 +95,34 @@ __device__ __forceinline__ void bsx_track(const bsx_ctl& c, int64_t i, int type,
 }
 
 // The scalar TimeStep fields of one lane: wrapper epilogue + Logging bookkeeping, values only.
+// LOG: -1 decide at run time (c.log.steps != nullptr), 0 logging compiled out, 1 always track.
+template <int LOG = -1, int NOISE = -1>
 __device__ __forceinline__ void bsx_emit_values(const bsx_ctl& c, int64_t i, uint64_t lane, uint64_t step,
                                                 int type, double reward, float& r, float& d) {
   r = 0.0f; d = 1.0f;         // FIRST: dm_env.restart has reward/discount None -> 0 / 1 in a batch
   double wrapped = 0.0;
   if (type != BSX_FIRST) {
-    wrapped = bsx_wrap_reward(c, lane, step, reward);
+    wrapped = bsx_wrap_reward<NOISE>(c, lane, step, reward);
     r = (float)wrapped;
     d = (type == BSX_LAST) ? 0.0f : 1.0f;
   }
-  if (c.log.steps != nullptr) bsx_track(c, i, type, wrapped);
+  if (LOG == 1 || (LOG == -1 && c.log.steps != nullptr)) bsx_track(c, i, type, wrapped);
 }
 
-// Writes the scalar TimeStep fields of one lane (coalesced: lane i -> element i of each column).
+// Writes the scalar TimeStep fields of one lane (coalesced: lane i -> element oi of each column;
+// oi == i for step(), oi == t*B + i inside a fused T-step rollout).
+template <int LOG = -1, int NOISE = -1>
+__device__ __forceinline__ void bsx_emit_at(const bsx_ctl& c, const bsx_timestep_t& out, int64_t i, int64_t oi,
+                                            uint64_t lane, uint64_t step, int type, double reward) {
+  float r, d;
+  bsx_emit_values<LOG, NOISE>(c, i, lane, step, type, reward, r, d);
+  out.reward[oi] = r;
+  out.discount[oi] = d;
+  out.step_type[oi] = (int8_t)type;
+}
 __device__ __forceinline__ void bsx_emit(const bsx_ctl& c, const bsx_timestep_t& out, int64_t i,
                                          uint64_t lane, uint64_t step, int type, double reward) {
-  float r, d;
-  bsx_emit_values(c, i, lane, step, type, reward, r, d);
-  out.reward[i] = r;
-  out.discount[i] = d;
-  out.step_type[i] = (int8_t)type;
+  bsx_emit_at(c, out, i, i, lane, step, type, reward);
 }
 
 // Termination / restart masks by wavefront ballot.  Each wave popcounts its LAST / FIRST masks

@@ -16,6 +16,7 @@ static inline int bsx_check_call(const bsx_call_t* call, const void* action, con
   if (action == nullptr && !call->force_reset) return BSX_ENULL;
   if ((reinterpret_cast<uintptr_t>(out.observation) & 15u) != 0) return BSX_EALIGN;
   if (call->wrap.kind < BSX_WRAP_NONE || call->wrap.kind > BSX_WRAP_NOISE) return BSX_EINVAL;
+  if (call->n_steps < 0 || (call->n_steps > 1 && call->force_reset)) return BSX_EINVAL;
   if (call->logging != nullptr) {
     const bsx_logging_t* g = call->logging;
     if (g->steps == nullptr || g->episode == nullptr || g->total_return == nullptr || g->episode_len == nullptr ||
@@ -44,6 +45,8 @@ static inline bsx_ctl bsx_make_ctl(const bsx_call_t* call) {
   else c.log = bsx_logging_t{};
   return c;
 }
+
+static inline int bsx_n_steps(const bsx_call_t* call) { return call->n_steps > 1 ? call->n_steps : 1; }
 
 // magic for q = n / d via __umulhi(n, magic): exact for n < 2^20, d <= 4096
 static inline uint32_t bsx_div_magic(uint32_t d) { return (uint32_t)((0x100000000ull / d) + 1ull); }

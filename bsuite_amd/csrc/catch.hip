@@ -79,10 +79,18 @@ extern "C" int bsx_catch_step(const bsx_catch_t* cfg, const bsx_call_t* call, co
   a.rows = cfg->rows; a.columns = cfg->columns;
   const uint32_t cells = (uint32_t)(cfg->rows * cfg->columns);
   hipStream_t st = (hipStream_t)call->hip_stream;
-  rc = bsx_launch_advance<catch_fam>(a, action, state, out, st);
-  if (rc != 0) return rc;
   catch_hot fn{cfg->rows, cfg->columns};
-  rc = bsx_launch_hot_stream(out.observation, state, call->n_lanes, cells, bsx_div_magic(cells), fn, st, 2);
-  if (rc != 0) return rc;
+  const int n_steps = bsx_n_steps(call);
+  for (int t = 0; t < n_steps; ++t) {       // rollout: the kernel pair once per step, outputs [T,B,...]
+    const int64_t off = (int64_t)t * call->n_lanes;
+    a.ctl.step_index = call->stream.step_index + (uint64_t)t;
+    a.action = action ? action + off : action;
+    a.out.reward = out.reward + off; a.out.discount = out.discount + off; a.out.step_type = out.step_type + off;
+    a.out.observation = out.observation + off * (int64_t)cells;
+    rc = bsx_launch_advance<catch_fam>(a, a.action, state, a.out, st);
+    if (rc != 0) return rc;
+    rc = bsx_launch_hot_stream(a.out.observation, state, call->n_lanes, cells, bsx_div_magic(cells), fn, st, 2);
+    if (rc != 0) return rc;
+  }
   return bsx_launch_status();
 }

@@ -133,10 +133,8 @@ extern "C" int bsx_mnist_step(const bsx_mnist_t* cfg, const bsx_call_t* call, co
   a.images = cfg->images; a.labels = cfg->labels; a.num_data = cfg->num_data; a.num_pixels = cfg->num_pixels;
   const int64_t blocks_a = (call->n_lanes + BSX_BLOCK - 1) / BSX_BLOCK;
   if (blocks_a > 0x7FFFFFFF) return BSX_EINVAL;
-  mnist_advance_kernel<<<dim3((unsigned)blocks_a), dim3(BSX_BLOCK), 0, st>>>(a);
-
   mnist_observe_args o;
-  o.obs = out.observation; o.state = state; o.images = cfg->images; o.n_lanes = call->n_lanes;
+  o.state = state; o.images = cfg->images; o.n_lanes = call->n_lanes;
   o.cells = (uint32_t)cfg->num_pixels; o.cells_magic = bsx_div_magic(o.cells); o.dv = bsx_make_div64(o.cells);
   for (int k = 0; k < 256; ++k) o.lut[k] = cfg->pixel_lut[k];
   constexpr int K = 4;
@@ -144,6 +142,15 @@ extern "C" int bsx_mnist_step(const bsx_mnist_t* cfg, const bsx_call_t* call, co
   const uint64_t per_block = (uint64_t)K * 4 * BSX_BLOCK;
   const uint64_t blocks_o = (total + per_block - 1) / per_block;
   if (blocks_o > 0x7FFFFFFFull) return BSX_EINVAL;
-  mnist_observe_kernel<K><<<dim3((unsigned)blocks_o), dim3(BSX_BLOCK), 0, st>>>(o);
+  const int n_steps = bsx_n_steps(call);
+  for (int t = 0; t < n_steps; ++t) {       // rollout: the kernel pair once per step
+    const int64_t off = (int64_t)t * call->n_lanes;
+    a.ctl.step_index = call->stream.step_index + (uint64_t)t;
+    a.action = action ? action + off : action;
+    a.out.reward = out.reward + off; a.out.discount = out.discount + off; a.out.step_type = out.step_type + off;
+    mnist_advance_kernel<<<dim3((unsigned)blocks_a), dim3(BSX_BLOCK), 0, st>>>(a);
+    o.obs = out.observation + off * (int64_t)o.cells;
+    mnist_observe_kernel<K><<<dim3((unsigned)blocks_o), dim3(BSX_BLOCK), 0, st>>>(o);
+  }
   return bsx_launch_status();
 }

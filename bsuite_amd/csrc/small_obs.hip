@@ -16,56 +16,84 @@
 // reference forms them and cast once.
 #include "bsx_host.h"
 
-template <class Env, int LPB>
-__global__ void __launch_bounds__(BSX_BLOCK) small_obs_kernel(const typename Env::args a) {
+// n_steps == 1 is env.step()/reset(); n_steps = T > 1 is the fused rollout: the same thread advances
+// its lane T times inside one launch (actions [T,B], outputs [T,B,...]); per-lane state columns are
+// re-read from L2 by the thread that wrote them, so HBM sees only the action/TimeStep streams —
+// the tiny families are otherwise bound by one ~8 us launch per step.
+template <class Env, int LPB, bool ROLLOUT, int LOG, int NOISE>
+__global__ void __launch_bounds__(BSX_BLOCK) small_obs_kernel(const typename Env::args a, const int n_steps_arg) {
+  const int n_steps = ROLLOUT ? n_steps_arg : 1;   // the single-step instantiation has no loop: keeping
+                                                    // every kernarg live across iterations costs ~120 VGPRs
   extern __shared__ __attribute__((aligned(16))) float s_obs[];
   __shared__ unsigned int s_cnt[2];
   if (threadIdx.x < 2) s_cnt[threadIdx.x] = 0;
   __syncthreads();
   const int numel = a.obs_numel;
+  const int64_t B = a.ctl.n_lanes;
   const int64_t lane0 = (int64_t)blockIdx.x * LPB;
-  const int64_t remaining = a.ctl.n_lanes - lane0;
+  const int64_t remaining = B - lane0;
   const int lanes_here = remaining < LPB ? (int)remaining : LPB;
+  const uint64_t step0 = bsx_step_of(a.ctl);
 
-  if (LPB == BSX_BLOCK || threadIdx.x < LPB) {
-    const int64_t i = lane0 + threadIdx.x;
-    int type = -1;
-    if ((int)threadIdx.x < lanes_here) {
-      const uint64_t lane = a.ctl.lane_offset + (uint64_t)i;
-      const uint64_t step = bsx_step_of(a.ctl);
-      double reward = 0.0;
-      type = Env::step(a, i, lane, step, s_obs + (int)threadIdx.x * numel, reward);
-      bsx_emit(a.ctl, a.out, i, lane, step, type, reward);
+#pragma unroll 1
+  for (int t = 0; t < n_steps; ++t) {
+    if (LPB == BSX_BLOCK || threadIdx.x < LPB) {
+      const int64_t i = lane0 + threadIdx.x;
+      int type = -1;
+      if ((int)threadIdx.x < lanes_here) {
+        const uint64_t lane = a.ctl.lane_offset + (uint64_t)i;
+        const int64_t oi = (int64_t)t * B + i;
+        double reward = 0.0;
+        type = Env::step(a, i, oi, lane, step0 + (uint64_t)t, s_obs + (int)threadIdx.x * numel, reward);
+        bsx_emit_at<LOG, NOISE>(a.ctl, a.out, i, oi, lane, step0 + (uint64_t)t, type, reward);
+      }
+      bsx_count_types(a.ctl, type, s_cnt);
     }
-    bsx_count_types(a.ctl, type, s_cnt);
+    __syncthreads();
+
+    // stream the tile: [lanes_here x numel] floats, contiguous in HBM, 16-byte aligned start
+    float* __restrict__ tile = a.out.observation + ((int64_t)t * B + lane0) * (int64_t)numel;
+    const int total = lanes_here * numel;
+    const bool vec = ((((int64_t)t * B * numel) & 3) == 0);            // [t] slice 16-byte aligned?
+    const int n_chunks = vec ? total >> 2 : 0;
+    const bsx_f4* s4 = reinterpret_cast<const bsx_f4*>(s_obs);
+    bsx_f4* __restrict__ t4 = reinterpret_cast<bsx_f4*>(tile);
+    for (int ch = threadIdx.x; ch < n_chunks; ch += BSX_BLOCK) t4[ch] = s4[ch];
+    for (int f = (n_chunks << 2) + (int)threadIdx.x; f < total; f += BSX_BLOCK) tile[f] = s_obs[f];
+    if (t + 1 < n_steps) __syncthreads();                              // tile is rewritten next step
   }
   __syncthreads();
   bsx_flush_counts(a.ctl, s_cnt);
-
-  // stream the tile: [lanes_here x numel] floats, contiguous in HBM, 16-byte aligned start
-  float* __restrict__ tile = a.out.observation + lane0 * (int64_t)numel;
-  const int total = lanes_here * numel;
-  const int n_chunks = total >> 2;
-  const bsx_f4* s4 = reinterpret_cast<const bsx_f4*>(s_obs);
-  bsx_f4* __restrict__ t4 = reinterpret_cast<bsx_f4*>(tile);
-  for (int ch = threadIdx.x; ch < n_chunks; ch += BSX_BLOCK) t4[ch] = s4[ch];
-  const int f = (n_chunks << 2) + (int)threadIdx.x;
-  if (f < total) tile[f] = s_obs[f];
 }
 
 template <class Env>
-static int launch_small_obs(const typename Env::args& a, int numel, void* hip_stream) {
+static int launch_small_obs(const typename Env::args& a, int numel, int n_steps, void* hip_stream) {
   hipStream_t st = (hipStream_t)hip_stream;
+  if (n_steps < 1) return BSX_EINVAL;
   // Full 256-lane tiles while the LDS tile stays <= 32 KiB (8 resident blocks/CU); 64-lane tiles
   // for the wide umbrella/memory rows.
   if (numel <= 32) {
     const int64_t blocks = (a.ctl.n_lanes + 255) / 256;
     if (blocks > 0x7FFFFFFF) return BSX_EINVAL;
-    small_obs_kernel<Env, 256><<<dim3((unsigned)blocks), dim3(BSX_BLOCK), (size_t)256 * numel * 4, st>>>(a);
+    const size_t lds = (size_t)256 * numel * 4;
+    const dim3 g((unsigned)blocks), b(BSX_BLOCK);
+    const bool logging = a.ctl.log.steps != nullptr, noise = a.ctl.wrap_kind == BSX_WRAP_NOISE;
+    if (n_steps == 1) small_obs_kernel<Env, 256, false, -1, -1><<<g, b, lds, st>>>(a, 1);
+    else if (logging && noise) small_obs_kernel<Env, 256, true, 1, 1><<<g, b, lds, st>>>(a, n_steps);
+    else if (logging) small_obs_kernel<Env, 256, true, 1, 0><<<g, b, lds, st>>>(a, n_steps);
+    else if (noise) small_obs_kernel<Env, 256, true, 0, 1><<<g, b, lds, st>>>(a, n_steps);
+    else small_obs_kernel<Env, 256, true, 0, 0><<<g, b, lds, st>>>(a, n_steps);
   } else {
     const int64_t blocks = (a.ctl.n_lanes + 63) / 64;
     if (blocks > 0x7FFFFFFF) return BSX_EINVAL;
-    small_obs_kernel<Env, 64><<<dim3((unsigned)blocks), dim3(BSX_BLOCK), (size_t)64 * numel * 4, st>>>(a);
+    const size_t lds = (size_t)64 * numel * 4;
+    const dim3 g((unsigned)blocks), b(BSX_BLOCK);
+    const bool logging = a.ctl.log.steps != nullptr, noise = a.ctl.wrap_kind == BSX_WRAP_NOISE;
+    if (n_steps == 1) small_obs_kernel<Env, 64, false, -1, -1><<<g, b, lds, st>>>(a, 1);
+    else if (logging && noise) small_obs_kernel<Env, 64, true, 1, 1><<<g, b, lds, st>>>(a, n_steps);
+    else if (logging) small_obs_kernel<Env, 64, true, 1, 0><<<g, b, lds, st>>>(a, n_steps);
+    else if (noise) small_obs_kernel<Env, 64, true, 0, 1><<<g, b, lds, st>>>(a, n_steps);
+    else small_obs_kernel<Env, 64, true, 0, 0><<<g, b, lds, st>>>(a, n_steps);
   }
   return bsx_launch_status();
 }
@@ -76,11 +104,11 @@ struct bandit_env {
     bsx_ctl ctl; const int32_t* action; int32_t* state; bsx_timestep_t out; double* info;
     int32_t obs_numel; int32_t num_actions; double rewards[BSX_BANDIT_MAX_ACTIONS];
   };
-  __device__ static int step(const args& a, int64_t i, uint64_t, uint64_t, float* o, double& reward) {
+  __device__ static int step(const args& a, int64_t i, int64_t oi, uint64_t, uint64_t, float* o, double& reward) {
     BSX_NO_CONTRACT
     o[0] = 1.0f;                                                // bandit.py:54 (ones)
     if (a.ctl.force_reset || a.state[i]) { a.state[i] = 0; return BSX_FIRST; }
-    int act = a.action[i];
+    int act = a.action[oi];
     act = act < 0 ? 0 : (act >= a.num_actions ? a.num_actions - 1 : act);   // never read OOB
     reward = a.rewards[act];                                    // :61
     a.info[i] += 1.0 - reward;                                  // :62
@@ -101,7 +129,7 @@ extern "C" int bsx_bandit_step(const bsx_bandit_t* cfg, const bsx_call_t* call, 
   a.ctl = bsx_make_ctl(call); a.action = action; a.state = state; a.out = out; a.info = info;
   a.obs_numel = 1; a.num_actions = cfg->num_actions;
   for (int k = 0; k < BSX_BANDIT_MAX_ACTIONS; ++k) a.rewards[k] = cfg->rewards[k];
-  return launch_small_obs<bandit_env>(a, 1, call->hip_stream);
+  return launch_small_obs<bandit_env>(a, 1, bsx_n_steps(call), call->hip_stream);
 }
 
 // ------------------------------------------------------------------------------ memory_chain
@@ -118,7 +146,7 @@ struct memory_chain_env {
     for (int b = 0; b < a.nb; ++b)                              // :69-70
       o[2 + b] = (t == 0) ? (float)(2 * (int)((ctx >> b) & 1ull) - 1) : 0.0f;
   }
-  __device__ static int step(const args& a, int64_t i, uint64_t lane, uint64_t step, float* o, double& reward) {
+  __device__ static int step(const args& a, int64_t i, int64_t oi, uint64_t lane, uint64_t step, float* o, double& reward) {
     int32_t st = a.state[i];
     int t = st & 0xFFFFF, query = (st >> 20) & 0xFF;
     uint64_t ctx = a.context[i];
@@ -138,7 +166,7 @@ struct memory_chain_env {
     observe(a, o, t, query, ctx);                               // :74 — before the increment
     t += 1;                                                     // :75
     if (t - 1 < a.L) { a.state[i] = t | (query << 20); return BSX_MID; }   // :77-79
-    if (a.action[i] == (int)((ctx >> query) & 1ull)) { reward = 1.0; a.info[i] += 1.0; }   // :83-85
+    if (a.action[oi] == (int)((ctx >> query) & 1ull)) { reward = 1.0; a.info[i] += 1.0; }   // :83-85
     else { reward = -1.0; a.info[a.ctl.n_lanes + i] += 2.0; }   // :86-88
     a.state[i] = t | (query << 20) | MC_RESET_BIT;
     return BSX_LAST;
@@ -158,7 +186,7 @@ extern "C" int bsx_memory_chain_step(const bsx_memory_chain_t* cfg, const bsx_ca
   memory_chain_env::args a;
   a.ctl = bsx_make_ctl(call); a.action = action; a.state = state; a.context = context; a.out = out;
   a.info = info; a.obs_numel = cfg->num_bits + 2; a.L = cfg->memory_length; a.nb = cfg->num_bits;
-  return launch_small_obs<memory_chain_env>(a, a.obs_numel, call->hip_stream);
+  return launch_small_obs<memory_chain_env>(a, a.obs_numel, bsx_n_steps(call), call->hip_stream);
 }
 
 // ------------------------------------------------------------------------------ umbrella_chain
@@ -179,7 +207,7 @@ struct umbrella_chain_env {
       o[3 + b] = (float)((w >> (b & 31)) & 1u);
     }
   }
-  __device__ static int step(const args& a, int64_t i, uint64_t lane, uint64_t step, float* o, double& reward) {
+  __device__ static int step(const args& a, int64_t i, int64_t oi, uint64_t lane, uint64_t step, float* o, double& reward) {
     BSX_NO_CONTRACT
     int32_t st = a.state[i];
     int t = st & 0xFFFFF, need = (st >> 20) & 1, has = (st >> 21) & 1;
@@ -194,7 +222,7 @@ struct umbrella_chain_env {
       return BSX_FIRST;
     }
     t += 1;                                                     // :69
-    if (t == 1) has = (a.action[i] == 1);                       // :71-72 (action_spec: {0,1})
+    if (t == 1) has = (a.action[oi] == 1);                       // :71-72 (action_spec: {0,1})
     int type;
     if (t == a.L) {                                             // :74-81
       if (has == need) reward = 1.0;
@@ -224,7 +252,7 @@ extern "C" int bsx_umbrella_chain_step(const bsx_umbrella_chain_t* cfg, const bs
   umbrella_chain_env::args a;
   a.ctl = bsx_make_ctl(call); a.action = action; a.state = state; a.out = out; a.info = info;
   a.obs_numel = 3 + cfg->n_distractor; a.L = cfg->chain_length; a.nd = cfg->n_distractor;
-  return launch_small_obs<umbrella_chain_env>(a, a.obs_numel, call->hip_stream);
+  return launch_small_obs<umbrella_chain_env>(a, a.obs_numel, bsx_n_steps(call), call->hip_stream);
 }
 
 // ------------------------------------------------------------------------------ discounting_chain
@@ -234,7 +262,7 @@ struct discounting_chain_env {
     bsx_ctl ctl; const int32_t* action; int32_t* state; bsx_timestep_t out;
     int32_t obs_numel; int32_t bonus;
   };
-  __device__ static int step(const args& a, int64_t i, uint64_t, uint64_t, float* o, double& reward) {
+  __device__ static int step(const args& a, int64_t i, int64_t oi, uint64_t, uint64_t, float* o, double& reward) {
     BSX_NO_CONTRACT
     int32_t st = a.state[i];
     int t = st & 0xFF, ctx = ((st >> 8) & 0xF) - 1;
@@ -245,7 +273,7 @@ struct discounting_chain_env {
       return BSX_FIRST;
     }
     if (t == 0) {                                               // :76-77
-      ctx = a.action[i];
+      ctx = a.action[oi];
       ctx = ctx < 0 ? 0 : (ctx > 4 ? 4 : ctx);                  // action_spec: 5 values; never OOB
     }
     t += 1;
@@ -270,7 +298,7 @@ extern "C" int bsx_discounting_chain_step(const bsx_discounting_chain_t* cfg, co
   discounting_chain_env::args a;
   a.ctl = bsx_make_ctl(call); a.action = action; a.state = state; a.out = out;
   a.obs_numel = 2; a.bonus = cfg->bonus_chain;
-  return launch_small_obs<discounting_chain_env>(a, 2, call->hip_stream);
+  return launch_small_obs<discounting_chain_env>(a, 2, bsx_n_steps(call), call->hip_stream);
 }
 
 // ------------------------------------------------------------------------------ cartpole / swingup
@@ -280,7 +308,7 @@ struct cartpole_env {
     bsx_ctl ctl; const int32_t* action; float* state; int32_t* steps; bsx_timestep_t out;
     double* info; int32_t obs_numel; bsx_cartpole_t cfg;
   };
-  __device__ static int step(const args& a, int64_t i, uint64_t lane, uint64_t step, float* o, double& reward) {
+  __device__ static int step(const args& a, int64_t i, int64_t oi, uint64_t lane, uint64_t step, float* o, double& reward) {
     BSX_NO_CONTRACT
     const int64_t B = a.ctl.n_lanes;
     const bsx_cartpole_t& g = a.cfg;
@@ -301,7 +329,7 @@ struct cartpole_env {
       type = BSX_FIRST;
     } else {
       x = a.state[i]; xd = a.state[B + i]; th = a.state[2 * B + i]; thd = a.state[3 * B + i];
-      const int act = a.action[i];
+      const int act = a.action[oi];
       // step_cartpole, cartpole.py:37-65, in f32
       const float force = (float)(act - 1) * g.force_mag;
       const float co = cosf(th), si = sinf(th);
@@ -371,7 +399,7 @@ extern "C" int bsx_cartpole_step(const bsx_cartpole_t* cfg, const bsx_call_t* ca
   cartpole_env::args a;
   a.ctl = bsx_make_ctl(call); a.action = action; a.state = state; a.steps = steps; a.out = out;
   a.info = info; a.obs_numel = cfg->swingup ? 8 : 6; a.cfg = *cfg;
-  return launch_small_obs<cartpole_env>(a, a.obs_numel, call->hip_stream);
+  return launch_small_obs<cartpole_env>(a, a.obs_numel, bsx_n_steps(call), call->hip_stream);
 }
 
 // ------------------------------------------------------------------------------ mountain_car
@@ -380,7 +408,7 @@ struct mountain_car_env {
     bsx_ctl ctl; const int32_t* action; float* state; int32_t* steps; bsx_timestep_t out;
     double* info; int32_t obs_numel; int32_t max_steps;
   };
-  __device__ static int step(const args& a, int64_t i, uint64_t lane, uint64_t step, float* o, double& reward) {
+  __device__ static int step(const args& a, int64_t i, int64_t oi, uint64_t lane, uint64_t step, float* o, double& reward) {
     BSX_NO_CONTRACT
     const int64_t B = a.ctl.n_lanes;
     const int32_t sk = a.steps[i];
@@ -399,7 +427,7 @@ struct mountain_car_env {
       t += 1;                                                   // :74
       reward = -1.0;
       a.info[i] += reward;                                      // :76
-      vel += (float)(a.action[i] - 1) * 0.001f + cosf(3.0f * pos) * -0.0025f;   // :79-80
+      vel += (float)(a.action[oi] - 1) * 0.001f + cosf(3.0f * pos) * -0.0025f;   // :79-80
       vel = fminf(fmaxf(vel, -0.07f), 0.07f);                   // :81
       pos += vel;                                               // :82
       pos = fminf(fmaxf(pos, -1.2f), 0.6f);                     // :83
@@ -427,5 +455,5 @@ extern "C" int bsx_mountain_car_step(const bsx_mountain_car_t* cfg, const bsx_ca
   mountain_car_env::args a;
   a.ctl = bsx_make_ctl(call); a.action = action; a.state = state; a.steps = steps; a.out = out;
   a.info = info; a.obs_numel = 3; a.max_steps = cfg->max_steps;
-  return launch_small_obs<mountain_car_env>(a, 3, call->hip_stream);
+  return launch_small_obs<mountain_car_env>(a, 3, bsx_n_steps(call), call->hip_stream);
 }

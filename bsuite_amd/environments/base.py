@@ -263,6 +263,59 @@ class Environment(dm_env.EnvironmentBase):
     self._ensure_allocated()
     return self._wrap_output(self._call(self._coerce_actions(action).data_ptr(), force_reset=False))
 
+  def rollout(self, actions) -> dm_env.TimeStep:
+    """T consecutive step() calls in one entry-point call (batched view only).
+
+    actions: int32 device tensor [T, B].  Returns a TimeStep whose fields carry a leading T
+    dimension (step_type/reward/discount [T,B], observation [T,B,*obs_shape]) — exactly what T
+    step() calls would have returned, in order.  The small-observation families run the T steps
+    inside ONE kernel launch (state stays in L2, HBM sees only actions in / TimeSteps out); deep_sea,
+    catch and mnist issue their kernel pair T times.  Output buffers are cached per T and
+    overwritten by the next rollout of the same length."""
+    if self._scalar:
+      raise TypeError('rollout() needs the batched view (batch=B)')
+    self._ensure_allocated()
+    if not torch.is_tensor(actions) or actions.dim() != 2 or actions.shape[1] != self._batch:
+      raise ValueError(f'expected actions of shape (T, {self._batch})')
+    if actions.device != self._device or actions.dtype != torch.int32:
+      actions = actions.to(device=self._device, dtype=torch.int32)
+    actions = actions.contiguous()
+    T = int(actions.shape[0])
+    if T < 1:
+      raise ValueError('rollout needs at least one step')
+    cache = self.__dict__.setdefault('_rollout_out', {})
+    if T not in cache:
+      B, dev = self._batch, self._device
+      o = dict(reward=torch.empty((T, B), dtype=torch.float32, device=dev),
+               discount=torch.empty((T, B), dtype=torch.float32, device=dev),
+               step_type=torch.empty((T, B), dtype=torch.int8, device=dev),
+               observation=torch.empty((T, B) + self._obs_shape, dtype=torch.float32, device=dev))
+      cache[T] = (o, _native.TimeStepPtrs(o['reward'].data_ptr(), o['discount'].data_ptr(),
+                                          o['step_type'].data_ptr(), o['observation'].data_ptr()))
+    out, ptrs = cache[T]
+    call = self._call_desc
+    call.force_reset = 0
+    call.n_steps = T
+    kind, param, wseed = self._wrap
+    call.wrap.kind, call.wrap.param, call.wrap.seed = kind, param, wseed
+    hip_stream = torch.cuda.current_stream(self._device).cuda_stream
+    call.hip_stream = hip_stream
+    try:
+      if self._device_step_counter:
+        rc = self._launch(call, actions.data_ptr(), ptrs)
+        if rc == 0 and self._shared_step_counter is None:
+          rc = _native.lib.bsx_counter_add(self._step_base.data_ptr(), T, hip_stream)
+      else:
+        call.stream.step_index = self._step_index
+        rc = self._launch(call, actions.data_ptr(), ptrs)
+    finally:
+      call.n_steps = 0
+    if rc != 0:
+      _native.check(rc, f'{type(self).__name__} rollout')
+    self._step_index += T
+    return dm_env.TimeStep(step_type=out['step_type'], reward=out['reward'], discount=out['discount'],
+                           observation=out['observation'])
+
   def _step(self, action):
     raise NotImplementedError('The batched engine fuses _step/_reset into one kernel; call step().')
 

@@ -38,6 +38,9 @@ class _RewardWrapper(dm_env.EnvironmentBase):
   def step(self, action):
     return self._env.step(action)
 
+  def rollout(self, actions):
+    return self._env.rollout(actions)
+
   def observation_spec(self):
     return self._env.observation_spec()
 

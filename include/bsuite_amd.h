@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define BSX_ABI_VERSION 2
+#define BSX_ABI_VERSION 3
 
 #define BSX_FIRST 0
 #define BSX_MID 1
@@ -103,7 +103,12 @@ typedef struct {
 typedef struct {
   int64_t n_lanes;          /* B of this shard                                                   */
   int32_t force_reset;      /* 1: this call is env.reset() (base.py:54-57) for every lane        */
-  int32_t _pad;
+  int32_t n_steps;          /* 0 or 1: one step() call.  T > 1: a rollout of T consecutive step()
+                               calls in ONE entry-point call: `action` is [T,B], every bsx_timestep_t
+                               array gains a leading T dimension (observation [T,B,obs_numel]), call
+                               index of step t is step_index + t.  The small-observation families
+                               fuse the T steps into one kernel; deep_sea / catch / mnist launch
+                               their kernel pair T times.  Not combinable with force_reset.      */
   bsx_stream_t stream;
   bsx_reward_wrap_t wrap;
   uint64_t* counters;       /* device, nullable: BSX_COUNTER_SHARDS x BSX_COUNTER_STRIDE uint64.

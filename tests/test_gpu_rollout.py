@@ -1,0 +1,60 @@
+"""GPU: rollout(actions[T,B]) == T consecutive step() calls, bit for bit, for every family —
+including the fused T-step kernels of the small-observation families, odd observation widths
+(unaligned [t] slices), wrappers and the Logging bookkeeping."""
+import numpy as np
+import pytest
+import torch
+
+from bsuite_amd.utils import wrappers
+from tests import engine_util as eu
+from tests import golden_util as gu
+
+pytestmark = pytest.mark.gpu
+
+CASES = [
+    ('bandit', dict(mapping_seed=2), None, 11),
+    ('bandit', dict(mapping_seed=2), ('noise', 0.5), 11),
+    ('memory_chain', dict(memory_length=3, num_bits=3), None, 2),      # numel 5: unaligned slices
+    ('memory_chain', dict(memory_length=2, num_bits=40), None, 2),     # 64-lane tiles
+    ('umbrella_chain', dict(chain_length=4, n_distractor=20), ('scale', 3.0), 2),
+    ('discounting_chain', dict(mapping_seed=1), None, 5),
+    ('cartpole', dict(), None, 3),
+    ('cartpole_swingup', dict(), None, 3),
+    ('mountain_car', dict(max_steps=15), None, 3),
+    ('deep_sea', dict(size=6, deterministic=False, mapping_seed=1), None, 2),
+    ('catch', dict(rows=5, columns=3), None, 3),
+    ('mnist', dict(), None, 10),
+]
+
+
+@pytest.mark.parametrize('family,kwargs,wrap,na', CASES)
+@pytest.mark.parametrize('batch', [1, 1000])
+def test_rollout_equals_steps(family, kwargs, wrap, na, batch):
+  kw = dict(kwargs)
+  if family == 'mnist':
+    kw['images'], kw['labels'] = gu.mnist_dataset()
+  T, seed = 37, 21
+  g = torch.Generator(device='cuda'); g.manual_seed(3)
+  acts = torch.randint(na, (T, batch), generator=g, device='cuda', dtype=torch.int32)
+  a = eu.make_env(family, kw, batch=batch, lane_offset=9, seed=seed, wrap=wrap)
+  b = eu.make_env(family, kw, batch=batch, lane_offset=9, seed=seed, wrap=wrap)
+  la = wrappers.Logging(a, None)
+  lb = wrappers.Logging(b, None)
+  warm = acts[:5]
+  for t in range(5):                          # some ordinary steps first (state carried into the rollout)
+    la.step(warm[t]); lb.step(warm[t])
+  ro = la.rollout(acts)
+  for t in range(T):
+    ts = lb.step(acts[t])
+    for x, y in zip((ro.step_type[t], ro.reward[t], ro.discount[t], ro.observation[t]),
+                    (ts.step_type, ts.reward, ts.discount, ts.observation)):
+      np.testing.assert_array_equal(x.cpu().numpy(), y.cpu().numpy(), err_msg=f'{family} t={t}')
+  after_a, after_b = la.step(acts[0]), lb.step(acts[0])     # and the state left behind is the same
+  np.testing.assert_array_equal(after_a.observation.cpu().numpy(), after_b.observation.cpu().numpy())
+  for k, v in eu.raw(a).bsuite_info().items():
+    torch.testing.assert_close(v, eu.raw(b).bsuite_info()[k], rtol=0, atol=0)
+  for k, v in la.counters().items():
+    torch.testing.assert_close(v, lb.counters()[k], rtol=0, atol=0)
+  torch.testing.assert_close(la.num_rows(), lb.num_rows(), rtol=0, atol=0)
+  torch.testing.assert_close(eu.raw(a).episode_counters(), eu.raw(b).episode_counters(), rtol=0, atol=0)
+  assert eu.raw(a).step_index == eu.raw(b).step_index == 5 + T + 1
