@@ -177,15 +177,6 @@ def main():
 
   if args.workload == 'sweep':
     return bench_sweep(args, torch, dist, dev, rank, world)
-  bsuite_id, family, okw, obs_numel, state_bytes = WORKLOADS[args.workload]
-  B = args.lanes
-  env = bsuite_amd.load_from_id(bsuite_id, batch=B, device=dev, seed=42, lane_offset=rank * B,
-                                num_buffers=2, device_step_counter=bool(args.graph))
-  num_actions = env.action_spec().num_values
-  gen = torch.Generator(device=dev)
-  gen.manual_seed(1234 + rank)
-  n_act = max(32, args.graph, args.rollout)
-  actions = torch.randint(num_actions, (n_act, B), generator=gen, device=dev, dtype=torch.int32)
 
   def sync_all():
     torch.cuda.synchronize(dev)
@@ -193,46 +184,82 @@ def main():
       dist.barrier()
       torch.cuda.synchronize(dev)
 
-  if args.graph:
-    assert args.steps % args.graph == 0 and args.warmup % args.graph == 0, '--steps/--warmup must be multiples of --graph'
-    env.step(actions[0])                       # allocate outside capture
-    side = torch.cuda.Stream(device=dev)
-    side.wait_stream(torch.cuda.current_stream(dev))
-    graph = torch.cuda.CUDAGraph()
-    with torch.cuda.stream(side):
-      with torch.cuda.graph(graph, stream=side):
-        for t in range(args.graph):
-          env.step(actions[t])
-    torch.cuda.current_stream(dev).wait_stream(side)
+  def measure(workload):
+    """Times exactly args.steps step() calls of `workload` after args.warmup untimed ones."""
+    bsuite_id, family, okw, obs_numel, state_bytes = WORKLOADS[workload]
+    B = args.lanes
+    env = bsuite_amd.load_from_id(bsuite_id, batch=B, device=dev, seed=42, lane_offset=rank * B,
+                                  num_buffers=2, device_step_counter=bool(args.graph))
+    num_actions = env.action_spec().num_values
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(1234 + rank)
+    n_act = max(32, args.graph, args.rollout)
+    actions = torch.randint(num_actions, (n_act, B), generator=gen, device=dev, dtype=torch.int32)
 
-    def run(n_steps):
-      for _ in range(n_steps // args.graph):
-        graph.replay()
-  elif args.rollout:
-    assert args.steps % args.rollout == 0 and args.warmup % args.rollout == 0, '--steps/--warmup must be multiples of --rollout'
+    if args.graph:
+      assert args.steps % args.graph == 0 and args.warmup % args.graph == 0, '--steps/--warmup must be multiples of --graph'
+      env.step(actions[0])                       # allocate outside capture
+      side = torch.cuda.Stream(device=dev)
+      side.wait_stream(torch.cuda.current_stream(dev))
+      graph = torch.cuda.CUDAGraph()
+      with torch.cuda.stream(side):
+        with torch.cuda.graph(graph, stream=side):
+          for t in range(args.graph):
+            env.step(actions[t])
+      torch.cuda.current_stream(dev).wait_stream(side)
 
-    def run(n_steps):
-      for _ in range(n_steps // args.rollout):
-        env.rollout(actions[:args.rollout])
-  else:
-    def run(n_steps):
-      for t in range(n_steps):
-        env.step(actions[t % n_act])
+      def run(n_steps):
+        for _ in range(n_steps // args.graph):
+          graph.replay()
+    elif args.rollout:
+      assert args.steps % args.rollout == 0 and args.warmup % args.rollout == 0, '--steps/--warmup must be multiples of --rollout'
 
-  run(args.warmup)
-  sync_all()
-  ev0 = torch.cuda.Event(enable_timing=True)
-  ev1 = torch.cuda.Event(enable_timing=True)
-  t0 = time.perf_counter()
-  ev0.record()
-  run(args.steps)
-  ev1.record()
-  torch.cuda.synchronize(dev)
-  wall = time.perf_counter() - t0
-  sync_all()
-  kernel_ms = ev0.elapsed_time(ev1) / args.steps   # HIP events on the launch stream
+      def run(n_steps):
+        for _ in range(n_steps // args.rollout):
+          env.rollout(actions[:args.rollout])
+    else:
+      def run(n_steps):
+        for t in range(n_steps):
+          env.step(actions[t % n_act])
 
-  # Pure-store ceiling of THIS box (same 16-B cooperative store shape, no other work): context for
+    run(args.warmup)
+    sync_all()
+    ev0 = torch.cuda.Event(enable_timing=True)
+    ev1 = torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    ev0.record()
+    run(args.steps)
+    ev1.record()
+    torch.cuda.synchronize(dev)
+    wall = time.perf_counter() - t0
+    sync_all()
+    kernel_ms = ev0.elapsed_time(ev1) / args.steps   # HIP events on the launch stream
+
+    # end-of-rollout summary: the only collective on the path (RCCL all-gather over xGMI)
+    from bsuite_amd import distributed as bdist
+    vec, names = bdist.local_summary(env)
+    summary = bdist.reduce_summary(bdist.all_gather_summary(vec), names)
+    if world > 1:
+      t_wall = torch.tensor([wall, kernel_ms], dtype=torch.float64,
+                            device=dev if dist.get_backend() == 'nccl' else 'cpu')
+      dist.all_reduce(t_wall, op=dist.ReduceOp.MAX)
+      wall, kernel_ms = float(t_wall[0].item()), float(t_wall[1].item())
+    bytes_per_step = algorithmic_bytes_per_step(obs_numel, state_bytes)
+    achieved = bytes_per_step * B / (kernel_ms * 1e-3) / 1e9
+    traffic, traffic_src = pmc_traffic(workload, B)
+    del env, actions
+    torch.cuda.empty_cache()
+    return dict(bsuite_id=bsuite_id, family=family, okw=okw, num_actions=num_actions, wall=wall,
+                kernel_ms=kernel_ms, value=B * world * args.steps / wall, bytes_per_step=bytes_per_step,
+                achieved=achieved, traffic=traffic, traffic_src=traffic_src,
+                episodes_finished=summary['episodes_finished'])
+
+  m = measure(args.workload)
+  also = None
+  if args.workload == 'deep_sea' and not (args.graph or args.rollout):
+    also = measure('catch')        # the other half of BASELINE.json's metric, same K/W, same box
+
+  # Pure-store ceiling of THIS box (one 16-B store per thread over 2 GiB, no other work): context for
   # the roofline fraction of the store-bound families.  Not part of the timed region.
   from bsuite_amd import _native
   scratch = torch.empty(1 << 31, dtype=torch.uint8, device=dev)   # 2 GiB: far beyond L2 + Infinity Cache
@@ -249,43 +276,38 @@ def main():
   torch.cuda.synchronize(dev)
   store_ceiling_gbps = nbytes * 10 / (c0.elapsed_time(c1) * 1e-3) / 1e9
 
-  # end-of-rollout summary: the only collective on the path (RCCL all-gather over xGMI)
-  from bsuite_amd import distributed as bdist
-  vec, names = bdist.local_summary(env)
-  gathered = bdist.all_gather_summary(vec)
-  summary = bdist.reduce_summary(gathered, names)
-  if world > 1:
-    t_wall = torch.tensor([wall, kernel_ms], dtype=torch.float64,
-                          device=dev if dist.get_backend() == 'nccl' else 'cpu')
-    dist.all_reduce(t_wall, op=dist.ReduceOp.MAX)
-    wall, kernel_ms = float(t_wall[0].item()), float(t_wall[1].item())
+  def roofline(r):
+    return {'bound': 'hbm', 'achieved': r['achieved'], 'peak': HBM_PEAK_GBPS, 'unit': 'GB/s',
+            'frac': r['achieved'] / HBM_PEAK_GBPS, 'traffic': r['traffic'],
+            'traffic_source': r['traffic_src'],
+            'algorithmic_bytes_per_launch': r['bytes_per_step'] * args.lanes,
+            'kernel_ms': r['kernel_ms'], 'box_store_ceiling_GBps': store_ceiling_gbps,
+            'frac_of_box_store_ceiling': r['achieved'] / store_ceiling_gbps}
 
   if rank == 0:
-    total_steps = B * world * args.steps
-    bytes_per_step = algorithmic_bytes_per_step(obs_numel, state_bytes)
-    achieved = bytes_per_step * B / (kernel_ms * 1e-3) / 1e9
-    traffic, traffic_src = pmc_traffic(args.workload, B)
+    B = args.lanes
     line = {
-        'metric': 'env-steps/sec', 'value': total_steps / wall, 'unit': 'env-steps/s',
+        'metric': 'env-steps/sec', 'value': m['value'], 'unit': 'env-steps/s',
         'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
-        'ms_per_step': wall / args.steps * 1e3, 'higher_is_better': True, 'scaling': 'weak',
-        'vs_baseline': None, 'dtype': 'f32' if family in ('cartpole', 'mountain_car') else 'int32',
+        'ms_per_step': m['wall'] / args.steps * 1e3, 'higher_is_better': True, 'scaling': 'weak',
+        'vs_baseline': None, 'dtype': 'f32' if m['family'] in ('cartpole', 'mountain_car') else 'int32',
         'data': 'synthetic',
-        'config': {'workload': f'{bsuite_id} ({family} {okw}) random-action rollout, dense TimeStep',
+        'config': {'workload': f"{m['bsuite_id']} ({m['family']} {m['okw']}) random-action rollout, dense TimeStep",
                    'lanes_per_gpu': B, 'global_lanes': B * world, 'sharding': f'lanes x{world}',
-                   'bytes_per_env_step': bytes_per_step},
-        'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBPS, 'unit': 'GB/s',
-                     'frac': achieved / HBM_PEAK_GBPS, 'traffic': traffic,
-                     'traffic_source': traffic_src, 'algorithmic_bytes_per_launch': bytes_per_step * B,
-                     'kernel_ms': kernel_ms,
-                     'box_store_ceiling_GBps': store_ceiling_gbps,
-                     'frac_of_box_store_ceiling': achieved / store_ceiling_gbps},
+                   'bytes_per_env_step': m['bytes_per_step']},
+        'roofline': roofline(m),
         'launch': (f'hipGraph x{args.graph}' if args.graph else
                    f'rollout x{args.rollout} per call' if args.rollout else 'eager'),
-        'episodes_finished': summary['episodes_finished'],
+        'episodes_finished': m['episodes_finished'],
     }
+    if also is not None:
+      line['also'] = {also['bsuite_id']: {
+          'value': also['value'], 'unit': 'env-steps/s', 'ms_per_step': also['wall'] / args.steps * 1e3,
+          'workload': f"{also['bsuite_id']} ({also['family']} 10x5) random-action rollout, dense TimeStep, "
+                      f'{B} lanes per GPU', 'bytes_per_env_step': also['bytes_per_step'],
+          'roofline': roofline(also)}}
     if world == 1 and not args.no_cpu_baseline:
-      line['cpu_baseline'] = cpu_baseline(family, okw, num_actions)
+      line['cpu_baseline'] = cpu_baseline(m['family'], m['okw'], m['num_actions'])
     print(json.dumps(line), flush=True)
   if world > 1:
     dist.destroy_process_group()
