@@ -42,7 +42,8 @@ def _load():
 
 class Stream(ctypes.Structure):
   _fields_ = [('seed', ctypes.c_uint64), ('lane_offset', ctypes.c_uint64),
-              ('step_index', ctypes.c_uint64), ('step_base', ctypes.c_void_p)]
+              ('step_index', ctypes.c_uint64), ('step_base', ctypes.c_void_p),
+              ('mt_state', ctypes.c_void_p), ('mt_pos', ctypes.c_void_p)]
 
 
 class RewardWrap(ctypes.Structure):
@@ -162,7 +163,7 @@ for _name, (_args, _res) in _SIGS.items():
   _fn.restype = _res
 if MISSING:
   raise NativeLibraryError(f'{SO_PATH} does not export {MISSING}; rebuild with `python -m bsuite_amd.build --force`')
-ABI_VERSION = 3
+ABI_VERSION = 4
 if lib.bsx_abi_version() != ABI_VERSION:
   raise NativeLibraryError('ABI version mismatch between bsuite_amd/_native.py and libbsuite_amd.so')
 

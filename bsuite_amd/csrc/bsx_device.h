@@ -29,11 +29,29 @@ struct bsx_ctl {
   uint64_t wrap_seed;
   int32_t wrap_kind;
   int32_t force_reset;
+  uint32_t* mt_state;       // MT19937-exact mode: [624, n_lanes] generator states, else nullptr
+  int32_t* mt_pos;          // [n_lanes]
   bsx_logging_t log;        // log.steps == nullptr: logging off
 };
 
 __device__ __forceinline__ uint64_t bsx_step_of(const bsx_ctl& c) {
   return c.step_index + (c.step_base ? *c.step_base : 0ull);
+}
+
+// Opens lane i's environment draw stream for this call: the counter-based stream, or — in
+// MT19937-exact mode — the lane's own RandomState carried in HBM.  bsx_draws_end writes the
+// generator position back (the state words are updated in place by the twist).
+__device__ __forceinline__ void bsx_draws_begin(bsx_draws* d, const bsx_ctl& c, int64_t i, uint64_t lane,
+                                                uint64_t step) {
+  bsx_draws_init(d, c.seed, lane, step, BSX_STREAM_ENV);
+  if (c.mt_state != nullptr) {
+    d->mt = c.mt_state + i;
+    d->mt_stride = c.n_lanes;
+    d->mt_pos = c.mt_pos[i];
+  }
+}
+__device__ __forceinline__ void bsx_draws_end(const bsx_draws* d, const bsx_ctl& c, int64_t i) {
+  if (c.mt_state != nullptr) c.mt_pos[i] = d->mt_pos;
 }
 
 // Reward epilogue of utils/wrappers.py:275-283 (RewardNoise) and :338-346 (RewardScale): non-FIRST

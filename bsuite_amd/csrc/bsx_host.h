@@ -17,6 +17,8 @@ static inline int bsx_check_call(const bsx_call_t* call, const void* action, con
   if ((reinterpret_cast<uintptr_t>(out.observation) & 15u) != 0) return BSX_EALIGN;
   if (call->wrap.kind < BSX_WRAP_NONE || call->wrap.kind > BSX_WRAP_NOISE) return BSX_EINVAL;
   if (call->n_steps < 0 || (call->n_steps > 1 && call->force_reset)) return BSX_EINVAL;
+  if ((call->stream.mt_state == nullptr) != (call->stream.mt_pos == nullptr)) return BSX_ENULL;
+  if (call->stream.mt_state != nullptr && call->wrap.kind == BSX_WRAP_NOISE) return BSX_EMODE;
   if (call->logging != nullptr) {
     const bsx_logging_t* g = call->logging;
     if (g->steps == nullptr || g->episode == nullptr || g->total_return == nullptr || g->episode_len == nullptr ||
@@ -41,6 +43,8 @@ static inline bsx_ctl bsx_make_ctl(const bsx_call_t* call) {
   c.wrap_seed = call->wrap.seed;
   c.wrap_kind = call->wrap.kind;
   c.force_reset = call->force_reset;
+  c.mt_state = call->stream.mt_state;
+  c.mt_pos = call->stream.mt_pos;
   if (call->logging != nullptr) c.log = *call->logging;
   else c.log = bsx_logging_t{};
   return c;

@@ -34,8 +34,9 @@ struct catch_fam {
     reward = 0.0;
     if (a.ctl.force_reset || (st & CATCH_RESET_BIT)) {         // catch.py:80-81 -> :68-76
       bsx_draws d;
-      bsx_draws_init(&d, a.ctl.seed, lane, step, BSX_STREAM_ENV);
+      bsx_draws_begin(&d, a.ctl, i, lane, step);
       ball_x = (int)bsx_randint(&d, (uint32_t)cols);            // :71
+      bsx_draws_end(&d, a.ctl, i);
       ball_y = 0;
       paddle_x = cols / 2;
       type = BSX_FIRST;

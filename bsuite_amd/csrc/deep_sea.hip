@@ -55,7 +55,7 @@ struct deep_sea_fam {
       const int mapped = (int)((s.map[cell >> 5] >> (cell & 31)) & 1u);
       const bool right = (act == mapped);                       // deep_sea.py:118
       bsx_draws d;
-      bsx_draws_init(&d, a.ctl.seed, lane, step, BSX_STREAM_ENV);
+      bsx_draws_begin(&d, a.ctl, i, lane, step);
       if (col == N - 1 && right) {                              // :121-123
         reward += 1.0;
         a.info[a.ctl.n_lanes + i] += 1.0;
@@ -70,6 +70,7 @@ struct deep_sea_fam {
         if (row == col) bad = 1;
         col = col - 1 < 0 ? 0 : col - 1;
       }
+      bsx_draws_end(&d, a.ctl, i);
       row += 1;                                                 // :137
       if (row == N) {                                           // :140-143
         if (bad) a.info[i] += 1.0;
@@ -100,6 +101,7 @@ extern "C" int bsx_deep_sea_step(const bsx_deep_sea_t* cfg, const bsx_call_t* ca
   int rc = bsx_check_call(call, action, out);
   if (rc != 0) return rc;
   if (cfg->size < 1 || cfg->size > BSX_DEEP_SEA_MAX_SIZE) return BSX_ERANGE;
+  if (call->stream.mt_state != nullptr && !cfg->deterministic) return BSX_EMODE;   // needs randn
   if (call->n_lanes == 0) return 0;
   if (state == nullptr || info == nullptr) return BSX_ENULL;
 

@@ -11,6 +11,7 @@ extern "C" const char* bsx_strerror(int code) {
     case BSX_ENULL: return "required pointer is NULL";
     case BSX_EALIGN: return "observation buffer is not 16-byte aligned";
     case BSX_ERANGE: return "parameter outside the supported range of this family";
+    case BSX_EMODE: return "not available in MT19937-exact mode (RewardNoise / stochastic deep_sea need randn)";
     default: return code > 0 ? hipGetErrorString((hipError_t)code) : "unknown bsx error";
   }
 }

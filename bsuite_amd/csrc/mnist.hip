@@ -40,8 +40,9 @@ __global__ void __launch_bounds__(BSX_BLOCK) mnist_advance_kernel(const mnist_ar
     int32_t nst;
     if (a.ctl.force_reset || (st & MN_RESET_BIT)) {             // mnist.py:61-67
       bsx_draws d;
-      bsx_draws_init(&d, a.ctl.seed, lane, step, BSX_STREAM_ENV);
+      bsx_draws_begin(&d, a.ctl, i, lane, step);
       const uint32_t idx = bsx_randint(&d, (uint32_t)a.num_data);
+      bsx_draws_end(&d, a.ctl, i);
       nst = (int32_t)idx | ((int32_t)a.labels[idx] << 24) | MN_SHOW_BIT;
       type = BSX_FIRST;
     } else {                                                    // mnist.py:69-75

@@ -152,11 +152,12 @@ struct memory_chain_env {
     uint64_t ctx = a.context[i];
     if (a.ctl.force_reset || (st & MC_RESET_BIT)) {             // :91-97
       bsx_draws d;
-      bsx_draws_init(&d, a.ctl.seed, lane, step, BSX_STREAM_ENV);
-      uint64_t w0 = bsx_word(&d);                               // BernVec(nb)
-      uint64_t w1 = a.nb > 32 ? bsx_word(&d) : 0ull;
-      ctx = (w0 | (w1 << 32)) & (a.nb >= 64 ? ~0ull : ((1ull << a.nb) - 1ull));
+      bsx_draws_begin(&d, a.ctl, i, lane, step);
+      ctx = 0;
+      uint32_t w = 0;
+      for (int b = 0; b < a.nb; ++b) ctx |= (uint64_t)bsx_bern_vec_bit(&d, b, &w) << b;   // BernVec(nb)
       query = (int)bsx_randint(&d, (uint32_t)a.nb);
+      bsx_draws_end(&d, a.ctl, i);
       t = 0;
       a.context[i] = ctx;
       a.state[i] = t | (query << 20);
@@ -202,22 +203,20 @@ struct umbrella_chain_env {
     o[1] = (float)has;                                          // :63
     o[2] = (float)(1.0 - (double)t / (double)a.L);              // :64
     uint32_t w = 0;
-    for (int b = 0; b < a.nd; ++b) {                            // :65 BernVec(nd)
-      if ((b & 31) == 0) w = bsx_word(d);
-      o[3 + b] = (float)((w >> (b & 31)) & 1u);
-    }
+    for (int b = 0; b < a.nd; ++b) o[3 + b] = (float)bsx_bern_vec_bit(d, b, &w);   // :65 BernVec(nd)
   }
   __device__ static int step(const args& a, int64_t i, int64_t oi, uint64_t lane, uint64_t step, float* o, double& reward) {
     BSX_NO_CONTRACT
     int32_t st = a.state[i];
     int t = st & 0xFFFFF, need = (st >> 20) & 1, has = (st >> 21) & 1;
     bsx_draws d;
-    bsx_draws_init(&d, a.ctl.seed, lane, step, BSX_STREAM_ENV);
+    bsx_draws_begin(&d, a.ctl, i, lane, step);
     if (a.ctl.force_reset || (st & UC_RESET_BIT)) {             // :87-92
       t = 0;
       need = (int)bsx_bern(&d);
       has = (int)bsx_bern(&d);
       observe(a, o, t, need, has, &d);
+      bsx_draws_end(&d, a.ctl, i);
       a.state[i] = t | (need << 20) | (has << 21);
       return BSX_FIRST;
     }
@@ -234,6 +233,7 @@ struct umbrella_chain_env {
       observe(a, o, t, need, has, &d);
       type = BSX_MID;
     }
+    bsx_draws_end(&d, a.ctl, i);
     a.state[i] = t | (need << 20) | (has << 21) | (type == BSX_LAST ? UC_RESET_BIT : 0);
     return type;
   }
@@ -318,12 +318,13 @@ struct cartpole_env {
     int type;
     if (a.ctl.force_reset || (sk & CP_RESET_BIT)) {             // cartpole.py:118-128 / swingup:81-91
       bsx_draws d;
-      bsx_draws_init(&d, a.ctl.seed, lane, step, BSX_STREAM_ENV);
+      bsx_draws_begin(&d, a.ctl, i, lane, step);
       const double lo = -g.init_range, hi = g.init_range;
       x = (float)(lo + (hi - lo) * bsx_uniform(&d));
       xd = (float)(lo + (hi - lo) * bsx_uniform(&d));
       th = (float)(g.theta_offset + (lo + (hi - lo) * bsx_uniform(&d)));
       thd = (float)(lo + (hi - lo) * bsx_uniform(&d));
+      bsx_draws_end(&d, a.ctl, i);
       k = 0;
       a.info[2 * B + i] = 0.0;                                  // _episode_return = 0
       type = BSX_FIRST;
@@ -417,9 +418,10 @@ struct mountain_car_env {
     int type;
     if (a.ctl.force_reset || (sk & CP_RESET_BIT)) {             // mountain_car.py:66-71
       bsx_draws d;
-      bsx_draws_init(&d, a.ctl.seed, lane, step, BSX_STREAM_ENV);
+      bsx_draws_begin(&d, a.ctl, i, lane, step);
       t = 0;
       pos = (float)(-0.6 + (-0.4 - -0.6) * bsx_uniform(&d));
+      bsx_draws_end(&d, a.ctl, i);
       vel = 0.0f;
       type = BSX_FIRST;
     } else {

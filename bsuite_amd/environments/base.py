@@ -53,14 +53,15 @@ class Environment(dm_env.EnvironmentBase):
   _info_int_keys = ()      # keys the reference reports as Python ints
 
   def __init__(self, obs_shape, num_actions, *, seed=None, batch=None, device=None,
-               lane_offset=0, num_buffers=2, device_step_counter=False, shared_step_counter=None):
+               lane_offset=0, num_buffers=2, device_step_counter=False, shared_step_counter=None,
+               rng='philox'):
     self._scalar = batch is None
     self._batch = 1 if batch is None else int(batch)
     if self._batch < 1:
       raise ValueError('batch must be >= 1')
     self._device = torch.device('cuda:0' if device is None else device)
     self._lane_offset = int(lane_offset)
-    self._seed = _resolve_seed(seed)
+    self._seed = _resolve_seed(seed if seed is None or isinstance(seed, (int, np.integer)) else 0)
     self._obs_shape = tuple(int(d) for d in obs_shape)
     self._num_actions = int(num_actions)
     self._num_buffers = max(1, int(num_buffers))
@@ -71,6 +72,21 @@ class Environment(dm_env.EnvironmentBase):
     # shared_step_counter: an int64[1] device tensor owned by the caller (e.g. SweepBatch) who bumps
     # it once per sweep step for all its segments instead of one bump kernel per environment.
     self._shared_step_counter = shared_step_counter
+    # rng='mt19937': every lane carries the reference's own generator (np.random.RandomState(seed),
+    # MT19937 + numpy's legacy samplers) in HBM, so seeded runs reproduce the reference without any
+    # replay shim.  `seed` may be a sequence of B seeds; an int s seeds lane i with
+    # s + i.  2.5 KB of state per lane: meant for small batches.
+    if rng not in ('philox', 'mt19937'):
+      raise ValueError("rng must be 'philox' or 'mt19937'")
+    self._rng_mode = rng
+    self._mt_seeds = None
+    if rng == 'mt19937':
+      if seed is None or isinstance(seed, (int, np.integer)):
+        self._mt_seeds = [(self._seed + i) & 0xFFFFFFFF for i in range(self._batch)]
+      else:
+        self._mt_seeds = [int(x) for x in seed]
+        if len(self._mt_seeds) != self._batch:
+          raise ValueError('need one seed per lane')
     self._wrap = (_native.WRAP_NONE, 0.0, 0)
     self._step_index = 0
     self._buf = 0
@@ -113,6 +129,10 @@ class Environment(dm_env.EnvironmentBase):
     """Subclass hook: call the family's C-ABI entry point."""
     raise NotImplementedError
 
+  def _mt_constructor_draws(self, rs: np.random.RandomState):
+    """Subclass hook (rng='mt19937'): consume from `rs` exactly what the reference constructor
+    draws from `self._rng` before the first reset (most families: nothing)."""
+
   def _ensure_allocated(self):
     if self._allocated:
       return
@@ -142,11 +162,25 @@ class Environment(dm_env.EnvironmentBase):
             o['reward'].data_ptr(), o['discount'].data_ptr(), o['step_type'].data_ptr(),
             o['observation'].data_ptr()))
       self._scalar_action = torch.zeros(1, dtype=torch.int32, device=dev)
+    mt_state_ptr = mt_pos_ptr = None
+    if self._rng_mode == 'mt19937':
+      keys = np.empty((B, 624), np.uint32)
+      pos = np.empty(B, np.int32)
+      for i, s_i in enumerate(self._mt_seeds):
+        rs = np.random.RandomState(s_i)
+        self._mt_constructor_draws(rs)           # the draws the reference constructor makes
+        _, key, p, _, _ = rs.get_state()
+        keys[i], pos[i] = key, p
+      with torch.cuda.device(dev):
+        self._mt_state = torch.from_numpy(np.ascontiguousarray(keys.T).view(np.int32)).to(dev)   # [624, B]
+        self._mt_pos = torch.from_numpy(pos).to(dev)
+      mt_state_ptr, mt_pos_ptr = self._mt_state.data_ptr(), self._mt_pos.data_ptr()
     # One persistent call descriptor: only step_index / force_reset / stream change per call.
     self._call_desc = _native.Call(
         n_lanes=B, force_reset=0,
         stream=_native.Stream(self._seed, self._lane_offset, 0,
-                              self._step_base.data_ptr() if self._device_step_counter else None),
+                              self._step_base.data_ptr() if self._device_step_counter else None,
+                              mt_state_ptr, mt_pos_ptr),
         wrap=_native.RewardWrap(_native.WRAP_NONE, 0, 0.0, 0),
         counters=self._counters.data_ptr(), hip_stream=None)
     self._allocated = True
@@ -357,6 +391,8 @@ class Environment(dm_env.EnvironmentBase):
     d['__counters'] = self._counters.clone()
     d['__step_index'] = self.device_step_index()
     d['__seed'] = self._seed
+    if self._rng_mode == 'mt19937':
+      d['__mt_state'], d['__mt_pos'] = self._mt_state.clone(), self._mt_pos.clone()
     return d
 
   def load_state_dict(self, d: Dict[str, Any]):
@@ -370,3 +406,6 @@ class Environment(dm_env.EnvironmentBase):
       self._step_base.fill_(self._step_index)
     self._seed = int(d['__seed'])
     self._call_desc.stream.seed = self._seed
+    if self._rng_mode == 'mt19937':
+      self._mt_state.copy_(d['__mt_state'])
+      self._mt_pos.copy_(d['__mt_pos'])

@@ -24,6 +24,10 @@ class MemoryChain(base.Environment):
     self._cfg = _native.MemoryChainCfg(memory_length, num_bits)
     self.bsuite_num_episodes = 10_000  # Overridden by experiment load() (memory_chain.py:58).
 
+  def _mt_constructor_draws(self, rs):
+    rs.binomial(1, 0.5, self._num_bits)      # memory_chain.py:49
+    rs.randint(self._num_bits)               # memory_chain.py:50
+
   def _state_tensors(self):
     return dict(state=torch.full((self._batch,), 1 << 28, dtype=torch.int32, device=self._device),
                 context=torch.zeros(self._batch, dtype=torch.int64, device=self._device))

@@ -25,6 +25,9 @@ class UmbrellaChain(base.Environment):
     self._cfg = _native.UmbrellaChainCfg(chain_length, n_distractor)
     self.bsuite_num_episodes = NUM_EPISODES
 
+  def _mt_constructor_draws(self, rs):
+    rs.binomial(1, 0.5)                      # umbrella_chain.py:55 (need_umbrella)
+
   def _state_tensors(self):
     return dict(state=torch.full((self._batch,), 1 << 22, dtype=torch.int32, device=self._device))
 

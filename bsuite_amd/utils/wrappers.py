@@ -74,6 +74,9 @@ class RewardNoise(_RewardWrapper):
 
   def __init__(self, env: base.Environment, noise_scale: float, seed: Optional[int] = None):
     super().__init__(env)
+    if getattr(env, '_rng_mode', 'philox') == 'mt19937':
+      raise NotImplementedError("RewardNoise needs randn, which rng='mt19937' mode does not provide "
+                                '(numpy polar Box-Muller depends on libm log bit for bit)')
     self._noise_scale = noise_scale
     # The reference wrapper owns a RandomState(seed) separate from the env's (wrappers.py:267);
     # here that is stream_id 1 of the draw stream, keyed by this seed.

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define BSX_ABI_VERSION 3
+#define BSX_ABI_VERSION 4
 
 #define BSX_FIRST 0
 #define BSX_MID 1
@@ -37,6 +37,7 @@ extern "C" {
 #define BSX_ENULL (-2)      /* a required pointer is NULL                          */
 #define BSX_EALIGN (-3)     /* observation pointer not 16-byte aligned             */
 #define BSX_ERANGE (-4)     /* parameter outside the supported range of the family */
+#define BSX_EMODE (-5)      /* combination not available in MT19937-exact mode (needs randn) */
 
 /* Random stream coordinates of one call (include/bsx_stream.h).  The reference gives every env its
  * own np.random.RandomState (e.g. deep_sea.py:77, catch.py:58); here a lane's draws are a pure
@@ -48,6 +49,13 @@ typedef struct {
   uint64_t lane_offset;     /* global id of this shard's lane 0                               */
   uint64_t step_index;      /* index of this reset()/step() call (monotonic per env batch)    */
   const uint64_t* step_base; /* device pointer or NULL                                        */
+  /* MT19937-exact mode (include/bsx_stream.h "mode B"); both NULL = counter-based
+   * stream.  mt_state: device uint32 [624, B] (word k of lane i at [k*B + i]), each lane holding
+   * np.random.RandomState's key; mt_pos: device int32 [B], its `pos`.  The kernels then draw with
+   * numpy's legacy samplers from that generator and write the advanced state back.  Not available
+   * with RewardNoise or the stochastic deep_sea (both need randn).                              */
+  uint32_t* mt_state;
+  int32_t* mt_pos;
 } bsx_stream_t;
 
 /* Fused reward epilogue = bsuite/utils/wrappers.py RewardNoise (:275-283) / RewardScale (:338-346):

@@ -70,6 +70,10 @@ typedef struct {
   uint32_t next;      /* index of the next word to hand out */
   int32_t have;       /* block currently cached in `blk` (-1 none) */
   bsx_u32x4 blk;
+  /* MT19937-exact mode (see below): NULL = counter-based stream */
+  uint32_t* mt;       /* element k of this lane's 624-word state lives at mt[k * mt_stride]  */
+  int64_t mt_stride;
+  int32_t mt_pos;     /* numpy's `pos`: 0..624 */
 } bsx_draws;
 
 BSX_HD void bsx_draws_init(bsx_draws* d, uint64_t seed, uint64_t lane, uint64_t step, uint32_t stream_id) {
@@ -78,9 +82,52 @@ BSX_HD void bsx_draws_init(bsx_draws* d, uint64_t seed, uint64_t lane, uint64_t 
   d->c2 = (uint32_t)step;
   d->c3hi = (((uint32_t)(step >> 32) & 0xFFFFu) << 16) | ((stream_id & 0xFFu) << 8);
   d->next = 0; d->have = -1;
+  d->mt = 0; d->mt_stride = 0; d->mt_pos = 0;
+}
+
+/* ---- MT19937-exact mode ("mode B") ------------------------------------------------------------
+ * For seeded small batches the engine can instead carry, per lane, the very generator the
+ * reference uses — np.random.RandomState = MT19937 (624-word state + position) with numpy's LEGACY
+ * samplers — so that e.g. Catch(seed=0) here and in the reference produce the same trajectory with
+ * no replay shim.  The host builds each lane's initial state with numpy itself
+ * (RandomState(seed).get_state() after replaying the constructor's draws).  Samplers, restated
+ * from numpy's legacy distributions (verified against numpy 2.2 RandomState in the tests):
+ *   next_u32     genrand_int32 (Matsumoto-Nishimura reference algorithm, tempering included)
+ *   U()          a = next>>5, b = next>>6 ; (a*2^26 + b) / 2^53            (random_sample / rand)
+ *   uniform      lo + (hi-lo)*U()
+ *   binomial(1,.5)          one U() per draw: int(U > 0.5)  (inversion algorithm with n=1, p=.5)
+ *   binomial(1,.5,size=n)   n sequential draws
+ *   randint(n)   n==1: 0 without a draw; else mask = next_pow2(n-1)-1, reject next_u32&mask > n-1
+ *   randn        NOT available in this mode (polar Box-Muller needs libm's log bit for bit).    */
+BSX_HD void bsx_mt_twist(uint32_t* mt, int64_t st) {
+  const uint32_t UPPER = 0x80000000u, LOWER = 0x7fffffffu, MATRIX_A = 0x9908b0dfu;
+  int kk;
+  uint32_t y;
+  for (kk = 0; kk < 624 - 397; kk++) {
+    y = (mt[kk * st] & UPPER) | (mt[(kk + 1) * st] & LOWER);
+    mt[kk * st] = mt[(kk + 397) * st] ^ (y >> 1) ^ ((y & 1u) ? MATRIX_A : 0u);
+  }
+  for (; kk < 623; kk++) {
+    y = (mt[kk * st] & UPPER) | (mt[(kk + 1) * st] & LOWER);
+    mt[kk * st] = mt[(kk + (397 - 624)) * st] ^ (y >> 1) ^ ((y & 1u) ? MATRIX_A : 0u);
+  }
+  y = (mt[623 * st] & UPPER) | (mt[0] & LOWER);
+  mt[623 * st] = mt[396 * st] ^ (y >> 1) ^ ((y & 1u) ? MATRIX_A : 0u);
+}
+
+BSX_HD uint32_t bsx_mt_next(bsx_draws* d) {
+  if (d->mt_pos >= 624) { bsx_mt_twist(d->mt, d->mt_stride); d->mt_pos = 0; }
+  uint32_t y = d->mt[(int64_t)d->mt_pos * d->mt_stride];
+  d->mt_pos++;
+  y ^= (y >> 11);
+  y ^= (y << 7) & 0x9d2c5680u;
+  y ^= (y << 15) & 0xefc60000u;
+  y ^= (y >> 18);
+  return y;
 }
 
 BSX_HD uint32_t bsx_word(bsx_draws* d) {
+  if (d->mt) return bsx_mt_next(d);
   uint32_t w = d->next++;
   int32_t b = (int32_t)(w >> 2);
   if (b != d->have) {
@@ -96,8 +143,27 @@ BSX_HD uint64_t bsx_k53(bsx_draws* d) {
   return ((uint64_t)(a >> 5) << 26) | (uint64_t)(b >> 6);
 }
 BSX_HD double bsx_uniform(bsx_draws* d) { return (double)bsx_k53(d) * 0x1p-53; }
-BSX_HD uint32_t bsx_bern(bsx_draws* d) { return bsx_word(d) >> 31; }
-BSX_HD uint32_t bsx_randint(bsx_draws* d, uint32_t n) { return (uint32_t)(((uint64_t)bsx_word(d) * (uint64_t)n) >> 32); }
+BSX_HD uint32_t bsx_bern(bsx_draws* d) {
+  if (d->mt) return bsx_uniform(d) > 0.5 ? 1u : 0u;       /* legacy binomial(1, .5): one double */
+  return bsx_word(d) >> 31;
+}
+BSX_HD uint32_t bsx_randint(bsx_draws* d, uint32_t n) {
+  if (d->mt) {                                            /* legacy masked rejection on uint32 */
+    uint32_t rng = n - 1u, mask, v;
+    if (rng == 0u) return 0u;
+    mask = rng;
+    mask |= mask >> 1; mask |= mask >> 2; mask |= mask >> 4; mask |= mask >> 8; mask |= mask >> 16;
+    do { v = bsx_mt_next(d) & mask; } while (v > rng);
+    return v;
+  }
+  return (uint32_t)(((uint64_t)bsx_word(d) * (uint64_t)n) >> 32);
+}
+/* Element b of a BernVec(n) being drawn in order b = 0, 1, ...; *w carries the current word. */
+BSX_HD uint32_t bsx_bern_vec_bit(bsx_draws* d, int b, uint32_t* w) {
+  if (d->mt) return bsx_uniform(d) > 0.5 ? 1u : 0u;
+  if ((b & 31) == 0) *w = bsx_word(d);
+  return (*w >> (b & 31)) & 1u;
+}
 
 /* ---- bit-reproducible natural log for normal doubles in (0, 1] --------------------------- */
 BSX_HD double bsx_bits_to_f64(uint64_t u) { union { uint64_t u; double d; } x; x.u = u; return x.d; }

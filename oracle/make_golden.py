@@ -120,14 +120,21 @@ class _RowCollector:
 
 
 def run_case(bs, name, family, kwargs, lanes, T, seed=42, step0=0, wrap=None, policies=None,
-             reset_at=(), case_seed=0, log=None):
+             reset_at=(), case_seed=0, log=None, rng='replay'):
+  """rng='replay': the reference's RandomState is swapped for a replay of the engine's stream, keyed
+  by (seed, lane).  rng='mt19937': NOTHING is swapped — each "lane" value is the integer seed the
+  unmodified reference constructor is given (np.random.RandomState(seed) inside it)."""
   lanes = [int(x) for x in lanes]
   L = len(lanes)
   policies = list(policies or []) + ['random'] * L
   envs, rngs, collectors = [], [], []
   for lane in lanes:
-    env = _make_env(bs, family, kwargs, wrap)
-    rngs.append(replay.attach_replay(env, seed, lane))
+    if rng == 'mt19937':
+      env = _make_env(bs, family, dict(kwargs, seed=lane), wrap)
+      rngs.append([])
+    else:
+      env = _make_env(bs, family, kwargs, wrap)
+      rngs.append(replay.attach_replay(env, seed, lane))
     if log is not None:   # the UNMODIFIED reference Logging wrapper (utils/wrappers.py:34-137)
       from bsuite.utils import wrappers as ref_wrappers  # pylint: disable=import-outside-toplevel
       col = _RowCollector()
@@ -170,7 +177,7 @@ def run_case(bs, name, family, kwargs, lanes, T, seed=42, step0=0, wrap=None, po
   meta = dict(name=name, family=family, kwargs=kwargs, seed=seed, step0=step0,
               wrap=list(wrap) if wrap else None, info_keys=info_keys,
               reset_at=[int(x) for x in reset_at], num_actions=int(num_actions),
-              obs_shape=list(obs_shape), policies=policies[:L])
+              obs_shape=list(obs_shape), policies=policies[:L], rng=rng)
   out = dict(meta=np.array(json.dumps(meta)), lanes=np.array(lanes, np.uint64), actions=actions,
              step_type=step_type, reward=reward, discount=discount, obs=obs, info=info)
   if phys is not None:
@@ -276,6 +283,22 @@ def cases():
   add('logging_cartpole', 'cartpole', dict(), LANES[:4], 1500, log='by_episode')
   add('logging_umbrella_scale', 'umbrella_chain', dict(chain_length=3, n_distractor=4), LANES[:4], 200,
       wrap=('scale', 30.0), log='by_episode')
+  # MT19937-exact mode: the reference with its OWN np.random.RandomState(seed); "lanes" are seeds
+  SEEDS = [0, 1, 2, 3, 7, 42, 123456, 2**32 - 1]
+  mt = dict(rng='mt19937')
+  add('mt_catch', 'catch', dict(), SEEDS, 90, policies=['optimal', 'left'], **mt)
+  add('mt_catch_scale', 'catch', dict(rows=6, columns=9), SEEDS[:4], 60, wrap=('scale', 30.0), **mt)
+  add('mt_memory_l3_b5', 'memory_chain', dict(memory_length=3, num_bits=5), SEEDS, 70, policies=['optimal'], **mt)
+  add('mt_memory_len30', 'memory_chain', dict(memory_length=30, num_bits=1), SEEDS[:4], 100, **mt)
+  add('mt_umbrella_l4_d20', 'umbrella_chain', dict(chain_length=4, n_distractor=20), SEEDS, 70,
+      policies=['optimal'], reset_at=(9,), **mt)
+  add('mt_umbrella_l3_d200', 'umbrella_chain', dict(chain_length=3, n_distractor=200), SEEDS[:3], 40, **mt)
+  add('mt_cartpole', 'cartpole', dict(), SEEDS[:6], 400, **mt)
+  add('mt_swingup', 'cartpole_swingup', dict(), SEEDS[:3], 300, **mt)
+  add('mt_mountain_car', 'mountain_car', dict(max_steps=25), SEEDS, 90, **mt)
+  add('mt_deep_sea', 'deep_sea', dict(size=8, mapping_seed=3), SEEDS[:4], 40, policies=ds_pol, **mt)
+  add('mt_mnist', 'mnist', dict(), SEEDS, 50, policies=['optimal'], **mt)
+  add('mt_logging_catch', 'catch', dict(), SEEDS[:4], 200, log='by_episode', **mt)
   # mnist bandit (mnist.py) on the synthetic idx files staged in /tmp/mnist by main()
   add('mnist_synthetic', 'mnist', dict(), LANES, 40, policies=['optimal'], reset_at=(7,))
   add('mnist_fraction', 'mnist', dict(fraction=0.25), LANES[:4], 30, policies=['optimal'], step0=BIG_STEP)

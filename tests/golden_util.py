@@ -20,6 +20,16 @@ def mnist_dataset():
   return d['images_u8'].view(np.int8), d['labels']
 
 
+def replay_case_names():
+  """Fixtures made with the engine's draw stream replayed into the reference (not the mt_* ones)."""
+  return [n for n in case_names() if not n.startswith('mt_')]
+
+
+def mt_case_names():
+  """Fixtures made from the unmodified reference running on its own np.random.RandomState(seed)."""
+  return [n for n in case_names() if n.startswith('mt_')]
+
+
 def load_case(name):
   g = np.load(os.path.join(GOLDEN_DIR, name + '.npz'))
   meta = json.loads(str(g['meta']))

@@ -22,7 +22,7 @@ def _force_physics_state(env, fam, phys_prev, idx):
   r._state['state'].copy_(torch.from_numpy(np.ascontiguousarray(st)).to(r.device))
 
 
-@pytest.mark.parametrize('name', gu.case_names())
+@pytest.mark.parametrize('name', gu.replay_case_names())
 def test_engine_matches_reference(name):
   meta, g = gu.load_case(name)
   fam = meta['family']

@@ -8,7 +8,7 @@ from oracle import coracle
 from tests import golden_util as gu
 
 
-@pytest.mark.parametrize('name', gu.case_names())
+@pytest.mark.parametrize('name', gu.replay_case_names())
 def test_oracle_matches_reference(name):
   meta, g = gu.load_case(name)
   fam = meta['family']
