@@ -3,6 +3,6 @@ run() { python bench.py --workload $1 --steps 60 --warmup 6 --no-cpu-baseline 2>
 for w in deep_sea; do
   for cfg in "64 16" "64 8" "64 4" "128 8" "128 4" "128 2" "256 4" "256 2" "512 2" "512 1" "512 4" "1024 1" "1024 2"; do
     set -- $cfg
-    BSX_DS_SPLIT=1 BSX_CATCH_SPLIT=1 BSX_STREAM_BS=$1 BSX_STREAM_K=$2 run $w bs$1_k$2
+    BSX_STREAM_BS=$1 BSX_STREAM_K=$2 run $w bs$1_k$2
   done
 done
