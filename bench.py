@@ -87,6 +87,7 @@ def bench_sweep(args, torch, dist, dev, rank, world):
   datasets.write_idx_files(tmp, d['images_u8'], d['labels'])      # synthetic stand-in (no network)
   mn = dict(data_dir=tmp)
   batch = sb.SweepBatch(None, args.lanes, device=dev, seed=42, rank=rank, world_size=world,
+                        num_streams=int(os.environ.get('BSX_SWEEP_STREAMS', '32')),
                         env_kwargs=dict(mnist=mn, mnist_noise=mn, mnist_scale=mn))
   acts = batch.random_actions(seed=1 + rank)
   batch.capture(acts)

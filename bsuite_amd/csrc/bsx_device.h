@@ -168,80 +168,34 @@ __device__ __forceinline__ void bsx_flush_counts(const bsx_ctl& c, const unsigne
   if (s_cnt[1]) atomicAdd(&shard[1], (unsigned long long)s_cnt[1]);
 }
 
-// Advance kernel of the two-kernel families (deep_sea, catch): every thread advances FOUR
-// consecutive lanes with 16-byte column loads/stores (action, packed state, reward, discount) and
-// one 4-byte step_type store — a quarter of the memory instructions and workgroups of a
-// lane-per-thread kernel, which matters because at B=2^20 this kernel is latency/launch-bound
-// (~8-12 us for 22 MB).  The vector path requires 16-byte aligned columns (checked on the host,
-// `vec_ok`); otherwise every thread takes the scalar branch.
+// Advance kernel of the two-kernel families (deep_sea, catch): one lane per thread, coalesced
+// column loads/stores.  At B=2^20 it moves only 22 MB and sits at the ~8 us launch/latency floor of
+// any 2^20-lane kernel; a 4-lanes-per-thread variant with 16-byte column accesses measured the
+// same for catch and slower for deep_sea, whose per-lane Philox draw then runs 4x serially
+// (profiles/r01/ab_advance_vec4.log).
 //
 // Fam provides: struct args { bsx_ctl ctl; const int32_t* action; int32_t* state; bsx_timestep_t out;
 //                             double* info; ... };  struct shared;  static stage(args, shared&);
 //   static int advance(args, shared, i, lane, step, st, act, nst&, reward&)
-typedef int bsx_i4 __attribute__((ext_vector_type(4)));
-
 template <class Fam>
-__global__ void __launch_bounds__(BSX_BLOCK) bsx_advance4_kernel(const typename Fam::args a, const int vec_ok) {
+__global__ void __launch_bounds__(BSX_BLOCK) bsx_advance_kernel(const typename Fam::args a) {
   __shared__ typename Fam::shared s_fam;
   __shared__ unsigned int s_cnt[2];
   if (threadIdx.x < 2) s_cnt[threadIdx.x] = 0;
   Fam::stage(a, s_fam);
   __syncthreads();
-  const int64_t i0 = ((int64_t)blockIdx.x * BSX_BLOCK + threadIdx.x) * 4;
-  const uint64_t step = bsx_step_of(a.ctl);
-  int types[4] = {-1, -1, -1, -1};
-  if (vec_ok && i0 + 3 < a.ctl.n_lanes) {
-    const bsx_i4 st4 = *reinterpret_cast<const bsx_i4*>(a.state + i0);
-    bsx_i4 act4 = {0, 0, 0, 0};
-    if (!a.ctl.force_reset) act4 = *reinterpret_cast<const bsx_i4*>(a.action + i0);
-    bsx_i4 nst4;
-    bsx_f4 r4, d4;
-    uint32_t packed_types = 0;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int64_t i = i0 + j;
-      const uint64_t lane = a.ctl.lane_offset + (uint64_t)i;
-      int32_t nst; double reward;
-      const int t = Fam::advance(a, s_fam, i, lane, step, st4[j], act4[j], nst, reward);
-      float r, d;
-      bsx_emit_values(a.ctl, i, lane, step, t, reward, r, d);
-      nst4[j] = nst; r4[j] = r; d4[j] = d; types[j] = t;
-      packed_types |= (uint32_t)(t & 0xFF) << (8 * j);
-    }
-    *reinterpret_cast<bsx_i4*>(a.state + i0) = nst4;
-    *reinterpret_cast<bsx_f4*>(a.out.reward + i0) = r4;
-    *reinterpret_cast<bsx_f4*>(a.out.discount + i0) = d4;
-    *reinterpret_cast<uint32_t*>(a.out.step_type + i0) = packed_types;
-  } else if (vec_ok) {
-    // the last (< 4 lane) ragged group of the vector mapping
-    for (int j = 0; j < 4; ++j) {
-      const int64_t i = i0 + j;
-      if (i >= a.ctl.n_lanes) break;
-      const uint64_t lane = a.ctl.lane_offset + (uint64_t)i;
-      int32_t nst; double reward;
-      const int act = a.ctl.force_reset ? 0 : a.action[i];
-      const int t = Fam::advance(a, s_fam, i, lane, step, a.state[i], act, nst, reward);
-      a.state[i] = nst;
-      bsx_emit(a.ctl, a.out, i, lane, step, t, reward);
-      types[j] = t;
-    }
-  } else {
-    // unaligned columns: same four lanes per thread, but lane = block_base + j*256 + tid so that
-    // every scalar access is still coalesced across the wavefront
-    for (int j = 0; j < 4; ++j) {
-      const int64_t i = (int64_t)blockIdx.x * (4 * BSX_BLOCK) + j * BSX_BLOCK + threadIdx.x;
-      if (i >= a.ctl.n_lanes) break;
-      const uint64_t lane = a.ctl.lane_offset + (uint64_t)i;
-      int32_t nst; double reward;
-      const int act = a.ctl.force_reset ? 0 : a.action[i];
-      const int t = Fam::advance(a, s_fam, i, lane, step, a.state[i], act, nst, reward);
-      a.state[i] = nst;
-      bsx_emit(a.ctl, a.out, i, lane, step, t, reward);
-      types[j] = t;
-    }
+  const int64_t i = (int64_t)blockIdx.x * BSX_BLOCK + threadIdx.x;
+  int type = -1;
+  if (i < a.ctl.n_lanes) {
+    const uint64_t lane = a.ctl.lane_offset + (uint64_t)i;
+    const uint64_t step = bsx_step_of(a.ctl);
+    int32_t nst; double reward;
+    const int act = a.ctl.force_reset ? 0 : a.action[i];
+    type = Fam::advance(a, s_fam, i, lane, step, a.state[i], act, nst, reward);
+    a.state[i] = nst;
+    bsx_emit(a.ctl, a.out, i, lane, step, type, reward);
   }
-#pragma unroll
-  for (int j = 0; j < 4; ++j) bsx_count_types(a.ctl, types[j], s_cnt);
+  bsx_count_types(a.ctl, type, s_cnt);
   __syncthreads();
   bsx_flush_counts(a.ctl, s_cnt);
 }

@@ -60,20 +60,12 @@ static inline int bsx_env_int(const char* name, int dflt) {
   return (v != nullptr && *v != '\0') ? atoi(v) : dflt;
 }
 
-// Launches the four-lanes-per-thread advance kernel; the 16-byte vector path needs every column
-// 16-byte aligned (torch allocations are), otherwise all threads take its scalar branch.
+// Launches the lane-per-thread advance kernel of a two-kernel family.
 template <class Fam>
-static inline int bsx_launch_advance(const typename Fam::args& a, const int32_t* action, const int32_t* state,
-                                     const bsx_timestep_t& out, hipStream_t st) {
-  const uintptr_t bits = reinterpret_cast<uintptr_t>(action) | reinterpret_cast<uintptr_t>(state) |
-                         reinterpret_cast<uintptr_t>(out.reward) | reinterpret_cast<uintptr_t>(out.discount) |
-                         reinterpret_cast<uintptr_t>(out.step_type);
-  static const int vec_env = bsx_env_int("BSX_ADVANCE_VEC", 1);
-  const int vec_ok = vec_env && (bits & 15u) == 0;
-  const int64_t threads = (a.ctl.n_lanes + 3) / 4;
-  const int64_t blocks = (threads + BSX_BLOCK - 1) / BSX_BLOCK;
+static inline int bsx_launch_advance(const typename Fam::args& a, hipStream_t st) {
+  const int64_t blocks = (a.ctl.n_lanes + BSX_BLOCK - 1) / BSX_BLOCK;
   if (blocks > 0x7FFFFFFF) return BSX_EINVAL;
-  bsx_advance4_kernel<Fam><<<dim3((unsigned)blocks), dim3(BSX_BLOCK), 0, st>>>(a, vec_ok);
+  bsx_advance_kernel<Fam><<<dim3((unsigned)blocks), dim3(BSX_BLOCK), 0, st>>>(a);
   return 0;
 }
 

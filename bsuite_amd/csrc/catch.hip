@@ -4,7 +4,7 @@
 // 221 B per lane per call at 10x5: 21 B of scalar columns + a 200 B board with at most two ones.
 // The board is never materialised anywhere but in the output: a lane is its two hot cell indices
 // (ball, paddle), decoded from the packed state.  Two launches per call:
-//   advance  bsx_advance4_kernel<catch_fam>: four lanes per thread (paddle moves before the ball
+//   advance  bsx_advance_kernel<catch_fam>: one lane per thread (paddle moves before the ball
 //            drops, action ignored on the auto-reset call, `randint(columns)` on reset);
 //   observe  bsx_hot_stream_kernel<catch_hot,2,256>: pure store stream over [B x rows*cols] f32.
 //            rows*cols = 50 is not a multiple of 4, so a 16-byte chunk may straddle two lanes'
@@ -88,7 +88,7 @@ extern "C" int bsx_catch_step(const bsx_catch_t* cfg, const bsx_call_t* call, co
     a.action = action ? action + off : action;
     a.out.reward = out.reward + off; a.out.discount = out.discount + off; a.out.step_type = out.step_type + off;
     a.out.observation = out.observation + off * (int64_t)cells;
-    rc = bsx_launch_advance<catch_fam>(a, a.action, state, a.out, st);
+    rc = bsx_launch_advance<catch_fam>(a, st);
     if (rc != 0) return rc;
     rc = bsx_launch_hot_stream(a.out.observation, state, call->n_lanes, cells, bsx_div_magic(cells), fn, st, 2);
     if (rc != 0) return rc;

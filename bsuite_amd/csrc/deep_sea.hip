@@ -3,10 +3,10 @@
 //
 // Shape of the work at the headline config (N=30, B=2^20): 21 B of scalar traffic and 3600 B of
 // observation stores per lane per call — a pure store stream.  Two launches per call:
-//   advance  bsx_advance4_kernel<deep_sea_fam>: the N*N-bit action mapping goes kernarg -> LDS once
-//            per block (lane-divergent `mapping[row,col]` lookup); every thread advances four
-//            lanes (16-byte column loads/stores of action / packed state / reward / discount,
-//            4-byte step_type), LAST/FIRST masks by wavefront ballot;
+//   advance  bsx_advance_kernel<deep_sea_fam>: the N*N-bit action mapping goes kernarg -> LDS once
+//            per block (lane-divergent `mapping[row,col]` lookup); every thread advances one
+//            lane (coalesced column loads/stores of action / packed state / reward / discount /
+//            step_type), LAST/FIRST masks by wavefront ballot;
 //   observe  bsx_hot_stream_kernel<deep_sea_hot,4,256>: a pure store stream over [B x N*N] f32 —
 //            block b writes floats [b*4096,(b+1)*4096) as 4 lane-interleaved 16-byte stores per
 //            thread, hot cells recomputed from the packed state column (4 B/lane, L2-resident).
@@ -122,7 +122,7 @@ extern "C" int bsx_deep_sea_step(const bsx_deep_sea_t* cfg, const bsx_call_t* ca
     a.action = action ? action + off : action;
     a.out.reward = out.reward + off; a.out.discount = out.discount + off; a.out.step_type = out.step_type + off;
     a.out.observation = out.observation + off * (int64_t)cells;
-    rc = bsx_launch_advance<deep_sea_fam>(a, a.action, state, a.out, st);
+    rc = bsx_launch_advance<deep_sea_fam>(a, st);
     if (rc != 0) return rc;
     rc = bsx_launch_hot_stream(a.out.observation, state, call->n_lanes, cells, bsx_div_magic(cells), fn, st, 4);
     if (rc != 0) return rc;

@@ -60,7 +60,7 @@ class SweepBatch:
   """All (or some) bsuite_ids as lane segments on this rank's GPU."""
 
   def __init__(self, bsuite_ids: Optional[Sequence[str]] = None, total_lanes: int = 1 << 20, *,
-               device=None, seed: int = 0, rank: int = 0, world_size: int = 1, num_streams: int = 8,
+               device=None, seed: int = 0, rank: int = 0, world_size: int = 1, num_streams: int = 32,
                env_kwargs: Optional[Dict[str, dict]] = None):
     self.ids = list(_sweep.SWEEP if bsuite_ids is None else bsuite_ids)
     self.table = segment_table(self.ids, total_lanes)
