@@ -90,7 +90,12 @@ def bench_sweep(args, torch, dist, dev, rank, world):
                         num_streams=int(os.environ.get('BSX_SWEEP_STREAMS', '32')),
                         env_kwargs=dict(mnist=mn, mnist_noise=mn, mnist_scale=mn))
   acts = batch.random_actions(seed=1 + rank)
-  batch.capture(acts)
+  grouped = os.environ.get('BSX_SWEEP_MODE', 'grouped') == 'grouped'
+  if grouped:
+    batch.prepare_groups(acts)
+    batch.replay = batch.step_grouped
+  else:
+    batch.capture(acts)
 
   def sync_all():
     torch.cuda.synchronize(dev)
@@ -135,7 +140,8 @@ def bench_sweep(args, torch, dist, dev, rank, world):
         'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBPS, 'unit': 'GB/s',
                      'frac': achieved / HBM_PEAK_GBPS, 'traffic': None, 'kernel_ms': step_ms,
                      'algorithmic_bytes_per_launch': total_bytes / world},
-        'launch': f'one hipGraph per sweep step ({len(batch.envs)} segments over {batch.num_streams} streams)'}),
+        'launch': (f'{len(batch._groups)} grouped launches per sweep step ({len(batch.envs)} segments)' if grouped else
+                   f'one hipGraph per sweep step ({len(batch.envs)} segments over {batch.num_streams} streams)')}),
           flush=True)
   if world > 1:
     dist.destroy_process_group()

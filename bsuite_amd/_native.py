@@ -151,6 +151,19 @@ _SIGS = {
     'bsx_mountain_car_step': ([ctypes.POINTER(MountainCarCfg), ctypes.POINTER(Call), _P, _P, _P,
                                TimeStepPtrs, _P], ctypes.c_int),
 }
+_G = ctypes.c_void_p   # bsx_group_t*
+_SIGS.update({
+    'bsx_group_create': ([ctypes.c_int32, ctypes.c_int32, ctypes.POINTER(_G)], ctypes.c_int),
+    'bsx_group_commit': ([_G], ctypes.c_int),
+    'bsx_group_step': ([_G, _P], ctypes.c_int),
+    'bsx_group_destroy': ([_G], ctypes.c_int),
+})
+for _fam in ('deep_sea', 'catch', 'bandit', 'memory_chain', 'umbrella_chain', 'discounting_chain',
+             'cartpole', 'mountain_car', 'mnist'):
+  _step_args, _ = _SIGS[f'bsx_{_fam}_step']
+  _SIGS[f'bsx_group_set_{_fam}'] = ([_G, ctypes.c_int32] + list(_step_args), ctypes.c_int)
+FAMILY_IDS = dict(deep_sea=0, catch=1, bandit=2, memory_chain=3, umbrella_chain=4, discounting_chain=5,
+                  cartpole=6, mountain_car=7, mnist=8)
 EXPORTED = tuple(sorted(_SIGS))
 MISSING = []
 for _name, (_args, _res) in _SIGS.items():
@@ -163,7 +176,7 @@ for _name, (_args, _res) in _SIGS.items():
   _fn.restype = _res
 if MISSING:
   raise NativeLibraryError(f'{SO_PATH} does not export {MISSING}; rebuild with `python -m bsuite_amd.build --force`')
-ABI_VERSION = 4
+ABI_VERSION = 5
 if lib.bsx_abi_version() != ABI_VERSION:
   raise NativeLibraryError('ABI version mismatch between bsuite_amd/_native.py and libbsuite_amd.so')
 

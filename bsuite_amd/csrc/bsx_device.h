@@ -160,12 +160,25 @@ __device__ __forceinline__ void bsx_count_types(const bsx_ctl& c, int type, unsi
 }
 
 // Call after a __syncthreads() that follows every wave's bsx_count_types.
-__device__ __forceinline__ void bsx_flush_counts(const bsx_ctl& c, const unsigned int* s_cnt) {
+__device__ __forceinline__ void bsx_flush_counts(const bsx_ctl& c, const unsigned int* s_cnt,
+                                                 uint32_t block_id = 0xFFFFFFFFu) {
   if (c.counters == nullptr || threadIdx.x != 0) return;
+  if (block_id == 0xFFFFFFFFu) block_id = blockIdx.x;
   unsigned long long* shard = (unsigned long long*)c.counters +
-                              (size_t)(blockIdx.x & (BSX_COUNTER_SHARDS - 1)) * BSX_COUNTER_STRIDE;
+                              (size_t)(block_id & (BSX_COUNTER_SHARDS - 1)) * BSX_COUNTER_STRIDE;
   if (s_cnt[0]) atomicAdd(&shard[0], (unsigned long long)s_cnt[0]);
   if (s_cnt[1]) atomicAdd(&shard[1], (unsigned long long)s_cnt[1]);
+}
+
+// Grouped launch: segment of a workgroup = largest s with start[s] <= blockIdx.x (start is the
+// exclusive prefix sum of per-segment workgroup counts, n+1 entries, in device memory).
+__device__ __forceinline__ int bsx_group_find(const int32_t* __restrict__ start, int n, int b) {
+  int lo = 0, hi = n;            // invariant: start[lo] <= b < start[hi]
+  while (hi - lo > 1) {
+    const int mid = (lo + hi) >> 1;
+    if (start[mid] <= b) lo = mid; else hi = mid;
+  }
+  return lo;
 }
 
 // Advance kernel of the two-kernel families (deep_sea, catch): one lane per thread, coalesced
@@ -178,13 +191,12 @@ __device__ __forceinline__ void bsx_flush_counts(const bsx_ctl& c, const unsigne
 //                             double* info; ... };  struct shared;  static stage(args, shared&);
 //   static int advance(args, shared, i, lane, step, st, act, nst&, reward&)
 template <class Fam>
-__global__ void __launch_bounds__(BSX_BLOCK) bsx_advance_kernel(const typename Fam::args a) {
-  __shared__ typename Fam::shared s_fam;
-  __shared__ unsigned int s_cnt[2];
+__device__ __forceinline__ void bsx_advance_body(const typename Fam::args& a, uint32_t block_id,
+                                                 typename Fam::shared& s_fam, unsigned int* s_cnt) {
   if (threadIdx.x < 2) s_cnt[threadIdx.x] = 0;
   Fam::stage(a, s_fam);
   __syncthreads();
-  const int64_t i = (int64_t)blockIdx.x * BSX_BLOCK + threadIdx.x;
+  const int64_t i = (int64_t)block_id * BSX_BLOCK + threadIdx.x;
   int type = -1;
   if (i < a.ctl.n_lanes) {
     const uint64_t lane = a.ctl.lane_offset + (uint64_t)i;
@@ -197,7 +209,23 @@ __global__ void __launch_bounds__(BSX_BLOCK) bsx_advance_kernel(const typename F
   }
   bsx_count_types(a.ctl, type, s_cnt);
   __syncthreads();
-  bsx_flush_counts(a.ctl, s_cnt);
+  bsx_flush_counts(a.ctl, s_cnt, block_id);
+}
+
+template <class Fam>
+__global__ void __launch_bounds__(BSX_BLOCK) bsx_advance_kernel(const typename Fam::args a) {
+  __shared__ typename Fam::shared s_fam;
+  __shared__ unsigned int s_cnt[2];
+  bsx_advance_body<Fam>(a, blockIdx.x, s_fam, s_cnt);
+}
+
+template <class Fam>
+__global__ void __launch_bounds__(BSX_BLOCK) bsx_advance_group_kernel(const typename Fam::args* __restrict__ table,
+                                                                      const int32_t* __restrict__ start, int n) {
+  __shared__ typename Fam::shared s_fam;
+  __shared__ unsigned int s_cnt[2];
+  const int seg = bsx_group_find(start, n, (int)blockIdx.x);
+  bsx_advance_body<Fam>(table[seg], blockIdx.x - (uint32_t)start[seg], s_fam, s_cnt);
 }
 
 // n / cells for n < 2^20 via the host-built magic (bsx_div_magic); cells == 1 has no 32-bit magic.
@@ -221,14 +249,25 @@ struct bsx_div64 {            // n / d = __umul64hi(n, m) >> s, exact for n*d < 
   uint32_t s;
 };
 
+template <class HotFn>
+struct bsx_stream_seg {            // one segment's arguments of the observation stream kernel
+  float* obs;
+  const int32_t* state;
+  int64_t n_lanes;
+  uint32_t cells;
+  uint32_t cells_magic;
+  bsx_div64 dv;
+  HotFn fn;
+};
+
 template <class HotFn, int K, int BS>
-__global__ void __launch_bounds__(BS) bsx_hot_stream_kernel(float* __restrict__ obs,
-                                                                   const int32_t* __restrict__ state,
-                                                                   int64_t n_lanes, uint32_t cells,
-                                                                   uint32_t cells_magic, bsx_div64 dv,
-                                                                   HotFn fn) {
+__device__ __forceinline__ void bsx_hot_stream_body(float* __restrict__ obs,
+                                                    const int32_t* __restrict__ state,
+                                                    int64_t n_lanes, uint32_t cells,
+                                                    uint32_t cells_magic, bsx_div64 dv,
+                                                    const HotFn& fn, uint32_t block_id) {
   const uint64_t total = (uint64_t)n_lanes * cells;                      // floats in the array
-  const uint64_t F0 = (uint64_t)blockIdx.x * (uint64_t)(K * 4 * BS);
+  const uint64_t F0 = (uint64_t)block_id * (uint64_t)(K * 4 * BS);
   const uint64_t lane_b = __umul64hi(F0, dv.m) >> dv.s;                  // uniform
   const uint32_t r_b = (uint32_t)(F0 - lane_b * cells);                  // < cells
   const bool aligned = (cells & 3u) == 0;
@@ -285,6 +324,24 @@ __global__ void __launch_bounds__(BS) bsx_hot_stream_kernel(float* __restrict__ 
       obs[F] = (ha == r || hb == r) ? 1.0f : 0.0f;
     }
   }
+}
+
+template <class HotFn, int K, int BS>
+__global__ void __launch_bounds__(BS) bsx_hot_stream_kernel(float* __restrict__ obs,
+                                                                   const int32_t* __restrict__ state,
+                                                                   int64_t n_lanes, uint32_t cells,
+                                                                   uint32_t cells_magic, bsx_div64 dv,
+                                                                   HotFn fn) {
+  bsx_hot_stream_body<HotFn, K, BS>(obs, state, n_lanes, cells, cells_magic, dv, fn, blockIdx.x);
+}
+
+template <class HotFn, int K>
+__global__ void __launch_bounds__(BSX_BLOCK) bsx_hot_stream_group_kernel(
+    const bsx_stream_seg<HotFn>* __restrict__ table, const int32_t* __restrict__ start, int n) {
+  const int seg = bsx_group_find(start, n, (int)blockIdx.x);
+  const bsx_stream_seg<HotFn>& g = table[seg];
+  bsx_hot_stream_body<HotFn, K, BSX_BLOCK>(g.obs, g.state, g.n_lanes, g.cells, g.cells_magic, g.dv, g.fn,
+                                           blockIdx.x - (uint32_t)start[seg]);
 }
 
 // Degenerate boards (cells < 4: a 16-byte chunk spans several lanes): one float per thread.

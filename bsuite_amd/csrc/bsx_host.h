@@ -3,6 +3,9 @@
 #define BSX_HOST_H_
 
 #include <stdlib.h>
+#include <string.h>
+
+#include <vector>
 
 #include "bsx_device.h"
 
@@ -112,6 +115,77 @@ static inline int bsx_launch_hot_stream(float* obs, const int32_t* state, int64_
   else { BSX_HS_ALL(64) }
 #undef BSX_HS_ALL
 #undef BSX_HS
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Grouped launch (bsx_group_t): host-side container.  Each family file fills `args`/`args2` (its
+// kernel argument structs, one per segment) and the per-segment block counts, and installs `launch`.
+struct bsx_group {
+  int32_t family = -1;
+  int32_t n = 0;
+  int32_t klass = -1;                   // family-specific launch class (e.g. LPB of small_obs), -1 unset
+  size_t arg_size = 0, arg2_size = 0;
+  std::vector<uint8_t> args, args2;     // n * arg_size  /  n * arg2_size (second kernel of a pair)
+  std::vector<int32_t> blocks, blocks2; // workgroups of each segment in kernel 1 / kernel 2
+  std::vector<uint8_t> is_set;
+  size_t lds_bytes = 0;                 // max dynamic LDS over segments (kernel 1)
+  void* d_args = nullptr;
+  void* d_args2 = nullptr;
+  int32_t* d_start = nullptr;           // [n+1] exclusive prefix of blocks
+  int32_t* d_start2 = nullptr;
+  int64_t total_blocks = 0, total_blocks2 = 0;
+  bool committed = false;
+  int (*launch)(bsx_group*, hipStream_t) = nullptr;
+};
+
+static inline uint64_t bsx_flat_blocks(uint64_t total_floats, int k) {
+  const uint64_t per_block = (uint64_t)k * 4 * BSX_BLOCK;
+  return (total_floats + per_block - 1) / per_block;
+}
+
+// Records one segment of a two-kernel family (advance args + stream-kernel segment).
+template <class Fam, class HotFn>
+static inline int bsx_group_put_pair(bsx_group* g, int32_t index, const typename Fam::args& a, float* obs,
+                                     int32_t* state, uint32_t cells, const HotFn& fn, int k) {
+  if (cells < 4u) return BSX_ERANGE;                        // degenerate boards: step them singly
+  memcpy(&g->args[(size_t)index * sizeof(typename Fam::args)], &a, sizeof(a));
+  bsx_stream_seg<HotFn> sg;
+  sg.obs = obs; sg.state = state; sg.n_lanes = a.ctl.n_lanes; sg.cells = cells;
+  sg.cells_magic = bsx_div_magic(cells); sg.dv = bsx_make_div64(cells); sg.fn = fn;
+  memcpy(&g->args2[(size_t)index * sizeof(sg)], &sg, sizeof(sg));
+  const uint64_t b1 = (uint64_t)(a.ctl.n_lanes + BSX_BLOCK - 1) / BSX_BLOCK;
+  const uint64_t b2 = bsx_flat_blocks((uint64_t)a.ctl.n_lanes * cells, k);
+  if (b1 > 0x3FFFFFFFull || b2 > 0x3FFFFFFFull) return BSX_EINVAL;
+  g->blocks[index] = (int32_t)b1; g->blocks2[index] = (int32_t)b2;
+  g->is_set[index] = 1;
+  return 0;
+}
+
+template <class Fam, class HotFn, int K>
+static int bsx_group_launch_pair(bsx_group* g, hipStream_t st) {
+  bsx_advance_group_kernel<Fam><<<dim3((unsigned)g->total_blocks), dim3(BSX_BLOCK), 0, st>>>(
+      (const typename Fam::args*)g->d_args, g->d_start, g->n);
+  bsx_hot_stream_group_kernel<HotFn, K><<<dim3((unsigned)g->total_blocks2), dim3(BSX_BLOCK), 0, st>>>(
+      (const bsx_stream_seg<HotFn>*)g->d_args2, g->d_start2, g->n);
+  return (int)hipGetLastError();
+}
+
+// Common validation + bookkeeping of bsx_group_set_<family>.
+static inline int bsx_group_check_set(bsx_group* g, int32_t family, int32_t index, const bsx_call_t* call,
+                                      size_t arg_size, size_t arg2_size, int klass) {
+  if (g == nullptr || call == nullptr) return BSX_ENULL;
+  if (g->committed || g->family != family || index < 0 || index >= g->n) return BSX_EINVAL;
+  if (call->stream.step_base == nullptr || call->force_reset || call->n_steps > 1 || call->n_lanes < 1)
+    return BSX_EINVAL;                 // static arguments need a device-resident call counter
+  if (g->klass >= 0 && g->klass != klass) return BSX_EINVAL;
+  g->klass = klass;
+  if (g->args.empty()) {
+    g->arg_size = arg_size; g->arg2_size = arg2_size;
+    g->args.assign((size_t)g->n * arg_size, 0);
+    g->args2.assign((size_t)g->n * arg2_size, 0);
+  }
+  if (g->arg_size != arg_size || g->arg2_size != arg2_size) return BSX_EINVAL;
   return 0;
 }
 

@@ -66,18 +66,25 @@ struct catch_hot {
   }
 };
 
-extern "C" int bsx_catch_step(const bsx_catch_t* cfg, const bsx_call_t* call, const int32_t* action,
-                              int32_t* state, bsx_timestep_t out, double* info) {
+static int catch_make(const bsx_catch_t* cfg, const bsx_call_t* call, const int32_t* action, int32_t* state,
+                      bsx_timestep_t out, double* info, catch_fam::args* a) {
   if (cfg == nullptr) return BSX_ENULL;
   int rc = bsx_check_call(call, action, out);
   if (rc != 0) return rc;
   if (cfg->rows < 2 || cfg->rows > 64 || cfg->columns < 1 || cfg->columns > 64) return BSX_ERANGE;
-  if (call->n_lanes == 0) return 0;
-  if (state == nullptr || info == nullptr) return BSX_ENULL;
+  if (call->n_lanes > 0 && (state == nullptr || info == nullptr)) return BSX_ENULL;
+  a->ctl = bsx_make_ctl(call);
+  a->action = action; a->state = state; a->out = out; a->info = info;
+  a->rows = cfg->rows; a->columns = cfg->columns;
+  return 0;
+}
+
+extern "C" int bsx_catch_step(const bsx_catch_t* cfg, const bsx_call_t* call, const int32_t* action,
+                              int32_t* state, bsx_timestep_t out, double* info) {
   catch_fam::args a;
-  a.ctl = bsx_make_ctl(call);
-  a.action = action; a.state = state; a.out = out; a.info = info;
-  a.rows = cfg->rows; a.columns = cfg->columns;
+  int rc = catch_make(cfg, call, action, state, out, info, &a);
+  if (rc != 0) return rc;
+  if (call->n_lanes == 0) return 0;
   const uint32_t cells = (uint32_t)(cfg->rows * cfg->columns);
   hipStream_t st = (hipStream_t)call->hip_stream;
   catch_hot fn{cfg->rows, cfg->columns};
@@ -94,4 +101,18 @@ extern "C" int bsx_catch_step(const bsx_catch_t* cfg, const bsx_call_t* call, co
     if (rc != 0) return rc;
   }
   return bsx_launch_status();
+}
+
+extern "C" int bsx_group_set_catch(bsx_group_t* g, int32_t index, const bsx_catch_t* cfg, const bsx_call_t* call,
+                                   const int32_t* action, int32_t* state, bsx_timestep_t out, double* info) {
+  int rc = bsx_group_check_set(g, BSX_FAM_CATCH, index, call, sizeof(catch_fam::args),
+                               sizeof(bsx_stream_seg<catch_hot>), 0);
+  if (rc != 0) return rc;
+  catch_fam::args a;
+  rc = catch_make(cfg, call, action, state, out, info, &a);
+  if (rc != 0) return rc;
+  g->launch = bsx_group_launch_pair<catch_fam, catch_hot, 2>;
+  return bsx_group_put_pair<catch_fam, catch_hot>(g, index, a, out.observation, state,
+                                                  (uint32_t)(cfg->rows * cfg->columns),
+                                                  catch_hot{cfg->rows, cfg->columns}, 2);
 }

@@ -94,23 +94,30 @@ struct deep_sea_hot {
   }
 };
 
-extern "C" int bsx_deep_sea_step(const bsx_deep_sea_t* cfg, const bsx_call_t* call,
-                                 const int32_t* action, int32_t* state, bsx_timestep_t out,
-                                 double* info) {
+// Validates one call's arguments and fills the kernel argument struct (shared by step and group).
+static int deep_sea_make(const bsx_deep_sea_t* cfg, const bsx_call_t* call, const int32_t* action,
+                         int32_t* state, bsx_timestep_t out, double* info, deep_sea_fam::args* a) {
   if (cfg == nullptr) return BSX_ENULL;
   int rc = bsx_check_call(call, action, out);
   if (rc != 0) return rc;
   if (cfg->size < 1 || cfg->size > BSX_DEEP_SEA_MAX_SIZE) return BSX_ERANGE;
   if (call->stream.mt_state != nullptr && !cfg->deterministic) return BSX_EMODE;   // needs randn
-  if (call->n_lanes == 0) return 0;
-  if (state == nullptr || info == nullptr) return BSX_ENULL;
+  if (call->n_lanes > 0 && (state == nullptr || info == nullptr)) return BSX_ENULL;
+  a->ctl = bsx_make_ctl(call);
+  a->action = action; a->state = state; a->out = out; a->info = info;
+  a->move_cost = cfg->move_cost; a->inv_size = cfg->inv_size;
+  a->size = cfg->size; a->deterministic = cfg->deterministic;
+  for (int w = 0; w < DS_MAP_WORDS; ++w) a->mapping_bits[w] = cfg->mapping_bits[w];
+  return 0;
+}
 
+extern "C" int bsx_deep_sea_step(const bsx_deep_sea_t* cfg, const bsx_call_t* call,
+                                 const int32_t* action, int32_t* state, bsx_timestep_t out,
+                                 double* info) {
   deep_sea_fam::args a;
-  a.ctl = bsx_make_ctl(call);
-  a.action = action; a.state = state; a.out = out; a.info = info;
-  a.move_cost = cfg->move_cost; a.inv_size = cfg->inv_size;
-  a.size = cfg->size; a.deterministic = cfg->deterministic;
-  for (int w = 0; w < DS_MAP_WORDS; ++w) a.mapping_bits[w] = cfg->mapping_bits[w];
+  int rc = deep_sea_make(cfg, call, action, state, out, info, &a);
+  if (rc != 0) return rc;
+  if (call->n_lanes == 0) return 0;
   const uint32_t cells = (uint32_t)(cfg->size * cfg->size);
   hipStream_t st = (hipStream_t)call->hip_stream;
 
@@ -124,8 +131,23 @@ extern "C" int bsx_deep_sea_step(const bsx_deep_sea_t* cfg, const bsx_call_t* ca
     a.out.observation = out.observation + off * (int64_t)cells;
     rc = bsx_launch_advance<deep_sea_fam>(a, st);
     if (rc != 0) return rc;
+    // K = 4 stores/thread x 256 threads is a sharp optimum (profiles/r01/sweep_stream_*.log)
     rc = bsx_launch_hot_stream(a.out.observation, state, call->n_lanes, cells, bsx_div_magic(cells), fn, st, 4);
     if (rc != 0) return rc;
   }
   return bsx_launch_status();
+}
+
+extern "C" int bsx_group_set_deep_sea(bsx_group_t* g, int32_t index, const bsx_deep_sea_t* cfg,
+                                      const bsx_call_t* call, const int32_t* action, int32_t* state,
+                                      bsx_timestep_t out, double* info) {
+  int rc = bsx_group_check_set(g, BSX_FAM_DEEP_SEA, index, call, sizeof(deep_sea_fam::args),
+                               sizeof(bsx_stream_seg<deep_sea_hot>), 0);
+  if (rc != 0) return rc;
+  deep_sea_fam::args a;
+  rc = deep_sea_make(cfg, call, action, state, out, info, &a);
+  if (rc != 0) return rc;
+  g->launch = bsx_group_launch_pair<deep_sea_fam, deep_sea_hot, 4>;
+  return bsx_group_put_pair<deep_sea_fam, deep_sea_hot>(g, index, a, out.observation, state,
+                                                        (uint32_t)(cfg->size * cfg->size), deep_sea_hot{cfg->size}, 4);
 }

@@ -74,3 +74,59 @@ extern "C" int bsx_stream_dump(uint64_t seed, uint64_t lane0, int64_t n_lanes, u
       seed, lane0, n_lanes, step, (uint32_t)stream_id, n_words, words, normals);
   return bsx_launch_status();
 }
+
+// ------------------------------------------------------------------------------ grouped launch
+extern "C" int bsx_group_create(int32_t family, int32_t n_segments, bsx_group_t** group) {
+  if (group == nullptr) return BSX_ENULL;
+  if (family < BSX_FAM_DEEP_SEA || family > BSX_FAM_MNIST || n_segments < 1 || n_segments > (1 << 20)) return BSX_EINVAL;
+  bsx_group* g = new bsx_group();
+  g->family = family; g->n = n_segments;
+  g->blocks.assign(n_segments, 0); g->blocks2.assign(n_segments, 0); g->is_set.assign(n_segments, 0);
+  *group = g;
+  return 0;
+}
+
+static int upload(const void* src, size_t bytes, void** dst) {
+  if (bytes == 0) { *dst = nullptr; return 0; }
+  hipError_t e = hipMalloc(dst, bytes);
+  if (e != hipSuccess) return (int)e;
+  return (int)hipMemcpy(*dst, src, bytes, hipMemcpyHostToDevice);
+}
+
+extern "C" int bsx_group_commit(bsx_group_t* g) {
+  if (g == nullptr) return BSX_ENULL;
+  if (g->committed || g->launch == nullptr) return BSX_EINVAL;
+  for (int i = 0; i < g->n; ++i) if (!g->is_set[i]) return BSX_EINVAL;
+  std::vector<int32_t> start(g->n + 1, 0), start2(g->n + 1, 0);
+  int64_t t1 = 0, t2 = 0;
+  for (int i = 0; i < g->n; ++i) {
+    start[i] = (int32_t)t1; start2[i] = (int32_t)t2;
+    t1 += g->blocks[i]; t2 += g->blocks2[i];
+    if (t1 > 0x7FFFFFFF || t2 > 0x7FFFFFFF) return BSX_EINVAL;
+  }
+  start[g->n] = (int32_t)t1; start2[g->n] = (int32_t)t2;
+  g->total_blocks = t1; g->total_blocks2 = t2;
+  int rc = upload(g->args.data(), g->args.size(), &g->d_args);
+  if (rc == 0) rc = upload(g->args2.data(), g->args2.size(), &g->d_args2);
+  if (rc == 0) rc = upload(start.data(), start.size() * 4, (void**)&g->d_start);
+  if (rc == 0) rc = upload(start2.data(), start2.size() * 4, (void**)&g->d_start2);
+  if (rc != 0) return rc;
+  g->committed = true;
+  return 0;
+}
+
+extern "C" int bsx_group_step(bsx_group_t* g, void* hip_stream) {
+  if (g == nullptr) return BSX_ENULL;
+  if (!g->committed) return BSX_EINVAL;
+  return g->launch(g, (hipStream_t)hip_stream);
+}
+
+extern "C" int bsx_group_destroy(bsx_group_t* g) {
+  if (g == nullptr) return 0;
+  if (g->d_args) (void)hipFree(g->d_args);
+  if (g->d_args2) (void)hipFree(g->d_args2);
+  if (g->d_start) (void)hipFree(g->d_start);
+  if (g->d_start2) (void)hipFree(g->d_start2);
+  delete g;
+  return 0;
+}

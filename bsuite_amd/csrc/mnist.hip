@@ -26,11 +26,10 @@ struct mnist_args {
 #define MN_RESET_BIT (1 << 28)
 #define MN_SHOW_BIT (1 << 29)
 
-__global__ void __launch_bounds__(BSX_BLOCK) mnist_advance_kernel(const mnist_args a) {
-  __shared__ unsigned int s_cnt[2];
+__device__ __forceinline__ void mnist_advance_body(const mnist_args& a, uint32_t block_id, unsigned int* s_cnt) {
   if (threadIdx.x < 2) s_cnt[threadIdx.x] = 0;
   __syncthreads();
-  const int64_t i = (int64_t)blockIdx.x * BSX_BLOCK + threadIdx.x;
+  const int64_t i = (int64_t)block_id * BSX_BLOCK + threadIdx.x;
   int type = -1;
   if (i < a.ctl.n_lanes) {
     const uint64_t lane = a.ctl.lane_offset + (uint64_t)i;
@@ -57,7 +56,19 @@ __global__ void __launch_bounds__(BSX_BLOCK) mnist_advance_kernel(const mnist_ar
   }
   bsx_count_types(a.ctl, type, s_cnt);
   __syncthreads();
-  bsx_flush_counts(a.ctl, s_cnt);
+  bsx_flush_counts(a.ctl, s_cnt, block_id);
+}
+
+__global__ void __launch_bounds__(BSX_BLOCK) mnist_advance_kernel(const mnist_args a) {
+  __shared__ unsigned int s_cnt[2];
+  mnist_advance_body(a, blockIdx.x, s_cnt);
+}
+
+__global__ void __launch_bounds__(BSX_BLOCK) mnist_advance_group_kernel(const mnist_args* __restrict__ table,
+                                                                        const int32_t* __restrict__ start, int n) {
+  __shared__ unsigned int s_cnt[2];
+  const int seg = bsx_group_find(start, n, (int)blockIdx.x);
+  mnist_advance_body(table[seg], blockIdx.x - (uint32_t)start[seg], s_cnt);
 }
 
 struct mnist_observe_args {
@@ -74,13 +85,12 @@ struct mnist_observe_args {
 // Block b writes floats [b*K*1024, (b+1)*K*1024) of the [B x num_pixels] observation array
 // (num_pixels % 4 == 0, so a 16-byte chunk never straddles two lanes).
 template <int K>
-__global__ void __launch_bounds__(BSX_BLOCK) mnist_observe_kernel(const mnist_observe_args a) {
-  __shared__ float s_lut[256];
+__device__ __forceinline__ void mnist_observe_body(const mnist_observe_args& a, uint32_t block_id, float* s_lut) {
   s_lut[threadIdx.x] = a.lut[threadIdx.x];
   __syncthreads();
   const uint32_t cells = a.cells;
   const uint64_t total = (uint64_t)a.n_lanes * cells;
-  const uint64_t F0 = (uint64_t)blockIdx.x * (uint64_t)(K * 4 * BSX_BLOCK);
+  const uint64_t F0 = (uint64_t)block_id * (uint64_t)(K * 4 * BSX_BLOCK);
   const uint64_t lane_b = __umul64hi(F0, a.dv.m) >> a.dv.s;
   const uint32_t r_b = (uint32_t)(F0 - lane_b * cells);
   bsx_f4* __restrict__ o4 = reinterpret_cast<bsx_f4*>(a.obs + F0);
@@ -115,34 +125,53 @@ __global__ void __launch_bounds__(BSX_BLOCK) mnist_observe_kernel(const mnist_ob
   }
 }
 
-extern "C" int bsx_mnist_step(const bsx_mnist_t* cfg, const bsx_call_t* call, const int32_t* action,
-                              int32_t* state, bsx_timestep_t out, double* info) {
+template <int K>
+__global__ void __launch_bounds__(BSX_BLOCK) mnist_observe_kernel(const mnist_observe_args a) {
+  __shared__ float s_lut[256];
+  mnist_observe_body<K>(a, blockIdx.x, s_lut);
+}
+
+template <int K>
+__global__ void __launch_bounds__(BSX_BLOCK) mnist_observe_group_kernel(const mnist_observe_args* __restrict__ table,
+                                                                        const int32_t* __restrict__ start, int n) {
+  __shared__ float s_lut[256];
+  const int seg = bsx_group_find(start, n, (int)blockIdx.x);
+  mnist_observe_body<K>(table[seg], blockIdx.x - (uint32_t)start[seg], s_lut);
+}
+
+#define MNIST_K 4
+
+static int mnist_make(const bsx_mnist_t* cfg, const bsx_call_t* call, const int32_t* action, int32_t* state,
+                      bsx_timestep_t out, double* info, mnist_args* a, mnist_observe_args* o) {
   if (cfg == nullptr) return BSX_ENULL;
   int rc = bsx_check_call(call, action, out);
   if (rc != 0) return rc;
   if (cfg->num_data < 1 || cfg->num_data > (1 << 24) || cfg->num_pixels < 4 || cfg->num_pixels > 4096 ||
       (cfg->num_pixels & 3) != 0)
     return BSX_ERANGE;
-  if (call->n_lanes == 0) return 0;
-  if (state == nullptr || info == nullptr || cfg->images == nullptr || cfg->labels == nullptr) return BSX_ENULL;
+  if (call->n_lanes > 0 && (state == nullptr || info == nullptr || cfg->images == nullptr || cfg->labels == nullptr))
+    return BSX_ENULL;
   if ((reinterpret_cast<uintptr_t>(cfg->images) & 3u) != 0) return BSX_EALIGN;
-  hipStream_t st = (hipStream_t)call->hip_stream;
+  a->ctl = bsx_make_ctl(call);
+  a->action = action; a->state = state; a->out = out; a->info = info;
+  a->images = cfg->images; a->labels = cfg->labels; a->num_data = cfg->num_data; a->num_pixels = cfg->num_pixels;
+  o->obs = out.observation; o->state = state; o->images = cfg->images; o->n_lanes = call->n_lanes;
+  o->cells = (uint32_t)cfg->num_pixels; o->cells_magic = bsx_div_magic(o->cells); o->dv = bsx_make_div64(o->cells);
+  for (int k = 0; k < 256; ++k) o->lut[k] = cfg->pixel_lut[k];
+  return 0;
+}
 
+extern "C" int bsx_mnist_step(const bsx_mnist_t* cfg, const bsx_call_t* call, const int32_t* action,
+                              int32_t* state, bsx_timestep_t out, double* info) {
   mnist_args a;
-  a.ctl = bsx_make_ctl(call);
-  a.action = action; a.state = state; a.out = out; a.info = info;
-  a.images = cfg->images; a.labels = cfg->labels; a.num_data = cfg->num_data; a.num_pixels = cfg->num_pixels;
-  const int64_t blocks_a = (call->n_lanes + BSX_BLOCK - 1) / BSX_BLOCK;
-  if (blocks_a > 0x7FFFFFFF) return BSX_EINVAL;
   mnist_observe_args o;
-  o.state = state; o.images = cfg->images; o.n_lanes = call->n_lanes;
-  o.cells = (uint32_t)cfg->num_pixels; o.cells_magic = bsx_div_magic(o.cells); o.dv = bsx_make_div64(o.cells);
-  for (int k = 0; k < 256; ++k) o.lut[k] = cfg->pixel_lut[k];
-  constexpr int K = 4;
-  const uint64_t total = (uint64_t)call->n_lanes * o.cells;
-  const uint64_t per_block = (uint64_t)K * 4 * BSX_BLOCK;
-  const uint64_t blocks_o = (total + per_block - 1) / per_block;
-  if (blocks_o > 0x7FFFFFFFull) return BSX_EINVAL;
+  int rc = mnist_make(cfg, call, action, state, out, info, &a, &o);
+  if (rc != 0) return rc;
+  if (call->n_lanes == 0) return 0;
+  hipStream_t st = (hipStream_t)call->hip_stream;
+  const int64_t blocks_a = (call->n_lanes + BSX_BLOCK - 1) / BSX_BLOCK;
+  const uint64_t blocks_o = bsx_flat_blocks((uint64_t)call->n_lanes * o.cells, MNIST_K);
+  if (blocks_a > 0x7FFFFFFF || blocks_o > 0x7FFFFFFFull) return BSX_EINVAL;
   const int n_steps = bsx_n_steps(call);
   for (int t = 0; t < n_steps; ++t) {       // rollout: the kernel pair once per step
     const int64_t off = (int64_t)t * call->n_lanes;
@@ -151,7 +180,34 @@ extern "C" int bsx_mnist_step(const bsx_mnist_t* cfg, const bsx_call_t* call, co
     a.out.reward = out.reward + off; a.out.discount = out.discount + off; a.out.step_type = out.step_type + off;
     mnist_advance_kernel<<<dim3((unsigned)blocks_a), dim3(BSX_BLOCK), 0, st>>>(a);
     o.obs = out.observation + off * (int64_t)o.cells;
-    mnist_observe_kernel<K><<<dim3((unsigned)blocks_o), dim3(BSX_BLOCK), 0, st>>>(o);
+    mnist_observe_kernel<MNIST_K><<<dim3((unsigned)blocks_o), dim3(BSX_BLOCK), 0, st>>>(o);
   }
   return bsx_launch_status();
+}
+
+static int mnist_group_launch(bsx_group* g, hipStream_t st) {
+  mnist_advance_group_kernel<<<dim3((unsigned)g->total_blocks), dim3(BSX_BLOCK), 0, st>>>(
+      (const mnist_args*)g->d_args, g->d_start, g->n);
+  mnist_observe_group_kernel<MNIST_K><<<dim3((unsigned)g->total_blocks2), dim3(BSX_BLOCK), 0, st>>>(
+      (const mnist_observe_args*)g->d_args2, g->d_start2, g->n);
+  return (int)hipGetLastError();
+}
+
+extern "C" int bsx_group_set_mnist(bsx_group_t* g, int32_t index, const bsx_mnist_t* cfg, const bsx_call_t* call,
+                                   const int32_t* action, int32_t* state, bsx_timestep_t out, double* info) {
+  int rc = bsx_group_check_set(g, BSX_FAM_MNIST, index, call, sizeof(mnist_args), sizeof(mnist_observe_args), 0);
+  if (rc != 0) return rc;
+  mnist_args a;
+  mnist_observe_args o;
+  rc = mnist_make(cfg, call, action, state, out, info, &a, &o);
+  if (rc != 0) return rc;
+  memcpy(&g->args[(size_t)index * sizeof(a)], &a, sizeof(a));
+  memcpy(&g->args2[(size_t)index * sizeof(o)], &o, sizeof(o));
+  const uint64_t b1 = (uint64_t)(call->n_lanes + BSX_BLOCK - 1) / BSX_BLOCK;
+  const uint64_t b2 = bsx_flat_blocks((uint64_t)call->n_lanes * o.cells, MNIST_K);
+  if (b1 > 0x3FFFFFFFull || b2 > 0x3FFFFFFFull) return BSX_EINVAL;
+  g->blocks[index] = (int32_t)b1; g->blocks2[index] = (int32_t)b2;
+  g->is_set[index] = 1;
+  g->launch = mnist_group_launch;
+  return 0;
 }

@@ -21,16 +21,15 @@
 // re-read from L2 by the thread that wrote them, so HBM sees only the action/TimeStep streams —
 // the tiny families are otherwise bound by one ~8 us launch per step.
 template <class Env, int LPB, bool ROLLOUT, int LOG, int NOISE>
-__global__ void __launch_bounds__(BSX_BLOCK) small_obs_kernel(const typename Env::args a, const int n_steps_arg) {
+__device__ __forceinline__ void small_obs_body(const typename Env::args& a, const int n_steps_arg,
+                                               const uint32_t block_id, float* s_obs, unsigned int* s_cnt) {
   const int n_steps = ROLLOUT ? n_steps_arg : 1;   // the single-step instantiation has no loop: keeping
                                                     // every kernarg live across iterations costs ~120 VGPRs
-  extern __shared__ __attribute__((aligned(16))) float s_obs[];
-  __shared__ unsigned int s_cnt[2];
   if (threadIdx.x < 2) s_cnt[threadIdx.x] = 0;
   __syncthreads();
   const int numel = a.obs_numel;
   const int64_t B = a.ctl.n_lanes;
-  const int64_t lane0 = (int64_t)blockIdx.x * LPB;
+  const int64_t lane0 = (int64_t)block_id * LPB;
   const int64_t remaining = B - lane0;
   const int lanes_here = remaining < LPB ? (int)remaining : LPB;
   const uint64_t step0 = bsx_step_of(a.ctl);
@@ -63,7 +62,52 @@ __global__ void __launch_bounds__(BSX_BLOCK) small_obs_kernel(const typename Env
     if (t + 1 < n_steps) __syncthreads();                              // tile is rewritten next step
   }
   __syncthreads();
-  bsx_flush_counts(a.ctl, s_cnt);
+  bsx_flush_counts(a.ctl, s_cnt, block_id);
+}
+
+template <class Env, int LPB, bool ROLLOUT, int LOG, int NOISE>
+__global__ void __launch_bounds__(BSX_BLOCK) small_obs_kernel(const typename Env::args a, const int n_steps) {
+  extern __shared__ __attribute__((aligned(16))) float s_obs[];
+  __shared__ unsigned int s_cnt[2];
+  small_obs_body<Env, LPB, ROLLOUT, LOG, NOISE>(a, n_steps, blockIdx.x, s_obs, s_cnt);
+}
+
+// Grouped launch: every workgroup looks up its segment and runs the single-step body on that
+// segment's argument struct (device memory).
+template <class Env, int LPB>
+__global__ void __launch_bounds__(BSX_BLOCK) small_obs_group_kernel(const typename Env::args* __restrict__ table,
+                                                                    const int32_t* __restrict__ start, int n) {
+  extern __shared__ __attribute__((aligned(16))) float s_obs[];
+  __shared__ unsigned int s_cnt[2];
+  const int seg = bsx_group_find(start, n, (int)blockIdx.x);
+  small_obs_body<Env, LPB, false, -1, -1>(table[seg], 1, blockIdx.x - (uint32_t)start[seg], s_obs, s_cnt);
+}
+
+template <class Env>
+static int small_obs_group_launch(bsx_group* g, hipStream_t st) {
+  const dim3 grid((unsigned)g->total_blocks), block(BSX_BLOCK);
+  const typename Env::args* table = (const typename Env::args*)g->d_args;
+  if (g->klass == 256) small_obs_group_kernel<Env, 256><<<grid, block, g->lds_bytes, st>>>(table, g->d_start, g->n);
+  else small_obs_group_kernel<Env, 64><<<grid, block, g->lds_bytes, st>>>(table, g->d_start, g->n);
+  return (int)hipGetLastError();
+}
+
+// Records one segment of a small-observation family in a group.
+template <class Env>
+static int small_obs_group_put(bsx_group* g, int32_t family, int32_t index, const bsx_call_t* call,
+                               const typename Env::args& a, int numel) {
+  const int lpb = numel <= 32 ? 256 : 64;
+  int rc = bsx_group_check_set(g, family, index, call, sizeof(typename Env::args), 0, lpb);
+  if (rc != 0) return rc;
+  memcpy(&g->args[(size_t)index * sizeof(a)], &a, sizeof(a));
+  const uint64_t b = (uint64_t)(a.ctl.n_lanes + lpb - 1) / lpb;
+  if (b > 0x3FFFFFFFull) return BSX_EINVAL;
+  g->blocks[index] = (int32_t)b;
+  const size_t lds = (size_t)lpb * numel * 4;
+  if (lds > g->lds_bytes) g->lds_bytes = lds;
+  g->is_set[index] = 1;
+  g->launch = small_obs_group_launch<Env>;
+  return 0;
 }
 
 template <class Env>
@@ -117,19 +161,33 @@ struct bandit_env {
   }
 };
 
-extern "C" int bsx_bandit_step(const bsx_bandit_t* cfg, const bsx_call_t* call, const int32_t* action,
-                               int32_t* state, bsx_timestep_t out, double* info) {
+static int bandit_make(const bsx_bandit_t* cfg, const bsx_call_t* call, const int32_t* action, int32_t* state, bsx_timestep_t out, double* info, bandit_env::args* a) {
   if (cfg == nullptr) return BSX_ENULL;
   int rc = bsx_check_call(call, action, out);
   if (rc != 0) return rc;
   if (cfg->num_actions < 1 || cfg->num_actions > BSX_BANDIT_MAX_ACTIONS) return BSX_ERANGE;
-  if (call->n_lanes == 0) return 0;
-  if (state == nullptr || info == nullptr) return BSX_ENULL;
+  if (call->n_lanes > 0 && (state == nullptr || info == nullptr)) return BSX_ENULL;
+  a->ctl = bsx_make_ctl(call); a->action = action; a->state = state; a->out = out; a->info = info;
+  a->obs_numel = 1; a->num_actions = cfg->num_actions;
+  for (int k = 0; k < BSX_BANDIT_MAX_ACTIONS; ++k) a->rewards[k] = cfg->rewards[k];
+  return 0;
+}
+
+extern "C" int bsx_bandit_step(const bsx_bandit_t* cfg, const bsx_call_t* call, const int32_t* action, int32_t* state, bsx_timestep_t out, double* info) {
   bandit_env::args a;
-  a.ctl = bsx_make_ctl(call); a.action = action; a.state = state; a.out = out; a.info = info;
-  a.obs_numel = 1; a.num_actions = cfg->num_actions;
-  for (int k = 0; k < BSX_BANDIT_MAX_ACTIONS; ++k) a.rewards[k] = cfg->rewards[k];
+  int rc = bandit_make(cfg, call, action, state, out, info, &a);
+  if (rc != 0) return rc;
+  if (call->n_lanes == 0) return 0;
   return launch_small_obs<bandit_env>(a, 1, bsx_n_steps(call), call->hip_stream);
+}
+
+extern "C" int bsx_group_set_bandit(bsx_group_t* g, int32_t index, const bsx_bandit_t* cfg, const bsx_call_t* call,
+                                     const int32_t* action, int32_t* state, bsx_timestep_t out, double* info) {
+  if (g == nullptr) return BSX_ENULL;
+  bandit_env::args a;
+  int rc = bandit_make(cfg, call, action, state, out, info, &a);
+  if (rc != 0) return rc;
+  return small_obs_group_put<bandit_env>(g, BSX_FAM_BANDIT, index, call, a, 1);
 }
 
 // ------------------------------------------------------------------------------ memory_chain
@@ -174,20 +232,33 @@ struct memory_chain_env {
   }
 };
 
-extern "C" int bsx_memory_chain_step(const bsx_memory_chain_t* cfg, const bsx_call_t* call,
-                                     const int32_t* action, int32_t* state, uint64_t* context,
-                                     bsx_timestep_t out, double* info) {
+static int memory_chain_make(const bsx_memory_chain_t* cfg, const bsx_call_t* call, const int32_t* action, int32_t* state, uint64_t* context, bsx_timestep_t out, double* info, memory_chain_env::args* a) {
   if (cfg == nullptr) return BSX_ENULL;
   int rc = bsx_check_call(call, action, out);
   if (rc != 0) return rc;
   if (cfg->memory_length < 1 || cfg->memory_length > 1000000 || cfg->num_bits < 1 || cfg->num_bits > 62)
     return BSX_ERANGE;
-  if (call->n_lanes == 0) return 0;
-  if (state == nullptr || context == nullptr || info == nullptr) return BSX_ENULL;
+  if (call->n_lanes > 0 && (state == nullptr || context == nullptr || info == nullptr)) return BSX_ENULL;
+  a->ctl = bsx_make_ctl(call); a->action = action; a->state = state; a->context = context; a->out = out;
+  a->info = info; a->obs_numel = cfg->num_bits + 2; a->L = cfg->memory_length; a->nb = cfg->num_bits;
+  return 0;
+}
+
+extern "C" int bsx_memory_chain_step(const bsx_memory_chain_t* cfg, const bsx_call_t* call, const int32_t* action, int32_t* state, uint64_t* context, bsx_timestep_t out, double* info) {
   memory_chain_env::args a;
-  a.ctl = bsx_make_ctl(call); a.action = action; a.state = state; a.context = context; a.out = out;
-  a.info = info; a.obs_numel = cfg->num_bits + 2; a.L = cfg->memory_length; a.nb = cfg->num_bits;
+  int rc = memory_chain_make(cfg, call, action, state, context, out, info, &a);
+  if (rc != 0) return rc;
+  if (call->n_lanes == 0) return 0;
   return launch_small_obs<memory_chain_env>(a, a.obs_numel, bsx_n_steps(call), call->hip_stream);
+}
+
+extern "C" int bsx_group_set_memory_chain(bsx_group_t* g, int32_t index, const bsx_memory_chain_t* cfg, const bsx_call_t* call,
+                                     const int32_t* action, int32_t* state, uint64_t* context, bsx_timestep_t out, double* info) {
+  if (g == nullptr) return BSX_ENULL;
+  memory_chain_env::args a;
+  int rc = memory_chain_make(cfg, call, action, state, context, out, info, &a);
+  if (rc != 0) return rc;
+  return small_obs_group_put<memory_chain_env>(g, BSX_FAM_MEMORY_CHAIN, index, call, a, a.obs_numel);
 }
 
 // ------------------------------------------------------------------------------ umbrella_chain
@@ -239,20 +310,33 @@ struct umbrella_chain_env {
   }
 };
 
-extern "C" int bsx_umbrella_chain_step(const bsx_umbrella_chain_t* cfg, const bsx_call_t* call,
-                                       const int32_t* action, int32_t* state, bsx_timestep_t out,
-                                       double* info) {
+static int umbrella_chain_make(const bsx_umbrella_chain_t* cfg, const bsx_call_t* call, const int32_t* action, int32_t* state, bsx_timestep_t out, double* info, umbrella_chain_env::args* a) {
   if (cfg == nullptr) return BSX_ENULL;
   int rc = bsx_check_call(call, action, out);
   if (rc != 0) return rc;
   if (cfg->chain_length < 1 || cfg->chain_length > 1000000 || cfg->n_distractor < 0 || cfg->n_distractor > 253)
     return BSX_ERANGE;
-  if (call->n_lanes == 0) return 0;
-  if (state == nullptr || info == nullptr) return BSX_ENULL;
+  if (call->n_lanes > 0 && (state == nullptr || info == nullptr)) return BSX_ENULL;
+  a->ctl = bsx_make_ctl(call); a->action = action; a->state = state; a->out = out; a->info = info;
+  a->obs_numel = 3 + cfg->n_distractor; a->L = cfg->chain_length; a->nd = cfg->n_distractor;
+  return 0;
+}
+
+extern "C" int bsx_umbrella_chain_step(const bsx_umbrella_chain_t* cfg, const bsx_call_t* call, const int32_t* action, int32_t* state, bsx_timestep_t out, double* info) {
   umbrella_chain_env::args a;
-  a.ctl = bsx_make_ctl(call); a.action = action; a.state = state; a.out = out; a.info = info;
-  a.obs_numel = 3 + cfg->n_distractor; a.L = cfg->chain_length; a.nd = cfg->n_distractor;
+  int rc = umbrella_chain_make(cfg, call, action, state, out, info, &a);
+  if (rc != 0) return rc;
+  if (call->n_lanes == 0) return 0;
   return launch_small_obs<umbrella_chain_env>(a, a.obs_numel, bsx_n_steps(call), call->hip_stream);
+}
+
+extern "C" int bsx_group_set_umbrella_chain(bsx_group_t* g, int32_t index, const bsx_umbrella_chain_t* cfg, const bsx_call_t* call,
+                                     const int32_t* action, int32_t* state, bsx_timestep_t out, double* info) {
+  if (g == nullptr) return BSX_ENULL;
+  umbrella_chain_env::args a;
+  int rc = umbrella_chain_make(cfg, call, action, state, out, info, &a);
+  if (rc != 0) return rc;
+  return small_obs_group_put<umbrella_chain_env>(g, BSX_FAM_UMBRELLA_CHAIN, index, call, a, a.obs_numel);
 }
 
 // ------------------------------------------------------------------------------ discounting_chain
@@ -287,18 +371,32 @@ struct discounting_chain_env {
   }
 };
 
-extern "C" int bsx_discounting_chain_step(const bsx_discounting_chain_t* cfg, const bsx_call_t* call,
-                                          const int32_t* action, int32_t* state, bsx_timestep_t out) {
+static int discounting_chain_make(const bsx_discounting_chain_t* cfg, const bsx_call_t* call, const int32_t* action, int32_t* state, bsx_timestep_t out, discounting_chain_env::args* a) {
   if (cfg == nullptr) return BSX_ENULL;
   int rc = bsx_check_call(call, action, out);
   if (rc != 0) return rc;
   if (cfg->bonus_chain < 0 || cfg->bonus_chain > 4) return BSX_ERANGE;
-  if (call->n_lanes == 0) return 0;
-  if (state == nullptr) return BSX_ENULL;
+  if (call->n_lanes > 0 && state == nullptr) return BSX_ENULL;
+  a->ctl = bsx_make_ctl(call); a->action = action; a->state = state; a->out = out;
+  a->obs_numel = 2; a->bonus = cfg->bonus_chain;
+  return 0;
+}
+
+extern "C" int bsx_discounting_chain_step(const bsx_discounting_chain_t* cfg, const bsx_call_t* call, const int32_t* action, int32_t* state, bsx_timestep_t out) {
   discounting_chain_env::args a;
-  a.ctl = bsx_make_ctl(call); a.action = action; a.state = state; a.out = out;
-  a.obs_numel = 2; a.bonus = cfg->bonus_chain;
+  int rc = discounting_chain_make(cfg, call, action, state, out, &a);
+  if (rc != 0) return rc;
+  if (call->n_lanes == 0) return 0;
   return launch_small_obs<discounting_chain_env>(a, 2, bsx_n_steps(call), call->hip_stream);
+}
+
+extern "C" int bsx_group_set_discounting_chain(bsx_group_t* g, int32_t index, const bsx_discounting_chain_t* cfg, const bsx_call_t* call,
+                                     const int32_t* action, int32_t* state, bsx_timestep_t out) {
+  if (g == nullptr) return BSX_ENULL;
+  discounting_chain_env::args a;
+  int rc = discounting_chain_make(cfg, call, action, state, out, &a);
+  if (rc != 0) return rc;
+  return small_obs_group_put<discounting_chain_env>(g, BSX_FAM_DISCOUNTING_CHAIN, index, call, a, 2);
 }
 
 // ------------------------------------------------------------------------------ cartpole / swingup
@@ -389,18 +487,33 @@ struct cartpole_env {
   }
 };
 
-extern "C" int bsx_cartpole_step(const bsx_cartpole_t* cfg, const bsx_call_t* call, const int32_t* action,
-                                 float* state, int32_t* steps, bsx_timestep_t out, double* info) {
+static int cartpole_make(const bsx_cartpole_t* cfg, const bsx_call_t* call, const int32_t* action, float* state, int32_t* steps, bsx_timestep_t out, double* info, cartpole_env::args* a) {
   if (cfg == nullptr) return BSX_ENULL;
   int rc = bsx_check_call(call, action, out);
   if (rc != 0) return rc;
   if (cfg->last_step < 1 || cfg->last_step >= (1 << 30)) return BSX_ERANGE;
-  if (call->n_lanes == 0) return 0;
-  if (state == nullptr || steps == nullptr || info == nullptr || cfg->time_frac == nullptr) return BSX_ENULL;
+  if (call->n_lanes > 0 && (state == nullptr || steps == nullptr || info == nullptr || cfg->time_frac == nullptr))
+    return BSX_ENULL;
+  a->ctl = bsx_make_ctl(call); a->action = action; a->state = state; a->steps = steps; a->out = out;
+  a->info = info; a->obs_numel = cfg->swingup ? 8 : 6; a->cfg = *cfg;
+  return 0;
+}
+
+extern "C" int bsx_cartpole_step(const bsx_cartpole_t* cfg, const bsx_call_t* call, const int32_t* action, float* state, int32_t* steps, bsx_timestep_t out, double* info) {
   cartpole_env::args a;
-  a.ctl = bsx_make_ctl(call); a.action = action; a.state = state; a.steps = steps; a.out = out;
-  a.info = info; a.obs_numel = cfg->swingup ? 8 : 6; a.cfg = *cfg;
+  int rc = cartpole_make(cfg, call, action, state, steps, out, info, &a);
+  if (rc != 0) return rc;
+  if (call->n_lanes == 0) return 0;
   return launch_small_obs<cartpole_env>(a, a.obs_numel, bsx_n_steps(call), call->hip_stream);
+}
+
+extern "C" int bsx_group_set_cartpole(bsx_group_t* g, int32_t index, const bsx_cartpole_t* cfg, const bsx_call_t* call,
+                                     const int32_t* action, float* state, int32_t* steps, bsx_timestep_t out, double* info) {
+  if (g == nullptr) return BSX_ENULL;
+  cartpole_env::args a;
+  int rc = cartpole_make(cfg, call, action, state, steps, out, info, &a);
+  if (rc != 0) return rc;
+  return small_obs_group_put<cartpole_env>(g, BSX_FAM_CARTPOLE, index, call, a, a.obs_numel);
 }
 
 // ------------------------------------------------------------------------------ mountain_car
@@ -445,17 +558,30 @@ struct mountain_car_env {
   }
 };
 
-extern "C" int bsx_mountain_car_step(const bsx_mountain_car_t* cfg, const bsx_call_t* call,
-                                     const int32_t* action, float* state, int32_t* steps,
-                                     bsx_timestep_t out, double* info) {
+static int mountain_car_make(const bsx_mountain_car_t* cfg, const bsx_call_t* call, const int32_t* action, float* state, int32_t* steps, bsx_timestep_t out, double* info, mountain_car_env::args* a) {
   if (cfg == nullptr) return BSX_ENULL;
   int rc = bsx_check_call(call, action, out);
   if (rc != 0) return rc;
   if (cfg->max_steps < 1 || cfg->max_steps >= (1 << 30)) return BSX_ERANGE;
-  if (call->n_lanes == 0) return 0;
-  if (state == nullptr || steps == nullptr || info == nullptr) return BSX_ENULL;
+  if (call->n_lanes > 0 && (state == nullptr || steps == nullptr || info == nullptr)) return BSX_ENULL;
+  a->ctl = bsx_make_ctl(call); a->action = action; a->state = state; a->steps = steps; a->out = out;
+  a->info = info; a->obs_numel = 3; a->max_steps = cfg->max_steps;
+  return 0;
+}
+
+extern "C" int bsx_mountain_car_step(const bsx_mountain_car_t* cfg, const bsx_call_t* call, const int32_t* action, float* state, int32_t* steps, bsx_timestep_t out, double* info) {
   mountain_car_env::args a;
-  a.ctl = bsx_make_ctl(call); a.action = action; a.state = state; a.steps = steps; a.out = out;
-  a.info = info; a.obs_numel = 3; a.max_steps = cfg->max_steps;
+  int rc = mountain_car_make(cfg, call, action, state, steps, out, info, &a);
+  if (rc != 0) return rc;
+  if (call->n_lanes == 0) return 0;
   return launch_small_obs<mountain_car_env>(a, 3, bsx_n_steps(call), call->hip_stream);
+}
+
+extern "C" int bsx_group_set_mountain_car(bsx_group_t* g, int32_t index, const bsx_mountain_car_t* cfg, const bsx_call_t* call,
+                                     const int32_t* action, float* state, int32_t* steps, bsx_timestep_t out, double* info) {
+  if (g == nullptr) return BSX_ENULL;
+  mountain_car_env::args a;
+  int rc = mountain_car_make(cfg, call, action, state, steps, out, info, &a);
+  if (rc != 0) return rc;
+  return small_obs_group_put<mountain_car_env>(g, BSX_FAM_MOUNTAIN_CAR, index, call, a, 3);
 }

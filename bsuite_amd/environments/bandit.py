@@ -35,9 +35,10 @@ class SimpleBandit(base.Environment):
   def _state_tensors(self):
     return dict(state=torch.ones(self._batch, dtype=torch.int32, device=self._device))
 
-  def _launch(self, call, action_ptr, out):
-    return _native.lib.bsx_bandit_step(ctypes.byref(self._cfg), ctypes.byref(call), action_ptr,
-                                       self._state['state'].data_ptr(), out, self._info.data_ptr())
+  _abi_name = 'bandit'
+
+  def _native_args(self, call, action_ptr, out):
+    return (ctypes.byref(self._cfg), ctypes.byref(call), action_ptr, self._state['state'].data_ptr(), out, self._info.data_ptr())
 
   def _check_scalar_action(self, action):
     self._rewards[action]  # IndexError where bandit.py:61 raises it  pylint: disable=pointless-statement

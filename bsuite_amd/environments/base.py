@@ -125,9 +125,31 @@ class Environment(dm_env.EnvironmentBase):
     """Subclass hook: allocate the family's SoA state columns with their initial values."""
     raise NotImplementedError
 
-  def _launch(self, call, action_ptr, out) -> int:
-    """Subclass hook: call the family's C-ABI entry point."""
+  _abi_name = None   # subclass: family name in the C ABI (bsx_<name>_step / bsx_group_set_<name>)
+
+  def _native_args(self, call, action_ptr, out):
+    """Subclass hook: the argument tuple of bsx_<family>_step for this environment."""
     raise NotImplementedError
+
+  def _launch(self, call, action_ptr, out) -> int:
+    """Calls the family's C-ABI entry point."""
+    return getattr(_native.lib, f'bsx_{self._abi_name}_step')(*self._native_args(call, action_ptr, out))
+
+  def _group_set(self, group, index: int, action: torch.Tensor) -> int:
+    """Records this environment as segment `index` of a grouped launch (bsx_group_set_<family>):
+    static arguments — `action` is read in place every group step, outputs go to buffer 0, the call
+    index comes from the (shared) device step counter."""
+    self._ensure_allocated()
+    if not self._device_step_counter:
+      raise ValueError('grouped launches need device_step_counter / shared_step_counter')
+    call = self._call_desc
+    call.force_reset, call.n_steps = 0, 0
+    kind, param, wseed = self._wrap
+    call.wrap.kind, call.wrap.param, call.wrap.seed = kind, param, wseed
+    call.stream.step_index = 0
+    self._buf = 1 % self._num_buffers
+    return getattr(_native.lib, f'bsx_group_set_{self._abi_name}')(
+        group, index, *self._native_args(call, action.data_ptr(), self._out_ptrs[0]))
 
   def _mt_constructor_draws(self, rs: np.random.RandomState):
     """Subclass hook (rng='mt19937'): consume from `rs` exactly what the reference constructor

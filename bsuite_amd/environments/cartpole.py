@@ -70,10 +70,10 @@ class _CartpoleBase(base.Environment):
     return dict(state=torch.zeros((4, self._batch), dtype=torch.float32, device=self._device),
                 steps=torch.full((self._batch,), 1 << 30, dtype=torch.int32, device=self._device))
 
-  def _launch(self, call, action_ptr, out):
-    return _native.lib.bsx_cartpole_step(
-        ctypes.byref(self._cfg), ctypes.byref(call), action_ptr, self._state['state'].data_ptr(),
-        self._state['steps'].data_ptr(), out, self._info.data_ptr())
+  _abi_name = 'cartpole'
+
+  def _native_args(self, call, action_ptr, out):
+    return (ctypes.byref(self._cfg), ctypes.byref(call), action_ptr, self._state['state'].data_ptr(), self._state['steps'].data_ptr(), out, self._info.data_ptr())
 
   def action_spec(self):
     return specs.DiscreteArray(dtype=int, num_values=3, name='action')

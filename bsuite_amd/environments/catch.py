@@ -31,9 +31,10 @@ class Catch(base.Environment):
   def _state_tensors(self):
     return dict(state=torch.full((self._batch,), 1 << 24, dtype=torch.int32, device=self._device))
 
-  def _launch(self, call, action_ptr, out):
-    return _native.lib.bsx_catch_step(ctypes.byref(self._cfg), ctypes.byref(call), action_ptr,
-                                      self._state['state'].data_ptr(), out, self._info.data_ptr())
+  _abi_name = 'catch'
+
+  def _native_args(self, call, action_ptr, out):
+    return (ctypes.byref(self._cfg), ctypes.byref(call), action_ptr, self._state['state'].data_ptr(), out, self._info.data_ptr())
 
   def _check_scalar_action(self, action):
     _ACTIONS[action]  # IndexError exactly where catch.py:84 raises it  pylint: disable=pointless-statement

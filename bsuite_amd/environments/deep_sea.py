@@ -69,10 +69,10 @@ class DeepSea(base.Environment):
   def _state_tensors(self):
     return dict(state=torch.full((self._batch,), 1 << 17, dtype=torch.int32, device=self._device))
 
-  def _launch(self, call, action_ptr, out):
-    return _native.lib.bsx_deep_sea_step(ctypes.byref(self._cfg), ctypes.byref(call), action_ptr,
-                                         self._state['state'].data_ptr(), out,
-                                         self._info.data_ptr())
+  _abi_name = 'deep_sea'
+
+  def _native_args(self, call, action_ptr, out):
+    return (ctypes.byref(self._cfg), ctypes.byref(call), action_ptr, self._state['state'].data_ptr(), out, self._info.data_ptr())
 
   @property
   def optimal_return(self):

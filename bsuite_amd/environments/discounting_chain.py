@@ -31,10 +31,10 @@ class DiscountingChain(base.Environment):
   def _state_tensors(self):
     return dict(state=torch.full((self._batch,), 1 << 12, dtype=torch.int32, device=self._device))
 
-  def _launch(self, call, action_ptr, out):
-    return _native.lib.bsx_discounting_chain_step(
-        ctypes.byref(self._cfg), ctypes.byref(call), action_ptr, self._state['state'].data_ptr(),
-        out)
+  _abi_name = 'discounting_chain'
+
+  def _native_args(self, call, action_ptr, out):
+    return (ctypes.byref(self._cfg), ctypes.byref(call), action_ptr, self._state['state'].data_ptr(), out)
 
   @property
   def optimal_return(self):

@@ -32,7 +32,7 @@ class MemoryChain(base.Environment):
     return dict(state=torch.full((self._batch,), 1 << 28, dtype=torch.int32, device=self._device),
                 context=torch.zeros(self._batch, dtype=torch.int64, device=self._device))
 
-  def _launch(self, call, action_ptr, out):
-    return _native.lib.bsx_memory_chain_step(
-        ctypes.byref(self._cfg), ctypes.byref(call), action_ptr, self._state['state'].data_ptr(),
-        self._state['context'].data_ptr(), out, self._info.data_ptr())
+  _abi_name = 'memory_chain'
+
+  def _native_args(self, call, action_ptr, out):
+    return (ctypes.byref(self._cfg), ctypes.byref(call), action_ptr, self._state['state'].data_ptr(), self._state['context'].data_ptr(), out, self._info.data_ptr())

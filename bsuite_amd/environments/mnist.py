@@ -56,6 +56,7 @@ class MNISTBandit(base.Environment):
     self._cfg.labels = self._labels_dev.data_ptr()
     return dict(state=torch.full((self._batch,), 1 << 28, dtype=torch.int32, device=self._device))
 
-  def _launch(self, call, action_ptr, out):
-    return _native.lib.bsx_mnist_step(ctypes.byref(self._cfg), ctypes.byref(call), action_ptr,
-                                      self._state['state'].data_ptr(), out, self._info.data_ptr())
+  _abi_name = 'mnist'
+
+  def _native_args(self, call, action_ptr, out):
+    return (ctypes.byref(self._cfg), ctypes.byref(call), action_ptr, self._state['state'].data_ptr(), out, self._info.data_ptr())

@@ -27,7 +27,7 @@ class MountainCar(base.Environment):
     return dict(state=torch.zeros((2, self._batch), dtype=torch.float32, device=self._device),
                 steps=torch.full((self._batch,), 1 << 30, dtype=torch.int32, device=self._device))
 
-  def _launch(self, call, action_ptr, out):
-    return _native.lib.bsx_mountain_car_step(
-        ctypes.byref(self._cfg), ctypes.byref(call), action_ptr, self._state['state'].data_ptr(),
-        self._state['steps'].data_ptr(), out, self._info.data_ptr())
+  _abi_name = 'mountain_car'
+
+  def _native_args(self, call, action_ptr, out):
+    return (ctypes.byref(self._cfg), ctypes.byref(call), action_ptr, self._state['state'].data_ptr(), self._state['steps'].data_ptr(), out, self._info.data_ptr())

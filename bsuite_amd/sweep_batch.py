@@ -8,10 +8,13 @@ independent, so:
 * across GPUs — whole segments are bin-packed onto ranks by `lanes x bytes-per-step` (longest
   processing time first); no communication per step; summaries are all-gathered at the end
   (`bsuite_amd.distributed`);
-* on one GPU — segment launches are spread round-robin over a few HIP streams and the whole sweep
-  step (several hundred small launches) is captured once into a HIP graph and replayed, so the host
-  issues one graph launch per sweep step instead of ~10^3 kernel launches.  Call indices of the
-  draw stream live in device memory (`device_step_counter=True`) so replays stay reproducible.
+* on one GPU — **grouped launches** (`prepare_groups` / `step_grouped`): all segments of one family
+  are advanced by ONE kernel launch (pair); every workgroup finds its segment's arguments —
+  configuration, state columns, output buffers, exactly what `bsx_<family>_step` takes — in a
+  device-resident table (include/bsuite_amd.h `bsx_group_*`).  A sweep step is then ~15 launches
+  instead of ~10^3.  The older path (`capture` / `replay`) spreads per-segment launches over HIP
+  streams and replays them as one HIP graph.  Either way call indices of the draw stream live in
+  one device-resident counter bumped once per sweep step, so steps stay reproducible.
 
 Global lane ids are unique across the sweep (segment k starts where segment k-1 ended), so any
 assignment of segments to ranks reproduces the same per-lane trajectories.
@@ -93,6 +96,7 @@ class SweepBatch:
     self.num_streams = max(1, int(num_streams))
     self._graph = None
     self._streams = None
+    self._groups = []
 
   # ---------------------------------------------------------------------------------------
   def random_actions(self, seed: int = 0) -> List[torch.Tensor]:
@@ -114,6 +118,66 @@ class SweepBatch:
     outs = [env.step(a) for env, a in zip(self.envs, actions)]
     self._bump()
     return outs
+
+  # -- grouped launches --------------------------------------------------------------------
+  def prepare_groups(self, actions: Sequence[torch.Tensor]):
+    """Builds one launch group per (family, launch class): records every local segment with its
+    static `actions` tensor and uploads the argument tables.  Returns the per-segment output
+    TimeSteps (tensors that every `step_grouped()` overwrites)."""
+    import ctypes  # pylint: disable=import-outside-toplevel
+    from bsuite_amd import _native  # pylint: disable=import-outside-toplevel
+    from bsuite_amd import dm_env_compat as dm_env  # pylint: disable=import-outside-toplevel
+    self.release_groups()
+    buckets = {}
+    for k, env in enumerate(self.envs):
+      raw = env.raw_env if hasattr(env, 'raw_env') else env
+      raw._ensure_allocated()  # pylint: disable=protected-access
+      numel = int(np.prod(raw.observation_spec().shape))
+      small = raw._abi_name not in ('deep_sea', 'catch', 'mnist')  # pylint: disable=protected-access
+      klass = (256 if numel <= 32 else 64) if small else 0
+      buckets.setdefault((raw._abi_name, klass), []).append(k)  # pylint: disable=protected-access
+    outs = [None] * len(self.envs)
+    for (name, _), members in sorted(buckets.items()):
+      handle = ctypes.c_void_p()
+      _native.check(_native.lib.bsx_group_create(_native.FAMILY_IDS[name], len(members), ctypes.byref(handle)),
+                    'bsx_group_create')
+      self._groups.append(handle)
+      for idx, k in enumerate(members):
+        raw = self.envs[k].raw_env if hasattr(self.envs[k], 'raw_env') else self.envs[k]
+        _native.check(raw._group_set(handle, idx, actions[k]), f'bsx_group_set_{name}')  # pylint: disable=protected-access
+        o = raw._out[0]  # pylint: disable=protected-access
+        outs[k] = dm_env.TimeStep(step_type=o['step_type'], reward=o['reward'], discount=o['discount'],
+                                  observation=o['observation'])
+      _native.check(_native.lib.bsx_group_commit(handle), 'bsx_group_commit')
+    self._group_actions = list(actions)      # keep the static action tensors alive
+    self._group_outs = outs
+    return outs
+
+  def step_grouped(self):
+    """One sweep step = one grouped launch per (family, class) + one call-counter bump."""
+    from bsuite_amd import _native  # pylint: disable=import-outside-toplevel
+    stream = torch.cuda.current_stream(self.device).cuda_stream
+    for handle in self._groups:
+      rc = _native.lib.bsx_group_step(handle, stream)
+      if rc != 0:
+        _native.check(rc, 'bsx_group_step')
+    self._bump()
+    for env in self.envs:                      # host-side bookkeeping of the call index
+      raw = env.raw_env if hasattr(env, 'raw_env') else env
+      raw._step_index += 1  # pylint: disable=protected-access
+    return self._group_outs
+
+  def release_groups(self):
+    from bsuite_amd import _native  # pylint: disable=import-outside-toplevel
+    for handle in self._groups:
+      _native.lib.bsx_group_destroy(handle)
+    self._groups = []
+
+  def __del__(self):
+    try:
+      self.release_groups()
+    except Exception:  # pylint: disable=broad-except
+      pass
 
   def capture(self, actions: Sequence[torch.Tensor]):
     """Captures one sweep step reading `actions` (static tensors) into a HIP graph."""

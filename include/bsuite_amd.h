@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define BSX_ABI_VERSION 4
+#define BSX_ABI_VERSION 5
 
 #define BSX_FIRST 0
 #define BSX_MID 1
@@ -247,6 +247,55 @@ typedef struct {
  * info : double [1,B] = total_regret; obs float [B, rows, cols] */
 int bsx_mnist_step(const bsx_mnist_t* cfg, const bsx_call_t* call, const int32_t* action,
                    int32_t* state, bsx_timestep_t out, double* info);
+
+/* ---- grouped launch: many independent segments of ONE family in one kernel launch -------------
+ * BASELINE config 5 (the whole sweep as lane segments) issues ~10^3 tiny launches per sweep step
+ * when every bsuite_id is stepped on its own; a group turns that into one launch (pair) per family.
+ * Every segment keeps its own configuration, state columns and output buffers — exactly the
+ * arguments of its `bsx_<family>_step` — recorded once with `bsx_group_set_<family>`; workgroups
+ * find their segment through a block-offset table in device memory ("grouped GEMM" style).
+ * Because the recorded arguments are static, each segment's call index must come from a
+ * device-resident counter (`stream.step_base != NULL`, bumped by the caller once per group step
+ * with bsx_counter_add); `force_reset` and `n_steps > 1` are not available in a group.
+ * create / commit / destroy allocate device memory and synchronise (setup time only);
+ * bsx_group_step is asynchronous and capturable like every other entry point. */
+typedef struct bsx_group bsx_group_t;
+#define BSX_FAM_DEEP_SEA 0
+#define BSX_FAM_CATCH 1
+#define BSX_FAM_BANDIT 2
+#define BSX_FAM_MEMORY_CHAIN 3
+#define BSX_FAM_UMBRELLA_CHAIN 4
+#define BSX_FAM_DISCOUNTING_CHAIN 5
+#define BSX_FAM_CARTPOLE 6
+#define BSX_FAM_MOUNTAIN_CAR 7
+#define BSX_FAM_MNIST 8
+int bsx_group_create(int32_t family, int32_t n_segments, bsx_group_t** group);
+int bsx_group_set_deep_sea(bsx_group_t* g, int32_t index, const bsx_deep_sea_t* cfg, const bsx_call_t* call,
+                           const int32_t* action, int32_t* state, bsx_timestep_t out, double* info);
+int bsx_group_set_catch(bsx_group_t* g, int32_t index, const bsx_catch_t* cfg, const bsx_call_t* call,
+                        const int32_t* action, int32_t* state, bsx_timestep_t out, double* info);
+int bsx_group_set_bandit(bsx_group_t* g, int32_t index, const bsx_bandit_t* cfg, const bsx_call_t* call,
+                         const int32_t* action, int32_t* state, bsx_timestep_t out, double* info);
+int bsx_group_set_memory_chain(bsx_group_t* g, int32_t index, const bsx_memory_chain_t* cfg,
+                               const bsx_call_t* call, const int32_t* action, int32_t* state,
+                               uint64_t* context, bsx_timestep_t out, double* info);
+int bsx_group_set_umbrella_chain(bsx_group_t* g, int32_t index, const bsx_umbrella_chain_t* cfg,
+                                 const bsx_call_t* call, const int32_t* action, int32_t* state,
+                                 bsx_timestep_t out, double* info);
+int bsx_group_set_discounting_chain(bsx_group_t* g, int32_t index, const bsx_discounting_chain_t* cfg,
+                                    const bsx_call_t* call, const int32_t* action, int32_t* state,
+                                    bsx_timestep_t out);
+int bsx_group_set_cartpole(bsx_group_t* g, int32_t index, const bsx_cartpole_t* cfg, const bsx_call_t* call,
+                           const int32_t* action, float* state, int32_t* steps, bsx_timestep_t out,
+                           double* info);
+int bsx_group_set_mountain_car(bsx_group_t* g, int32_t index, const bsx_mountain_car_t* cfg,
+                               const bsx_call_t* call, const int32_t* action, float* state, int32_t* steps,
+                               bsx_timestep_t out, double* info);
+int bsx_group_set_mnist(bsx_group_t* g, int32_t index, const bsx_mnist_t* cfg, const bsx_call_t* call,
+                        const int32_t* action, int32_t* state, bsx_timestep_t out, double* info);
+int bsx_group_commit(bsx_group_t* g);
+int bsx_group_step(bsx_group_t* g, void* hip_stream);
+int bsx_group_destroy(bsx_group_t* g);
 
 /* ---- misc ---------------------------------------------------------------------------------- */
 int bsx_abi_version(void);

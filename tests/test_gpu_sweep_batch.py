@@ -70,3 +70,37 @@ def test_sweep_rank_assignment_is_a_partition():
   ids_a = [s[0] for s in a.segments]
   ids_b = [s[0] for s in b.segments]
   assert sorted(ids_a + ids_b) == sorted(IDS[:8]) and not set(ids_a) & set(ids_b)
+
+
+@pytest.mark.gpu
+def test_grouped_sweep_equals_standalone_envs(tmp_path):
+  """One grouped launch per family advances every segment exactly like its standalone environment."""
+  from bsuite_amd.utils import datasets
+  imgs, labels = gu.mnist_dataset()
+  datasets.write_idx_files(str(tmp_path), imgs.view(np.uint8), labels)
+  mn = dict(data_dir=str(tmp_path))
+  kw = dict(mnist=mn, mnist_noise=mn, mnist_scale=mn)
+  ids = IDS + ['deep_sea/7', 'catch_noise/11', 'bandit_scale/3', 'umbrella_distract/3', 'memory_size/2',
+               'cartpole_swingup/1', 'discounting_chain/9', 'mountain_car_noise/5']
+  total, seed, reps = len(ids) * 257 + 3, 77, 23
+  batch = sb.SweepBatch(ids, total, seed=seed, env_kwargs=kw)
+  acts = batch.random_actions(seed=2)
+  outs = batch.prepare_groups(acts)
+  assert 9 <= len(batch._groups) <= 12           # families (+ wide-row classes), not segments
+  for _ in range(reps):
+    batch.step_grouped()
+  torch.cuda.synchronize()
+  for (bid, begin, lanes), a, out, env in zip(batch.segments, acts, outs, batch.envs):
+    name = bid.split('/')[0]
+    ekw = dict(kw.get(name, {}))
+    if sweep.SETTINGS[bid].get('seed', 0) is None or 'seed' not in sweep.SETTINGS[bid]:
+      ekw['seed'] = seed
+    ref = bsuite_amd.load_from_id(bid, batch=lanes, lane_offset=begin, num_buffers=1, **ekw)
+    for _ in range(reps):
+      ts = ref.step(a)
+    for x, y in zip(eu.to_np(out), eu.to_np(ts)):
+      np.testing.assert_array_equal(x, y, err_msg=bid)
+    for k, v in ref.bsuite_info().items():
+      torch.testing.assert_close(env.bsuite_info()[k], v, rtol=0, atol=0)
+    torch.testing.assert_close(eu.raw(env).episode_counters(), eu.raw(ref).episode_counters(), rtol=0, atol=0)
+  batch.release_groups()
