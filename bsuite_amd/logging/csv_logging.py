@@ -33,27 +33,26 @@ def wrap_environment(env, bsuite_id: str, results_dir: str, overwrite: bool = Fa
 
 
 class Logger(base.Logger):
-  """Saves data to a CSV file via Pandas; rewrites the whole file on each write, like the reference."""
+  """Row sink for `wrappers.Logging`: accumulates the rows of one bsuite_id and mirrors them to its
+  CSV file after every write (the reference does the same — writes are log-spaced, hence rare)."""
 
   def __init__(self, bsuite_id: str, results_dir: str = '/tmp/bsuite', overwrite: bool = False):
-    if not os.path.exists(results_dir):
-      try:
-        os.makedirs(results_dir)
-      except OSError:  # concurrent processes can makedir at same time
-        pass
-    save_path = csv_path(bsuite_id, results_dir)
-    if os.path.exists(save_path) and not overwrite:
-      raise ValueError(
-          f'File {save_path} already exists. Specify a different '
-          'directory, or set overwrite=True to overwrite existing data.')
-    self._data = []
-    self._save_path = save_path
+    os.makedirs(results_dir, exist_ok=True)          # tolerant of concurrent creators
+    target = csv_path(bsuite_id, results_dir)
+    if not overwrite and os.path.exists(target):
+      raise ValueError(f'File {target} already exists. Specify a different '
+                       'directory, or set overwrite=True to overwrite existing data.')
+    self._save_path = target
+    self._rows = []
+
+  @property
+  def save_path(self) -> str:
+    return self._save_path
 
   def write(self, data: Mapping[str, Any]):
-    """Adds a row to the internal list of data and saves to CSV."""
-    self._data.append(data)
-    df = pd.DataFrame(self._data)
-    df.to_csv(self._save_path, index=False)
+    """Appends one row and rewrites the CSV (column order = first-seen key order, like pandas)."""
+    self._rows.append(dict(data))
+    pd.DataFrame(self._rows).to_csv(self._save_path, index=False)
 
 
 def write_lane_csvs(logging_env: wrappers.Logging, bsuite_id: str, results_root: str, lanes,

@@ -37,10 +37,12 @@ def test_struct_layouts_match_header():
 #include <stddef.h>
 #include "bsuite_amd.h"
 int main(void) {
-  printf("%zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu\n", sizeof(bsx_stream_t), sizeof(bsx_reward_wrap_t),
+  printf("%zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu\n", sizeof(bsx_stream_t), sizeof(bsx_reward_wrap_t),
          sizeof(bsx_timestep_t), sizeof(bsx_call_t), sizeof(bsx_deep_sea_t), sizeof(bsx_catch_t),
          sizeof(bsx_bandit_t), sizeof(bsx_cartpole_t), offsetof(bsx_call_t, counters),
-         offsetof(bsx_cartpole_t, move_cost), offsetof(bsx_cartpole_t, time_frac));
+         offsetof(bsx_cartpole_t, move_cost), offsetof(bsx_cartpole_t, time_frac),
+         sizeof(bsx_logging_t), sizeof(bsx_mnist_t), offsetof(bsx_call_t, logging),
+         offsetof(bsx_stream_t, mt_pos), offsetof(bsx_logging_t, log_by_step));
   return 0;
 }'''
   import tempfile
@@ -55,7 +57,9 @@ int main(void) {
           ctypes.sizeof(_native.DeepSeaCfg), ctypes.sizeof(_native.CatchCfg),
           ctypes.sizeof(_native.BanditCfg), ctypes.sizeof(_native.CartpoleCfg),
           _native.Call.counters.offset, _native.CartpoleCfg.move_cost.offset,
-          _native.CartpoleCfg.time_frac.offset]
+          _native.CartpoleCfg.time_frac.offset,
+          ctypes.sizeof(_native.Logging), ctypes.sizeof(_native.MnistCfg), _native.Call.logging.offset,
+          _native.Stream.mt_pos.offset, _native.Logging.log_by_step.offset]
   assert got == want
 
 
