@@ -265,7 +265,7 @@ __device__ __forceinline__ void bsx_hot_stream_body(float* __restrict__ obs,
                                                     const int32_t* __restrict__ state,
                                                     int64_t n_lanes, uint32_t cells,
                                                     uint32_t cells_magic, bsx_div64 dv,
-                                                    const HotFn& fn, uint32_t block_id) {
+                                                    const HotFn& fn, uint32_t block_id, int wave_contig = 1) {
   const uint64_t total = (uint64_t)n_lanes * cells;                      // floats in the array
   const uint64_t F0 = (uint64_t)block_id * (uint64_t)(K * 4 * BS);
   const uint64_t lane_b = __umul64hi(F0, dv.m) >> dv.s;                  // uniform
@@ -281,7 +281,11 @@ __device__ __forceinline__ void bsx_hot_stream_body(float* __restrict__ obs,
   bool live[K];
 #pragma unroll
   for (int u = 0; u < K; ++u) {
-    const uint32_t c = threadIdx.x + u * BS;                      // chunk within the block
+    // chunk within the block: each wave owns K consecutive KiB (store u of wave w covers KiB
+    // w*K + u) — measured +3 % on deep_sea over the block-interleaved order u*BS + tid
+    // (profiles/r01/ab_stream_wave_contig.log)
+    const uint32_t c = wave_contig ? ((threadIdx.x >> 6) * (K * 64) + u * 64 + (threadIdx.x & 63))
+                                   : (threadIdx.x + u * BS);
     const uint32_t f = r_b + (c << 2);                                   // float offset from lane_b's row start
     dl[u] = __umulhi(f, cells_magic);
     r0[u] = (int)(f - dl[u] * cells);
@@ -309,7 +313,7 @@ __device__ __forceinline__ void bsx_hot_stream_body(float* __restrict__ obs,
       if (over <= 2) v.z = (a1 == 2 || b1 == 2) ? 1.0f : 0.0f;
       v.w = (a1 == 3 || b1 == 3) ? 1.0f : 0.0f;
     }
-    o4[threadIdx.x + u * BS] = v;
+    o4[wave_contig ? ((threadIdx.x >> 6) * (K * 64) + u * 64 + (threadIdx.x & 63)) : (threadIdx.x + u * BS)] = v;
   }
   // ragged tail (< 4 floats) of an odd-sized array: the block that contains the array's end
   const uint64_t tail0 = total & ~3ull;
@@ -331,8 +335,8 @@ __global__ void __launch_bounds__(BS) bsx_hot_stream_kernel(float* __restrict__ 
                                                                    const int32_t* __restrict__ state,
                                                                    int64_t n_lanes, uint32_t cells,
                                                                    uint32_t cells_magic, bsx_div64 dv,
-                                                                   HotFn fn) {
-  bsx_hot_stream_body<HotFn, K, BS>(obs, state, n_lanes, cells, cells_magic, dv, fn, blockIdx.x);
+                                                                   HotFn fn, int wave_contig) {
+  bsx_hot_stream_body<HotFn, K, BS>(obs, state, n_lanes, cells, cells_magic, dv, fn, blockIdx.x, wave_contig);
 }
 
 template <class HotFn, int K>
