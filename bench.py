@@ -53,13 +53,12 @@ def pmc_traffic(workload, lanes):
   return d['per_launch']['hbm_bytes'], os.path.relpath(hits[-1], ROOT)
 
 
-def cpu_baseline(family, kwargs, num_actions, budget_s=12.0):
-  """The oracle (C restatement of the reference's numpy step) on ONE host core, bounded sample."""
+def _oracle_loop(family, kwargs, num_actions, lanes, lane0, budget_s):
+  """Steps one OracleEnv (its own lanes) for budget_s seconds; returns (env-steps, seconds)."""
   import numpy as np
   from oracle import coracle
-  lanes = 4096
-  env = coracle.OracleEnv(family, kwargs, np.arange(lanes, dtype=np.uint64), seed=42)
-  rng = np.random.default_rng(0)
+  env = coracle.OracleEnv(family, kwargs, np.arange(lane0, lane0 + lanes, dtype=np.uint64), seed=42)
+  rng = np.random.default_rng(lane0)
   acts = rng.integers(0, num_actions, size=(64, lanes)).astype(np.int32)
   for t in range(8):
     env.call(acts[t % 64], t)
@@ -69,10 +68,32 @@ def cpu_baseline(family, kwargs, num_actions, budget_s=12.0):
     for _ in range(16):
       env.call(acts[n % 64], 8 + n)
       n += 1
-  dt = time.perf_counter() - t0
-  return dict(value=lanes * n / dt, unit='env-steps/s', cores=1, kind='port',
-              sample=f'{lanes} lanes x {n} step() calls of {family} {kwargs} through oracle/oracle.c '
-                     f'(gcc -O2, single thread, {dt:.1f} s)')
+  return lanes * n, time.perf_counter() - t0
+
+
+def cpu_baseline(family, kwargs, num_actions, budget_s=12.0, all_cores_budget_s=4.0):
+  """The oracle (C restatement of the reference's numpy step) on ONE host core, bounded sample; plus
+  the same loop on every host core at once (one OracleEnv per thread; the C call drops the GIL) —
+  the analogue of the reference's one-process-per-bsuite_id pool (bsuite/baselines/utils/pool.py:48)."""
+  import threading
+  lanes = 4096
+  steps, dt = _oracle_loop(family, kwargs, num_actions, lanes, 0, budget_s)
+  out = dict(value=steps / dt, unit='env-steps/s', cores=1, kind='port',
+             sample=f'{lanes} lanes x {steps // lanes} step() calls of {family} {kwargs} through '
+                    f'oracle/oracle.c (gcc -O2, single thread, {dt:.1f} s)')
+  cores = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
+  if cores > 1 and all_cores_budget_s > 0:
+    res = [None] * cores
+    def work(j):
+      res[j] = _oracle_loop(family, kwargs, num_actions, lanes, (j + 1) * lanes, all_cores_budget_s)
+    t0 = time.perf_counter()
+    ths = [threading.Thread(target=work, args=(j,)) for j in range(cores)]
+    for th in ths: th.start()
+    for th in ths: th.join()
+    wall = time.perf_counter() - t0
+    out['all_cores'] = dict(value=sum(r[0] for r in res) / max(r[1] for r in res), cores=cores,
+                            sample=f'{cores} threads x {lanes} lanes, {wall:.1f} s wall')
+  return out
 
 
 def bench_sweep(args, torch, dist, dev, rank, world):
