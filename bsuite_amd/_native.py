@@ -12,6 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 SO_PATH = os.path.join(_HERE, '_lib', 'libbsuite_amd.so')
 
 FIRST, MID, LAST = 0, 1, 2
+BSX_EINVAL, BSX_ENULL, BSX_EALIGN, BSX_ERANGE, BSX_EMODE = -1, -2, -3, -4, -5
 WRAP_NONE, WRAP_SCALE, WRAP_NOISE = 0, 1, 2
 COUNTER_SHARDS, COUNTER_STRIDE = 256, 16
 DEEP_SEA_MAX_SIZE = 64
@@ -122,6 +123,14 @@ class MountainCarCfg(ctypes.Structure):
   _fields_ = [('max_steps', ctypes.c_int32), ('_pad', ctypes.c_int32)]
 
 
+IMAGE_SMALL, IMAGE_BILINEAR = 0, 1
+
+
+class ImageCfg(ctypes.Structure):
+  _fields_ = [('mode', ctypes.c_int32), ('in_rows', ctypes.c_int32), ('in_cols', ctypes.c_int32),
+              ('out_rows', ctypes.c_int32), ('out_cols', ctypes.c_int32), ('tail', ctypes.c_int32)]
+
+
 lib = _load()
 
 _P = ctypes.c_void_p
@@ -130,6 +139,7 @@ _SIGS = {
     'bsx_strerror': ([ctypes.c_int], ctypes.c_char_p),
     'bsx_calib_fill': ([_P, ctypes.c_int64, ctypes.c_int32, _P], ctypes.c_int),
     'bsx_counter_add': ([_P, ctypes.c_uint64, _P], ctypes.c_int),
+    'bsx_image_observation': ([ctypes.POINTER(ImageCfg), ctypes.c_int64, _P, _P, _P], ctypes.c_int),
     'bsx_stream_dump': ([ctypes.c_uint64, ctypes.c_uint64, ctypes.c_int64, ctypes.c_uint64,
                          ctypes.c_int32, ctypes.c_int32, _P, _P, _P], ctypes.c_int),
     'bsx_deep_sea_step': ([ctypes.POINTER(DeepSeaCfg), ctypes.POINTER(Call), _P, _P, TimeStepPtrs, _P],
@@ -176,7 +186,7 @@ for _name, (_args, _res) in _SIGS.items():
   _fn.restype = _res
 if MISSING:
   raise NativeLibraryError(f'{SO_PATH} does not export {MISSING}; rebuild with `python -m bsuite_amd.build --force`')
-ABI_VERSION = 5
+ABI_VERSION = 6
 if lib.bsx_abi_version() != ABI_VERSION:
   raise NativeLibraryError('ABI version mismatch between bsuite_amd/_native.py and libbsuite_amd.so')
 

@@ -12,11 +12,15 @@ un-perturbed (wrappers.py:305-306, :368-369).  The wrapper classes keep the refe
 fused into the kernels' emit epilogue (bsx_logging_t) so that every lane accumulates exactly what
 the reference wrapper would and snapshots a row at the same log-spaced counts; the Python class
 below keeps the reference constructor and forwards rows to a `logger.write(dict)` object.
-`ImageObservation` (wrappers.py:150-247) is an adapter and out of scope (§8 f-4).
+`ImageObservation` / `to_image` (wrappers.py:150-247) run as one store-stream kernel
+over the whole batch (bsx_image_observation, csrc/image.hip).
 """
 from typing import Any, Dict, List, Optional, Sequence
 
+import ctypes
+
 import numpy as np
+import torch
 
 from bsuite_amd import _native
 from bsuite_amd import dm_env_compat as dm_env
@@ -199,3 +203,98 @@ class Logging(_RewardWrapper):
   def counters(self) -> Dict[str, Any]:
     """The live per-lane accumulators as device tensors [B] (steps, episode, total_return, ...)."""
     return {k: self._lg[k] for k in ('steps', 'episode', 'total_return', 'episode_len', 'episode_return')}
+
+
+# ---------------------------------------------------------------------------------------------
+# ImageObservation (wrappers.py:150-247)
+def _image_cfg(shape: Sequence[int], obs_shape: Sequence[int]) -> '_native.ImageCfg':
+  """Validates like `to_image` (wrappers.py:222-247) and picks the rule."""
+  shape = tuple(int(s) for s in shape)
+  assert len(shape) >= 2
+  obs_shape = tuple(int(s) for s in obs_shape)
+  size = int(np.prod(obs_shape)) if obs_shape else 1
+  tail = int(np.prod(shape[2:])) if len(shape) > 2 else 1
+  if size <= 4:                                   # _small_state_to_image (:178-204)
+    return _native.ImageCfg(_native.IMAGE_SMALL, 1, size, shape[0], shape[1], tail)
+  if len(obs_shape) > 2:
+    raise ValueError('Cannot convert observation shape {} to desired shape {}'.format(obs_shape, shape))
+  rows, cols = (1, obs_shape[0]) if len(obs_shape) == 1 else obs_shape   # np.expand_dims(obs, 0) (:212-213)
+  if shape[0] < rows or shape[1] < cols:
+    raise NotImplementedError(
+        f'to_image: down-scaling {obs_shape} -> {shape[:2]} needs skimage\'s anti-aliasing filter, '
+        'which the device kernel does not restate')
+  return _native.ImageCfg(_native.IMAGE_BILINEAR, rows, cols, shape[0], shape[1], tail)
+
+
+def to_image(shape: Sequence[int], observation, out: Optional[torch.Tensor] = None, batched=None):
+  """Converts bsuite observations into an image-like format on the device (wrappers.py:222-247).
+
+  observation: a device tensor `[B, *obs_shape]` (batched; returns a device tensor `[B, *shape]`)
+  or a single numpy observation (returns numpy, like the reference; one H2D + D2H — compatibility
+  path).  Values are tiled (size <= 4) or bilinearly interpolated (skimage >= 0.19 `resize` =
+  scipy.ndimage.zoom(order=1, mode='mirror', grid_mode=True)) and broadcast over trailing dims."""
+  shape = tuple(int(s) for s in shape)
+  if batched is None:
+    batched = torch.is_tensor(observation)
+  if not batched:
+    obs_np = np.ascontiguousarray(np.asarray(observation, dtype=np.float32))
+    dev = torch.device('cuda', torch.cuda.current_device())
+    res = to_image(shape, torch.from_numpy(obs_np).to(dev).unsqueeze(0), batched=True)
+    return res[0].cpu().numpy().astype(np.asarray(observation).dtype, copy=False)
+  obs = observation
+  if obs.dtype != torch.float32 or not obs.is_cuda:
+    raise TypeError('to_image: batched observations must be float32 device tensors')
+  obs = obs.contiguous()
+  B = int(obs.shape[0])
+  cfg = _image_cfg(shape, obs.shape[1:])
+  if out is None:
+    out = torch.empty((B,) + shape, dtype=torch.float32, device=obs.device)
+  elif out.shape != (B,) + shape or out.dtype != torch.float32 or not out.is_contiguous() or out.device != obs.device:
+    raise ValueError('to_image: `out` must be a contiguous float32 tensor of shape (B, *shape) on the same device')
+  rc = _native.lib.bsx_image_observation(ctypes.byref(cfg), B, obs.data_ptr(), out.data_ptr(),
+                                         torch.cuda.current_stream(obs.device).cuda_stream)
+  _native.check(rc, 'to_image')
+  return out
+
+
+class ImageObservation(dm_env.EnvironmentBase):
+  """Environment wrapper to convert observations to an image-like format (wrappers.py:150-175).
+
+  Batched environments keep `num_buffers` image buffers `[B, *shape]` on the device and fill one per
+  call with a single kernel launch; the scalar view returns numpy images like the reference."""
+
+  def __init__(self, env, shape: Sequence[int], num_buffers: int = 2):
+    self._env = env
+    self._shape = tuple(int(s) for s in shape)
+    _image_cfg(self._shape, env.observation_spec().shape)       # validate once, like the first to_image call would
+    self._num_buffers = max(1, int(num_buffers))
+    self._images = None
+    self._buf = 0
+
+  def observation_spec(self):
+    spec = self._env.observation_spec()
+    return dm_env.specs.Array(shape=self._shape, dtype=spec.dtype, name=spec.name)
+
+  def action_spec(self):
+    return self._env.action_spec()
+
+  def _convert(self, timestep):
+    obs = timestep.observation
+    if not torch.is_tensor(obs):
+      return timestep._replace(observation=to_image(self._shape, obs))
+    if self._images is None:
+      self._images = [torch.empty((obs.shape[0],) + self._shape, dtype=torch.float32, device=obs.device)
+                      for _ in range(self._num_buffers)]
+    out = self._images[self._buf]
+    self._buf = (self._buf + 1) % self._num_buffers
+    return timestep._replace(observation=to_image(self._shape, obs, out=out))
+
+  def reset(self):
+    return self._convert(self._env.reset())
+
+  def step(self, action):
+    return self._convert(self._env.step(action))
+
+  def __getattr__(self, attr):
+    """Delegate attribute access to underlying environment."""
+    return getattr(self._env, attr)

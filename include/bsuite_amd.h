@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define BSX_ABI_VERSION 5
+#define BSX_ABI_VERSION 6
 
 #define BSX_FIRST 0
 #define BSX_MID 1
@@ -296,6 +296,28 @@ int bsx_group_set_mnist(bsx_group_t* g, int32_t index, const bsx_mnist_t* cfg, c
 int bsx_group_commit(bsx_group_t* g);
 int bsx_group_step(bsx_group_t* g, void* hip_stream);
 int bsx_group_destroy(bsx_group_t* g);
+
+/* ---- observation adapter ------------------------------------------------------
+ * Replaces utils/wrappers.py:150-247 (`ImageObservation.step/reset` -> `to_image(shape, obs)`):
+ * every lane's observation [in_rows,in_cols] becomes an image [out_rows,out_cols,tail] (tail =
+ * product of the trailing dimensions of `shape`, 1 for a 2-D shape); each plane value is broadcast
+ * over the tail.  mode BSX_IMAGE_SMALL is `_small_state_to_image` (:178-204, observation.size
+ * <= 4: constant / left-right halves / quadrants, incl. the reference's quadrant order);
+ * BSX_IMAGE_BILINEAR is `_interpolate_to_image` (:207-219) for out >= in in both dimensions, i.e.
+ * skimage.transform.resize(order=1, mode='reflect', no anti-aliasing) = scipy.ndimage.zoom(order=1,
+ * mode='mirror', grid_mode=True): per axis cc = (k+0.5)*(in/out)-0.5 mirrored, weights
+ * (1-frac, frac), the 4 terms (v*wy)*wx summed in f64 in scipy's order, cast to f32.
+ * obs: f32 [n_lanes, in_rows*in_cols]; image: f32 [n_lanes, out_rows*out_cols*tail], 16-B aligned.
+ * Limits: in_rows*in_cols <= 4096, out_rows/out_cols <= 1024, out_rows*out_cols*tail < 2^20. */
+#define BSX_IMAGE_SMALL 0
+#define BSX_IMAGE_BILINEAR 1
+typedef struct {
+  int32_t mode;
+  int32_t in_rows, in_cols;
+  int32_t out_rows, out_cols, tail;
+} bsx_image_t;
+int bsx_image_observation(const bsx_image_t* cfg, int64_t n_lanes, const float* obs, float* image,
+                          void* hip_stream);
 
 /* ---- misc ---------------------------------------------------------------------------------- */
 int bsx_abi_version(void);

@@ -11,7 +11,7 @@ PHYSICS = ('cartpole', 'cartpole_swingup', 'mountain_car')
 
 def case_names():
   names = [os.path.basename(p)[:-4] for p in sorted(glob.glob(os.path.join(GOLDEN_DIR, '*.npz')))]
-  return [n for n in names if n not in ('host_constants', 'mnist_synthetic_dataset')]
+  return [n for n in names if n not in ('host_constants', 'mnist_synthetic_dataset', 'image_adapter', 'gym_adapter')]
 
 
 def mnist_dataset():
@@ -47,3 +47,12 @@ def contiguous_runs(lanes):
     runs.append((i, lanes[i], j - i + 1))
     i = j + 1
   return runs
+
+
+def image_adapter_cases():
+  """(name, shape, obs [n,*obs_shape], image [n,*shape]) written by the reference's own to_image."""
+  with open(os.path.join(GOLDEN_DIR, 'adapters.json')) as f:
+    meta = json.load(f)
+  g = np.load(os.path.join(GOLDEN_DIR, 'image_adapter.npz'))
+  return [(k, tuple(m['shape']), g[k + '__obs'], g[k + '__image'])
+          for k, m in sorted(meta.items()) if k + '__obs' in g.files]
