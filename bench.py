@@ -111,10 +111,15 @@ def bench_sweep(args, torch, dist, dev, rank, world):
                         num_streams=int(os.environ.get('BSX_SWEEP_STREAMS', '32')),
                         env_kwargs=dict(mnist=mn, mnist_noise=mn, mnist_scale=mn))
   acts = batch.random_actions(seed=1 + rank)
-  grouped = os.environ.get('BSX_SWEEP_MODE', 'grouped') == 'grouped'
+  mode = os.environ.get('BSX_SWEEP_MODE', 'grouped_graph')
+  grouped = mode in ('grouped', 'grouped_graph')
   if grouped:
-    batch.prepare_groups(acts)
-    batch.replay = batch.step_grouped
+    batch.prepare_groups(acts, mix_small=os.environ.get('BSX_SWEEP_MIX_SMALL', '1') != '0')
+    if mode == 'grouped_graph':              # group launches as concurrent branches of one HIP graph
+      batch.capture_grouped(int(os.environ.get('BSX_SWEEP_STREAMS', '2')))
+      batch.replay = batch.replay_grouped
+    else:
+      batch.replay = batch.step_grouped
   else:
     batch.capture(acts)
 
@@ -161,7 +166,8 @@ def bench_sweep(args, torch, dist, dev, rank, world):
         'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBPS, 'unit': 'GB/s',
                      'frac': achieved / HBM_PEAK_GBPS, 'traffic': None, 'kernel_ms': step_ms,
                      'algorithmic_bytes_per_launch': total_bytes / world},
-        'launch': (f'{len(batch._groups)} grouped launches per sweep step ({len(batch.envs)} segments)' if grouped else
+        'launch': (f'{len(batch._groups)} grouped launches per sweep step ({len(batch.envs)} segments)'
+                   + (' as concurrent branches of one HIP graph' if mode == 'grouped_graph' else '') if grouped else
                    f'one hipGraph per sweep step ({len(batch.envs)} segments over {batch.num_streams} streams)')}),
           flush=True)
   if world > 1:

@@ -170,15 +170,34 @@ __device__ __forceinline__ void bsx_flush_counts(const bsx_ctl& c, const unsigne
   if (s_cnt[1]) atomicAdd(&shard[1], (unsigned long long)s_cnt[1]);
 }
 
-// Grouped launch: segment of a workgroup = largest s with start[s] <= blockIdx.x (start is the
-// exclusive prefix sum of per-segment workgroup counts, n+1 entries, in device memory).
-__device__ __forceinline__ int bsx_group_find(const int32_t* __restrict__ start, int n, int b) {
-  int lo = 0, hi = n;            // invariant: start[lo] <= b < start[hi]
+// Grouped launch: which segment a workgroup belongs to, and its index inside that segment.
+// `map` (device memory, one (segment, local block) pair per workgroup of the launch) answers with ONE
+// scalar load; without it (launches too large to tabulate) the segment is the largest s with
+// start[s] <= b, found by binary search over the exclusive prefix sums `start` (n+1 entries) — a
+// chain of ~log2(n) dependent loads in front of every workgroup, which cost the store-stream
+// kernels 10-35 % when the sweep's 16 KiB workgroups each paid it (profiles/r01/ab_sweep_modes.log).
+struct bsx_group_index {
+  const int32_t* start;
+  const int2* map;
+  int n;
+};
+
+struct bsx_group_slot { int seg; uint32_t block; };
+
+__device__ __forceinline__ bsx_group_slot bsx_group_find(const bsx_group_index& gi, int b) {
+  bsx_group_slot r;
+  if (gi.map != nullptr) {
+    const int2 v = gi.map[b];
+    r.seg = v.x; r.block = (uint32_t)v.y;
+    return r;
+  }
+  int lo = 0, hi = gi.n;         // invariant: start[lo] <= b < start[hi]
   while (hi - lo > 1) {
     const int mid = (lo + hi) >> 1;
-    if (start[mid] <= b) lo = mid; else hi = mid;
+    if (gi.start[mid] <= b) lo = mid; else hi = mid;
   }
-  return lo;
+  r.seg = lo; r.block = (uint32_t)(b - gi.start[lo]);
+  return r;
 }
 
 // Advance kernel of the two-kernel families (deep_sea, catch): one lane per thread, coalesced
@@ -221,11 +240,11 @@ __global__ void __launch_bounds__(BSX_BLOCK) bsx_advance_kernel(const typename F
 
 template <class Fam>
 __global__ void __launch_bounds__(BSX_BLOCK) bsx_advance_group_kernel(const typename Fam::args* __restrict__ table,
-                                                                      const int32_t* __restrict__ start, int n) {
+                                                                      const bsx_group_index gi) {
   __shared__ typename Fam::shared s_fam;
   __shared__ unsigned int s_cnt[2];
-  const int seg = bsx_group_find(start, n, (int)blockIdx.x);
-  bsx_advance_body<Fam>(table[seg], blockIdx.x - (uint32_t)start[seg], s_fam, s_cnt);
+  const bsx_group_slot w = bsx_group_find(gi, (int)blockIdx.x);
+  bsx_advance_body<Fam>(table[w.seg], w.block, s_fam, s_cnt);
 }
 
 // n / cells for n < 2^20 via the host-built magic (bsx_div_magic); cells == 1 has no 32-bit magic.
@@ -341,11 +360,10 @@ __global__ void __launch_bounds__(BS) bsx_hot_stream_kernel(float* __restrict__ 
 
 template <class HotFn, int K>
 __global__ void __launch_bounds__(BSX_BLOCK) bsx_hot_stream_group_kernel(
-    const bsx_stream_seg<HotFn>* __restrict__ table, const int32_t* __restrict__ start, int n) {
-  const int seg = bsx_group_find(start, n, (int)blockIdx.x);
-  const bsx_stream_seg<HotFn>& g = table[seg];
-  bsx_hot_stream_body<HotFn, K, BSX_BLOCK>(g.obs, g.state, g.n_lanes, g.cells, g.cells_magic, g.dv, g.fn,
-                                           blockIdx.x - (uint32_t)start[seg]);
+    const bsx_stream_seg<HotFn>* __restrict__ table, const bsx_group_index gi) {
+  const bsx_group_slot w = bsx_group_find(gi, (int)blockIdx.x);
+  const bsx_stream_seg<HotFn>& g = table[w.seg];
+  bsx_hot_stream_body<HotFn, K, BSX_BLOCK>(g.obs, g.state, g.n_lanes, g.cells, g.cells_magic, g.dv, g.fn, w.block);
 }
 
 // Degenerate boards (cells < 4: a 16-byte chunk spans several lanes): one float per thread.

@@ -135,6 +135,10 @@ struct bsx_group {
   void* d_args2 = nullptr;
   int32_t* d_start = nullptr;           // [n+1] exclusive prefix of blocks
   int32_t* d_start2 = nullptr;
+  int2* d_map = nullptr;                // [total_blocks] (segment, local block) per workgroup, or null
+  int2* d_map2 = nullptr;
+  bsx_group_index index1() const { bsx_group_index gi; gi.start = d_start; gi.map = d_map; gi.n = n; return gi; }
+  bsx_group_index index2() const { bsx_group_index gi; gi.start = d_start2; gi.map = d_map2; gi.n = n; return gi; }
   int64_t total_blocks = 0, total_blocks2 = 0;
   bool committed = false;
   int (*launch)(bsx_group*, hipStream_t) = nullptr;
@@ -166,9 +170,9 @@ static inline int bsx_group_put_pair(bsx_group* g, int32_t index, const typename
 template <class Fam, class HotFn, int K>
 static int bsx_group_launch_pair(bsx_group* g, hipStream_t st) {
   bsx_advance_group_kernel<Fam><<<dim3((unsigned)g->total_blocks), dim3(BSX_BLOCK), 0, st>>>(
-      (const typename Fam::args*)g->d_args, g->d_start, g->n);
+      (const typename Fam::args*)g->d_args, g->index1());
   bsx_hot_stream_group_kernel<HotFn, K><<<dim3((unsigned)g->total_blocks2), dim3(BSX_BLOCK), 0, st>>>(
-      (const bsx_stream_seg<HotFn>*)g->d_args2, g->d_start2, g->n);
+      (const bsx_stream_seg<HotFn>*)g->d_args2, g->index2());
   return (int)hipGetLastError();
 }
 

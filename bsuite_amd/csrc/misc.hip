@@ -78,7 +78,7 @@ extern "C" int bsx_stream_dump(uint64_t seed, uint64_t lane0, int64_t n_lanes, u
 // ------------------------------------------------------------------------------ grouped launch
 extern "C" int bsx_group_create(int32_t family, int32_t n_segments, bsx_group_t** group) {
   if (group == nullptr) return BSX_ENULL;
-  if (family < BSX_FAM_DEEP_SEA || family > BSX_FAM_MNIST || n_segments < 1 || n_segments > (1 << 20)) return BSX_EINVAL;
+  if (family < BSX_FAM_DEEP_SEA || family > BSX_FAM_SMALL_MIXED || n_segments < 1 || n_segments > (1 << 20)) return BSX_EINVAL;
   bsx_group* g = new bsx_group();
   g->family = family; g->n = n_segments;
   g->blocks.assign(n_segments, 0); g->blocks2.assign(n_segments, 0); g->is_set.assign(n_segments, 0);
@@ -110,6 +110,19 @@ extern "C" int bsx_group_commit(bsx_group_t* g) {
   if (rc == 0) rc = upload(g->args2.data(), g->args2.size(), &g->d_args2);
   if (rc == 0) rc = upload(start.data(), start.size() * 4, (void**)&g->d_start);
   if (rc == 0) rc = upload(start2.data(), start2.size() * 4, (void**)&g->d_start2);
+  // (segment, local block) of every workgroup: one load per workgroup instead of a binary search;
+  // launches beyond 2^24 workgroups (128 MiB of map) keep the search.
+  static const int use_map = bsx_env_int("BSX_GROUP_MAP", 1);
+  for (int pass = 0; pass < 2 && rc == 0 && use_map; ++pass) {
+    const int64_t total = pass == 0 ? t1 : t2;
+    const std::vector<int32_t>& blocks = pass == 0 ? g->blocks : g->blocks2;
+    if (total == 0 || total > (1 << 24)) continue;
+    std::vector<int2> map((size_t)total);
+    size_t w = 0;
+    for (int i = 0; i < g->n; ++i)
+      for (int32_t b = 0; b < blocks[i]; ++b) { map[w].x = i; map[w].y = b; ++w; }
+    rc = upload(map.data(), map.size() * sizeof(int2), (void**)(pass == 0 ? &g->d_map : &g->d_map2));
+  }
   if (rc != 0) return rc;
   g->committed = true;
   return 0;
@@ -127,6 +140,8 @@ extern "C" int bsx_group_destroy(bsx_group_t* g) {
   if (g->d_args2) (void)hipFree(g->d_args2);
   if (g->d_start) (void)hipFree(g->d_start);
   if (g->d_start2) (void)hipFree(g->d_start2);
+  if (g->d_map) (void)hipFree(g->d_map);
+  if (g->d_map2) (void)hipFree(g->d_map2);
   delete g;
   return 0;
 }

@@ -65,10 +65,10 @@ __global__ void __launch_bounds__(BSX_BLOCK) mnist_advance_kernel(const mnist_ar
 }
 
 __global__ void __launch_bounds__(BSX_BLOCK) mnist_advance_group_kernel(const mnist_args* __restrict__ table,
-                                                                        const int32_t* __restrict__ start, int n) {
+                                                                        const bsx_group_index gi) {
   __shared__ unsigned int s_cnt[2];
-  const int seg = bsx_group_find(start, n, (int)blockIdx.x);
-  mnist_advance_body(table[seg], blockIdx.x - (uint32_t)start[seg], s_cnt);
+  const bsx_group_slot w = bsx_group_find(gi, (int)blockIdx.x);
+  mnist_advance_body(table[w.seg], w.block, s_cnt);
 }
 
 struct mnist_observe_args {
@@ -83,11 +83,16 @@ struct mnist_observe_args {
 };
 
 // Block b writes floats [b*K*1024, (b+1)*K*1024) of the [B x num_pixels] observation array
-// (num_pixels % 4 == 0, so a 16-byte chunk never straddles two lanes).
-template <int K>
+// (num_pixels % 4 == 0, so a 16-byte chunk never straddles two lanes).  VAR (A/B knob
+// BSX_MNIST_VARIANT): bit 0 = issue the state loads + image gathers BEFORE the LUT fill and its
+// barrier; bit 1 = each wave owns K consecutive KiB (the deep_sea stream order) instead of the
+// block-interleaved order.
+template <int K, int VAR>
 __device__ __forceinline__ void mnist_observe_body(const mnist_observe_args& a, uint32_t block_id, float* s_lut) {
-  s_lut[threadIdx.x] = a.lut[threadIdx.x];
-  __syncthreads();
+  if (!(VAR & 1)) {
+    s_lut[threadIdx.x] = a.lut[threadIdx.x];
+    __syncthreads();
+  }
   const uint32_t cells = a.cells;
   const uint64_t total = (uint64_t)a.n_lanes * cells;
   const uint64_t F0 = (uint64_t)block_id * (uint64_t)(K * 4 * BSX_BLOCK);
@@ -95,11 +100,12 @@ __device__ __forceinline__ void mnist_observe_body(const mnist_observe_args& a, 
   const uint32_t r_b = (uint32_t)(F0 - lane_b * cells);
   bsx_f4* __restrict__ o4 = reinterpret_cast<bsx_f4*>(a.obs + F0);
   const int32_t* __restrict__ st = a.state + lane_b;
+  const uint32_t wave = threadIdx.x >> 6, wl = threadIdx.x & 63u;
   uint32_t px[K];
   bool live[K], show[K];
 #pragma unroll
   for (int u = 0; u < K; ++u) {
-    const uint32_t c = threadIdx.x + u * BSX_BLOCK;
+    const uint32_t c = (VAR & 2) ? (wave * K + u) * 64u + wl : threadIdx.x + u * BSX_BLOCK;
     const uint32_t f = r_b + (c << 2);
     const uint32_t dl = __umulhi(f, a.cells_magic);
     const uint32_t r0 = f - dl * cells;
@@ -113,30 +119,47 @@ __device__ __forceinline__ void mnist_observe_body(const mnist_observe_args& a, 
         px[u] = *reinterpret_cast<const uint32_t*>(a.images + (uint64_t)(s & 0x00FFFFFF) * cells + r0);
     }
   }
+  if (VAR & 1) {
+    s_lut[threadIdx.x] = a.lut[threadIdx.x];
+    __syncthreads();
+  }
 #pragma unroll
   for (int u = 0; u < K; ++u) {
     if (!live[u]) continue;
+    const uint32_t c = (VAR & 2) ? (wave * K + u) * 64u + wl : threadIdx.x + u * BSX_BLOCK;
     bsx_f4 v = {0.f, 0.f, 0.f, 0.f};                            // mnist.py:73 zeros after the guess
     if (show[u]) {                                              // mnist.py:64 astype(f32) / 255
       const uint32_t p = px[u];
       v.x = s_lut[p & 0xFF]; v.y = s_lut[(p >> 8) & 0xFF]; v.z = s_lut[(p >> 16) & 0xFF]; v.w = s_lut[p >> 24];
     }
-    o4[threadIdx.x + u * BSX_BLOCK] = v;
+    o4[c] = v;
   }
 }
 
-template <int K>
+template <int K, int VAR>
 __global__ void __launch_bounds__(BSX_BLOCK) mnist_observe_kernel(const mnist_observe_args a) {
   __shared__ float s_lut[256];
-  mnist_observe_body<K>(a, blockIdx.x, s_lut);
+  mnist_observe_body<K, VAR>(a, blockIdx.x, s_lut);
 }
 
-template <int K>
+template <int K, int VAR>
 __global__ void __launch_bounds__(BSX_BLOCK) mnist_observe_group_kernel(const mnist_observe_args* __restrict__ table,
-                                                                        const int32_t* __restrict__ start, int n) {
+                                                                        const bsx_group_index gi) {
   __shared__ float s_lut[256];
-  const int seg = bsx_group_find(start, n, (int)blockIdx.x);
-  mnist_observe_body<K>(table[seg], blockIdx.x - (uint32_t)start[seg], s_lut);
+  const bsx_group_slot w = bsx_group_find(gi, (int)blockIdx.x);
+  mnist_observe_body<K, VAR>(table[w.seg], w.block, s_lut);
+}
+
+static int mnist_variant() {
+  static const int v = bsx_env_int("BSX_MNIST_VARIANT", 3) & 3;
+  return v;
+}
+static int mnist_group_k() {
+  // grouped workgroups pay two extra dependent loads (map entry, argument table) before their first
+  // store: 32 KiB runs amortise that better than the 16 KiB of the single-segment kernel
+  // (profiles/r01/ab_mnist_group_k.log: 100 -> 86 us per sweep step)
+  static const int v = bsx_env_int("BSX_MNIST_GROUP_K", 8);
+  return (v == 2 || v == 4) ? v : 8;
 }
 
 #define MNIST_K 4
@@ -180,16 +203,28 @@ extern "C" int bsx_mnist_step(const bsx_mnist_t* cfg, const bsx_call_t* call, co
     a.out.reward = out.reward + off; a.out.discount = out.discount + off; a.out.step_type = out.step_type + off;
     mnist_advance_kernel<<<dim3((unsigned)blocks_a), dim3(BSX_BLOCK), 0, st>>>(a);
     o.obs = out.observation + off * (int64_t)o.cells;
-    mnist_observe_kernel<MNIST_K><<<dim3((unsigned)blocks_o), dim3(BSX_BLOCK), 0, st>>>(o);
+    const dim3 go((unsigned)blocks_o), bo(BSX_BLOCK);
+    switch (mnist_variant()) {
+      case 1: mnist_observe_kernel<MNIST_K, 1><<<go, bo, 0, st>>>(o); break;
+      case 2: mnist_observe_kernel<MNIST_K, 2><<<go, bo, 0, st>>>(o); break;
+      case 3: mnist_observe_kernel<MNIST_K, 3><<<go, bo, 0, st>>>(o); break;
+      default: mnist_observe_kernel<MNIST_K, 0><<<go, bo, 0, st>>>(o); break;
+    }
   }
   return bsx_launch_status();
 }
 
 static int mnist_group_launch(bsx_group* g, hipStream_t st) {
   mnist_advance_group_kernel<<<dim3((unsigned)g->total_blocks), dim3(BSX_BLOCK), 0, st>>>(
-      (const mnist_args*)g->d_args, g->d_start, g->n);
-  mnist_observe_group_kernel<MNIST_K><<<dim3((unsigned)g->total_blocks2), dim3(BSX_BLOCK), 0, st>>>(
-      (const mnist_observe_args*)g->d_args2, g->d_start2, g->n);
+      (const mnist_args*)g->d_args, g->index1());
+  const dim3 go((unsigned)g->total_blocks2), bo(BSX_BLOCK);
+  const mnist_observe_args* tb = (const mnist_observe_args*)g->d_args2;
+  const int k = mnist_group_k(), var = mnist_variant();
+#define MN_GO(K, V) mnist_observe_group_kernel<K, V><<<go, bo, 0, st>>>(tb, g->index2())
+  if (k == 8) { if (var == 3) MN_GO(8, 3); else MN_GO(8, 0); }
+  else if (k == 2) { if (var == 3) MN_GO(2, 3); else MN_GO(2, 0); }
+  else { if (var == 3) MN_GO(4, 3); else MN_GO(4, 0); }
+#undef MN_GO
   return (int)hipGetLastError();
 }
 
@@ -204,7 +239,7 @@ extern "C" int bsx_group_set_mnist(bsx_group_t* g, int32_t index, const bsx_mnis
   memcpy(&g->args[(size_t)index * sizeof(a)], &a, sizeof(a));
   memcpy(&g->args2[(size_t)index * sizeof(o)], &o, sizeof(o));
   const uint64_t b1 = (uint64_t)(call->n_lanes + BSX_BLOCK - 1) / BSX_BLOCK;
-  const uint64_t b2 = bsx_flat_blocks((uint64_t)call->n_lanes * o.cells, MNIST_K);
+  const uint64_t b2 = bsx_flat_blocks((uint64_t)call->n_lanes * o.cells, mnist_group_k());
   if (b1 > 0x3FFFFFFFull || b2 > 0x3FFFFFFFull) return BSX_EINVAL;
   g->blocks[index] = (int32_t)b1; g->blocks2[index] = (int32_t)b2;
   g->is_set[index] = 1;

@@ -76,37 +76,48 @@ __global__ void __launch_bounds__(BSX_BLOCK) small_obs_kernel(const typename Env
 // segment's argument struct (device memory).
 template <class Env, int LPB>
 __global__ void __launch_bounds__(BSX_BLOCK) small_obs_group_kernel(const typename Env::args* __restrict__ table,
-                                                                    const int32_t* __restrict__ start, int n) {
+                                                                    const bsx_group_index gi) {
   extern __shared__ __attribute__((aligned(16))) float s_obs[];
   __shared__ unsigned int s_cnt[2];
-  const int seg = bsx_group_find(start, n, (int)blockIdx.x);
-  small_obs_body<Env, LPB, false, -1, -1>(table[seg], 1, blockIdx.x - (uint32_t)start[seg], s_obs, s_cnt);
+  const bsx_group_slot w = bsx_group_find(gi, (int)blockIdx.x);
+  small_obs_body<Env, LPB, false, -1, -1>(table[w.seg], 1, w.block, s_obs, s_cnt);
 }
 
 template <class Env>
 static int small_obs_group_launch(bsx_group* g, hipStream_t st) {
   const dim3 grid((unsigned)g->total_blocks), block(BSX_BLOCK);
   const typename Env::args* table = (const typename Env::args*)g->d_args;
-  if (g->klass == 256) small_obs_group_kernel<Env, 256><<<grid, block, g->lds_bytes, st>>>(table, g->d_start, g->n);
-  else small_obs_group_kernel<Env, 64><<<grid, block, g->lds_bytes, st>>>(table, g->d_start, g->n);
+  if (g->klass == 256) small_obs_group_kernel<Env, 256><<<grid, block, g->lds_bytes, st>>>(table, g->index1());
+  else small_obs_group_kernel<Env, 64><<<grid, block, g->lds_bytes, st>>>(table, g->index1());
   return (int)hipGetLastError();
 }
 
-// Records one segment of a small-observation family in a group.
+// A BSX_FAM_SMALL_MIXED group holds segments of ANY of the families in this file: every segment's
+// argument struct sits in a fixed-stride slot next to a family tag, and one launch per tile class
+// advances them all (the kernel switches on the tag per workgroup).  Six ~8 us launches of a
+// heterogeneous sweep become one.
+#define SMALL_MIXED_STRIDE 1024
+static int small_obs_mixed_launch(bsx_group* g, hipStream_t st);
+
+// Records one segment of a small-observation family in a group (of its own family, or mixed).
 template <class Env>
 static int small_obs_group_put(bsx_group* g, int32_t family, int32_t index, const bsx_call_t* call,
                                const typename Env::args& a, int numel) {
+  static_assert(sizeof(typename Env::args) <= SMALL_MIXED_STRIDE, "argument struct exceeds the mixed-group slot");
   const int lpb = numel <= 32 ? 256 : 64;
-  int rc = bsx_group_check_set(g, family, index, call, sizeof(typename Env::args), 0, lpb);
+  const bool mixed = g != nullptr && g->family == BSX_FAM_SMALL_MIXED;
+  int rc = bsx_group_check_set(g, mixed ? BSX_FAM_SMALL_MIXED : family, index, call,
+                               mixed ? SMALL_MIXED_STRIDE : sizeof(typename Env::args), mixed ? sizeof(int32_t) : 0, lpb);
   if (rc != 0) return rc;
-  memcpy(&g->args[(size_t)index * sizeof(a)], &a, sizeof(a));
+  memcpy(&g->args[(size_t)index * g->arg_size], &a, sizeof(a));
+  if (mixed) memcpy(&g->args2[(size_t)index * sizeof(int32_t)], &family, sizeof(int32_t));
   const uint64_t b = (uint64_t)(a.ctl.n_lanes + lpb - 1) / lpb;
   if (b > 0x3FFFFFFFull) return BSX_EINVAL;
   g->blocks[index] = (int32_t)b;
   const size_t lds = (size_t)lpb * numel * 4;
   if (lds > g->lds_bytes) g->lds_bytes = lds;
   g->is_set[index] = 1;
-  g->launch = small_obs_group_launch<Env>;
+  g->launch = mixed ? small_obs_mixed_launch : small_obs_group_launch<Env>;
   return 0;
 }
 
@@ -584,4 +595,38 @@ extern "C" int bsx_group_set_mountain_car(bsx_group_t* g, int32_t index, const b
   int rc = mountain_car_make(cfg, call, action, state, steps, out, info, &a);
   if (rc != 0) return rc;
   return small_obs_group_put<mountain_car_env>(g, BSX_FAM_MOUNTAIN_CAR, index, call, a, 3);
+}
+
+// ------------------------------------------------------------------------------ mixed-family group
+template <int LPB>
+__global__ void __launch_bounds__(BSX_BLOCK) small_obs_mixed_group_kernel(const uint8_t* __restrict__ table,
+                                                                          const int32_t* __restrict__ family,
+                                                                          const bsx_group_index gi) {
+  extern __shared__ __attribute__((aligned(16))) float s_obs[];
+  __shared__ unsigned int s_cnt[2];
+  const bsx_group_slot w = bsx_group_find(gi, (int)blockIdx.x);
+  const int seg = w.seg;
+  const uint32_t blk = w.block;
+  const uint8_t* slot = table + (size_t)seg * SMALL_MIXED_STRIDE;
+#define SMALL_MIXED_CASE(FAM, ENV) \
+  case FAM: small_obs_body<ENV, LPB, false, -1, -1>(*reinterpret_cast<const ENV::args*>(slot), 1, blk, s_obs, s_cnt); break;
+  switch (family[seg]) {                           // uniform per workgroup
+    SMALL_MIXED_CASE(BSX_FAM_BANDIT, bandit_env)
+    SMALL_MIXED_CASE(BSX_FAM_MEMORY_CHAIN, memory_chain_env)
+    SMALL_MIXED_CASE(BSX_FAM_UMBRELLA_CHAIN, umbrella_chain_env)
+    SMALL_MIXED_CASE(BSX_FAM_DISCOUNTING_CHAIN, discounting_chain_env)
+    SMALL_MIXED_CASE(BSX_FAM_CARTPOLE, cartpole_env)
+    SMALL_MIXED_CASE(BSX_FAM_MOUNTAIN_CAR, mountain_car_env)
+    default: break;
+  }
+#undef SMALL_MIXED_CASE
+}
+
+static int small_obs_mixed_launch(bsx_group* g, hipStream_t st) {
+  const dim3 grid((unsigned)g->total_blocks), block(BSX_BLOCK);
+  const uint8_t* table = (const uint8_t*)g->d_args;
+  const int32_t* family = (const int32_t*)g->d_args2;
+  if (g->klass == 256) small_obs_mixed_group_kernel<256><<<grid, block, g->lds_bytes, st>>>(table, family, g->index1());
+  else small_obs_mixed_group_kernel<64><<<grid, block, g->lds_bytes, st>>>(table, family, g->index1());
+  return (int)hipGetLastError();
 }

@@ -1,5 +1,7 @@
 """Batched MNIST contextual bandit (counterpart of bsuite/environments/mnist.py; csrc/mnist.hip)."""
 import ctypes
+import warnings
+import weakref
 from typing import Optional
 
 import numpy as np
@@ -10,6 +12,9 @@ from bsuite_amd.environments import base
 from bsuite_amd.utils import datasets
 
 NUM_EPISODES = 10000  # bsuite/experiments/mnist/sweep.py:19
+
+
+_DEVICE_TABLES = {}   # key -> (weakref images_dev, weakref labels_dev, host array kept alive for the key)
 
 
 class MNISTBandit(base.Environment):
@@ -50,8 +55,21 @@ class MNISTBandit(base.Environment):
     self.bsuite_num_episodes = NUM_EPISODES
 
   def _state_tensors(self):
-    self._images_dev = torch.from_numpy(np.ascontiguousarray(self._images).reshape(self._num_data, -1)).to(self._device)
-    self._labels_dev = torch.from_numpy(np.ascontiguousarray(self._labels)).to(self._device)
+    # One device copy of the image table per (host array, device): environments built on the same
+    # dataset (a sweep has 60) share it — real MNIST is 47 MB per copy.
+    key = (self._images.__array_interface__['data'][0], self._images.shape,
+           self._labels.__array_interface__['data'][0], str(self._device))
+    hit = _DEVICE_TABLES.get(key)
+    if hit is None or hit[0]() is None:
+      host = np.ascontiguousarray(self._images).reshape(self._num_data, -1)
+      with warnings.catch_warnings():
+        warnings.simplefilter('ignore')            # read-only numpy view -> tensor (never written)
+        images_dev = torch.from_numpy(host).to(self._device)
+        labels_dev = torch.from_numpy(np.ascontiguousarray(self._labels)).to(self._device)
+      _DEVICE_TABLES[key] = hit = (weakref.ref(images_dev), weakref.ref(labels_dev), self._images)
+      self._images_dev, self._labels_dev = images_dev, labels_dev
+    else:
+      self._images_dev, self._labels_dev = hit[0](), hit[1]()
     self._cfg.images = self._images_dev.data_ptr()
     self._cfg.labels = self._labels_dev.data_ptr()
     return dict(state=torch.full((self._batch,), 1 << 28, dtype=torch.int32, device=self._device))

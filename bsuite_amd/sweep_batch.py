@@ -97,6 +97,8 @@ class SweepBatch:
     self._graph = None
     self._streams = None
     self._groups = []
+    self._groups_by_cost = []
+    self._grouped_graph = None
 
   # ---------------------------------------------------------------------------------------
   def random_actions(self, seed: int = 0) -> List[torch.Tensor]:
@@ -120,8 +122,10 @@ class SweepBatch:
     return outs
 
   # -- grouped launches --------------------------------------------------------------------
-  def prepare_groups(self, actions: Sequence[torch.Tensor]):
-    """Builds one launch group per (family, launch class): records every local segment with its
+  def prepare_groups(self, actions: Sequence[torch.Tensor], mix_small: bool = True):
+    """Builds the launch groups: one per two-kernel family (deep_sea, catch, mnist) and — with
+    `mix_small` — ONE mixed group per tile class for all small-observation families together
+    (BSX_FAM_SMALL_MIXED), else one per (family, class).  Records every local segment with its
     static `actions` tensor and uploads the argument tables.  Returns the per-segment output
     TimeSteps (tensors that every `step_grouped()` overwrites)."""
     import ctypes  # pylint: disable=import-outside-toplevel
@@ -135,8 +139,10 @@ class SweepBatch:
       numel = int(np.prod(raw.observation_spec().shape))
       small = raw._abi_name not in ('deep_sea', 'catch', 'mnist')  # pylint: disable=protected-access
       klass = (256 if numel <= 32 else 64) if small else 0
-      buckets.setdefault((raw._abi_name, klass), []).append(k)  # pylint: disable=protected-access
+      group_family = 'small_mixed' if (small and mix_small) else raw._abi_name  # pylint: disable=protected-access
+      buckets.setdefault((group_family, klass), []).append(k)
     outs = [None] * len(self.envs)
+    costs = []
     for (name, _), members in sorted(buckets.items()):
       handle = ctypes.c_void_p()
       _native.check(_native.lib.bsx_group_create(_native.FAMILY_IDS[name], len(members), ctypes.byref(handle)),
@@ -144,11 +150,15 @@ class SweepBatch:
       self._groups.append(handle)
       for idx, k in enumerate(members):
         raw = self.envs[k].raw_env if hasattr(self.envs[k], 'raw_env') else self.envs[k]
-        _native.check(raw._group_set(handle, idx, actions[k]), f'bsx_group_set_{name}')  # pylint: disable=protected-access
+        _native.check(raw._group_set(handle, idx, actions[k]), f'bsx_group_set_{raw._abi_name}')  # pylint: disable=protected-access
         o = raw._out[0]  # pylint: disable=protected-access
         outs[k] = dm_env.TimeStep(step_type=o['step_type'], reward=o['reward'], discount=o['discount'],
                                   observation=o['observation'])
       _native.check(_native.lib.bsx_group_commit(handle), 'bsx_group_commit')
+      costs.append(sum(self.segments[k][2] * bytes_per_step(int(np.prod(self.envs[k].observation_spec().shape)))
+                       for k in members))
+    order = sorted(range(len(costs)), key=lambda j: -costs[j])
+    self._groups_by_cost = [self._groups[j] for j in order]     # heaviest store streams first
     self._group_actions = list(actions)      # keep the static action tensors alive
     self._group_outs = outs
     return outs
@@ -167,11 +177,52 @@ class SweepBatch:
       raw._step_index += 1  # pylint: disable=protected-access
     return self._group_outs
 
+  def capture_grouped(self, num_streams: int = 2):
+    """Captures one grouped sweep step as a HIP graph whose group launches run as `num_streams`
+    concurrent branches (largest groups first, round-robin): the small families' launches — each
+    near the ~8 us floor of a launch — overlap the store streams of deep_sea / mnist / catch instead
+    of queueing behind them.  Groups are independent (disjoint segments); the shared call counter is
+    bumped after the join.  Call prepare_groups() first; then `replay_grouped()` per sweep step."""
+    from bsuite_amd import _native  # pylint: disable=import-outside-toplevel
+    if not self._groups:
+      raise RuntimeError('capture_grouped() needs prepare_groups() first')
+    self.step_grouped()                        # one eager step: first-use work stays out of the capture
+    torch.cuda.synchronize(self.device)
+    main = torch.cuda.Stream(device=self.device)
+    side = [torch.cuda.Stream(device=self.device) for _ in range(max(1, int(num_streams)) - 1)]
+    lanes = [main] + side
+    main.wait_stream(torch.cuda.current_stream(self.device))
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.stream(main):
+      with torch.cuda.graph(graph, stream=main):
+        for st in side:
+          st.wait_stream(main)                 # fork
+        for j, handle in enumerate(self._groups_by_cost):
+          st = lanes[j % len(lanes)]
+          _native.check(_native.lib.bsx_group_step(handle, st.cuda_stream), 'bsx_group_step')
+        for st in side:
+          main.wait_stream(st)                 # join
+        self._bump()
+    torch.cuda.current_stream(self.device).wait_stream(main)
+    self._grouped_graph = graph
+    self._grouped_streams = lanes
+    return self._group_outs
+
+  def replay_grouped(self):
+    """One sweep step from the graph captured by capture_grouped()."""
+    self._grouped_graph.replay()
+    for env in self.envs:
+      raw = env.raw_env if hasattr(env, 'raw_env') else env
+      raw._step_index += 1  # pylint: disable=protected-access
+    return self._group_outs
+
   def release_groups(self):
     from bsuite_amd import _native  # pylint: disable=import-outside-toplevel
+    self._grouped_graph = None
     for handle in self._groups:
       _native.lib.bsx_group_destroy(handle)
     self._groups = []
+    self._groups_by_cost = []
 
   def __del__(self):
     try:

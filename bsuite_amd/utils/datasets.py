@@ -36,7 +36,19 @@ def load_mnist(directory='/tmp/mnist'):
         '(bsuite/utils/datasets.py:58-60) but this system has no network — place the idx .gz files '
         'there first.')
   p = lambda f: os.path.join(directory, f)  # noqa: E731
-  return ((_images(p(FILES[0])), _labels(p(FILES[1]))), (_images(p(FILES[2])), _labels(p(FILES[3]))))
+  # One parse per (directory, file stamps): a sweep builds 60 mnist environments on the same files.
+  key = (os.path.abspath(directory),) + tuple((os.path.getmtime(p(f)), os.path.getsize(p(f))) for f in FILES)
+  if key not in _PARSED:
+    _PARSED.clear()
+    out = ((_images(p(FILES[0])), _labels(p(FILES[1]))), (_images(p(FILES[2])), _labels(p(FILES[3]))))
+    for pair in out:
+      for arr in pair:
+        arr.setflags(write=False)
+    _PARSED[key] = out
+  return _PARSED[key]
+
+
+_PARSED = {}
 
 
 def write_idx_files(directory, train_images_u8, train_labels, test_images_u8=None, test_labels=None):

@@ -269,6 +269,10 @@ typedef struct bsx_group bsx_group_t;
 #define BSX_FAM_CARTPOLE 6
 #define BSX_FAM_MOUNTAIN_CAR 7
 #define BSX_FAM_MNIST 8
+/* A group of this family accepts bsx_group_set_<family> of bandit, memory_chain, umbrella_chain,
+ * discounting_chain, cartpole and mountain_car segments alike (all of one tile class: observation
+ * rows of <= 32 floats, or all wider) and advances them with ONE launch. */
+#define BSX_FAM_SMALL_MIXED 9
 int bsx_group_create(int32_t family, int32_t n_segments, bsx_group_t** group);
 int bsx_group_set_deep_sea(bsx_group_t* g, int32_t index, const bsx_deep_sea_t* cfg, const bsx_call_t* call,
                            const int32_t* action, int32_t* state, bsx_timestep_t out, double* info);

@@ -73,23 +73,35 @@ def test_sweep_rank_assignment_is_a_partition():
 
 
 @pytest.mark.gpu
-def test_grouped_sweep_equals_standalone_envs(tmp_path):
-  """One grouped launch per family advances every segment exactly like its standalone environment."""
+@pytest.mark.parametrize('mode', ['eager', 'graph', 'per_family'])
+def test_grouped_sweep_equals_standalone_envs(tmp_path, mode):
+  """One grouped launch per family advances every segment exactly like its standalone environment
+  (eager on one stream, or as concurrent branches of one captured HIP graph)."""
   from bsuite_amd.utils import datasets
   imgs, labels = gu.mnist_dataset()
   datasets.write_idx_files(str(tmp_path), imgs.view(np.uint8), labels)
   mn = dict(data_dir=str(tmp_path))
   kw = dict(mnist=mn, mnist_noise=mn, mnist_scale=mn)
   ids = IDS + ['deep_sea/7', 'catch_noise/11', 'bandit_scale/3', 'umbrella_distract/3', 'memory_size/2',
-               'cartpole_swingup/1', 'discounting_chain/9', 'mountain_car_noise/5']
+               'cartpole_swingup/1', 'discounting_chain/9', 'mountain_car_noise/5', 'umbrella_distract/22',
+               'memory_size/16']
   total, seed, reps = len(ids) * 257 + 3, 77, 23
   batch = sb.SweepBatch(ids, total, seed=seed, env_kwargs=kw)
   acts = batch.random_actions(seed=2)
-  outs = batch.prepare_groups(acts)
-  assert 9 <= len(batch._groups) <= 12           # families (+ wide-row classes), not segments
-  for _ in range(reps):
-    batch.step_grouped()
+  outs = batch.prepare_groups(acts, mix_small=(mode != 'per_family'))
+  if mode == 'per_family':
+    assert 9 <= len(batch._groups) <= 12         # families (+ wide-row classes), not segments
+  else:
+    assert len(batch._groups) == 5               # deep_sea, catch, mnist + two mixed tile classes
+  if mode == 'graph':
+    assert batch.capture_grouped(num_streams=4) is outs       # runs sweep step 0 eagerly, captures one step
+    for _ in range(reps - 1):
+      batch.replay_grouped()
+  else:
+    for _ in range(reps):
+      batch.step_grouped()
   torch.cuda.synchronize()
+  assert all(eu.raw(e).step_index == reps for e in batch.envs)
   for (bid, begin, lanes), a, out, env in zip(batch.segments, acts, outs, batch.envs):
     name = bid.split('/')[0]
     ekw = dict(kw.get(name, {}))
