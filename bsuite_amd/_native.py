@@ -24,6 +24,12 @@ class NativeLibraryError(RuntimeError):
 
 
 def _load():
+  override = os.environ.get('BSX_NATIVE_LIB')     # A/B of kernel variants: load this build instead
+  if override:
+    try:
+      return ctypes.CDLL(override)
+    except OSError as e:
+      raise NativeLibraryError(f'cannot load BSX_NATIVE_LIB={override}: {e}') from e
   # Build in-tree on first use, and rebuild when a kernel source is newer than the library (a
   # stale .so silently running old kernels is worse than a slow import).  No toolchain and no
   # library -> fail loudly.
