@@ -256,14 +256,17 @@ class Environment(dm_env.EnvironmentBase):
       max_rows = 4096 if log_every else len(points) + 2
     B, dev = self._batch, self._device
     n_info = len(self._info_keys)
+    # scalar view: the one lane's counters and rows sit in mapped host memory like its TimeStep, so
+    # the Logging wrapper reads them after the step's synchronisation without device-to-host copies
+    place = dict(pin_memory=True) if self._host_out else dict(device=dev)
     lg = dict(
-        steps=torch.zeros(B, dtype=torch.int64, device=dev),
-        episode=torch.zeros(B, dtype=torch.int64, device=dev),
-        total_return=torch.zeros(B, dtype=torch.float64, device=dev),
-        episode_len=torch.zeros(B, dtype=torch.int64, device=dev),
-        episode_return=torch.zeros(B, dtype=torch.float64, device=dev),
-        rows=torch.zeros((B, max_rows, 5 + n_info), dtype=torch.float64, device=dev),
-        n_rows=torch.zeros(B, dtype=torch.int32, device=dev),
+        steps=torch.zeros(B, dtype=torch.int64, **place),
+        episode=torch.zeros(B, dtype=torch.int64, **place),
+        total_return=torch.zeros(B, dtype=torch.float64, **place),
+        episode_len=torch.zeros(B, dtype=torch.int64, **place),
+        episode_return=torch.zeros(B, dtype=torch.float64, **place),
+        rows=torch.zeros((B, max_rows, 5 + n_info), dtype=torch.float64, **place),
+        n_rows=torch.zeros(B, dtype=torch.int32, **place),
         log_points=torch.tensor(points, dtype=torch.int64, device=dev))
     self._logging = lg
     self._logging_desc = _native.Logging(

@@ -22,3 +22,19 @@ for bid in ('catch/0', 'deep_sea/10', 'cartpole/0'):
   dt = time.perf_counter() - t0
   print(json.dumps(dict(bsuite_id=bid, view='scalar (batch=None)', steps=len(acts), steps_per_s=round(len(acts) / dt),
                         us_per_step=round(dt / len(acts) * 1e6, 1))), flush=True)
+
+# the way most bsuite users run it: load_and_record_to_csv + the reference run loop shape
+import tempfile
+tmp = tempfile.mkdtemp(prefix='bsx_csv_')
+env = bsuite_amd.load_and_record_to_csv('catch/0', results_dir=tmp, overwrite=True)
+rng = np.random.RandomState(0)
+acts = rng.randint(3, size=4096)
+ts = env.reset()
+for a in acts[:200]:
+  ts = env.step(int(a))
+t0 = time.perf_counter()
+for a in acts:
+  ts = env.step(int(a))
+dt = time.perf_counter() - t0
+print(json.dumps(dict(bsuite_id='catch/0', view='scalar + load_and_record_to_csv', steps=len(acts),
+                      steps_per_s=round(len(acts) / dt), us_per_step=round(dt / len(acts) * 1e6, 1))), flush=True)
