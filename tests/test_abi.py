@@ -83,3 +83,9 @@ def test_argument_errors_without_touching_the_gpu():
   cfg.size = 10
   assert lib.bsx_deep_sea_step(ctypes.byref(cfg), ctypes.byref(call), 0, 0, out, 0) == 0     # empty batch
   assert b'NULL' in lib.bsx_strerror(-2)
+
+
+def test_graft_entry_build_runs():
+  """The driver's build check: compiles (or finds up to date) every HIP source + the oracle checker."""
+  import __graft_entry__ as g
+  g.build()
