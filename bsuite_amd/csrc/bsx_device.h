@@ -170,6 +170,18 @@ __device__ __forceinline__ void bsx_flush_counts(const bsx_ctl& c, const unsigne
   if (s_cnt[1]) atomicAdd(&shard[1], (unsigned long long)s_cnt[1]);
 }
 
+// Error word: the batched kernels never fault on an action outside the action_spec —
+// bandit / discounting_chain clamp, catch moves the paddle by (action - 1) and clips — where the
+// reference raises IndexError; every such lane-step is counted in word 2 of the lane's counter shard
+// so a caller can assert `invalid_action_count() == 0` without a per-step host check.  Rare path:
+// a plain global atomic.
+__device__ __forceinline__ void bsx_note_invalid_action(const bsx_ctl& c, int64_t i) {
+  if (c.counters == nullptr) return;
+  unsigned long long* shard = (unsigned long long*)c.counters +
+                              (size_t)((uint64_t)(i >> 8) & (BSX_COUNTER_SHARDS - 1)) * BSX_COUNTER_STRIDE;
+  atomicAdd(&shard[2], 1ull);
+}
+
 // Grouped launch: which segment a workgroup belongs to, and its index inside that segment.
 // `map` (device memory, one (segment, local block) pair per workgroup of the launch) answers with ONE
 // scalar load; without it (launches too large to tabulate) the segment is the largest s with

@@ -41,6 +41,7 @@ struct catch_fam {
       paddle_x = cols / 2;
       type = BSX_FIRST;
     } else {
+      if (act < 0 || act > 2) bsx_note_invalid_action(a.ctl, i);   // reference: IndexError (catch.py:84)
       const int dx = act - 1;                                   // _ACTIONS :27
       paddle_x = paddle_x + dx;                                 // :85 np.clip
       paddle_x = paddle_x < 0 ? 0 : (paddle_x > cols - 1 ? cols - 1 : paddle_x);

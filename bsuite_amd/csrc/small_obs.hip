@@ -164,7 +164,10 @@ struct bandit_env {
     o[0] = 1.0f;                                                // bandit.py:54 (ones)
     if (a.ctl.force_reset || a.state[i]) { a.state[i] = 0; return BSX_FIRST; }
     int act = a.action[oi];
-    act = act < 0 ? 0 : (act >= a.num_actions ? a.num_actions - 1 : act);   // never read OOB
+    if (act < 0 || act >= a.num_actions) {                      // reference: IndexError (bandit.py:61)
+      bsx_note_invalid_action(a.ctl, i);
+      act = act < 0 ? 0 : a.num_actions - 1;                    // never read OOB
+    }
     reward = a.rewards[act];                                    // :61
     a.info[i] += 1.0 - reward;                                  // :62
     a.state[i] = 1;
@@ -369,7 +372,10 @@ struct discounting_chain_env {
     }
     if (t == 0) {                                               // :76-77
       ctx = a.action[oi];
-      ctx = ctx < 0 ? 0 : (ctx > 4 ? 4 : ctx);                  // action_spec: 5 values; never OOB
+      if (ctx < 0 || ctx > 4) {                                 // reference: IndexError at the reward lookup
+        bsx_note_invalid_action(a.ctl, i);
+        ctx = ctx < 0 ? 0 : 4;                                  // action_spec: 5 values; never OOB
+      }
     }
     t += 1;
     const int when = ctx == 0 ? 1 : ctx == 1 ? 3 : ctx == 2 ? 10 : ctx == 3 ? 30 : 100;   // :49

@@ -423,6 +423,14 @@ class Environment(dm_env.EnvironmentBase):
     self._ensure_allocated()
     return self._counters[:, :2].sum(dim=0)
 
+  def invalid_action_count(self) -> torch.Tensor:
+    """int64 scalar device tensor: lane-steps so far whose action was outside the action_spec in a
+    family where the reference raises IndexError (bandit, catch, discounting_chain).  The batched
+    kernels clamp such actions instead of faulting; assert this is 0 to get the reference's
+    strictness without a per-step host check (the scalar view raises like the reference)."""
+    self._ensure_allocated()
+    return self._counters[:, 2].sum()
+
   def state_dict(self) -> Dict[str, Any]:
     """Everything needed to resume this batch bit-exactly (device tensors are cloned)."""
     self._ensure_allocated()

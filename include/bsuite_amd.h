@@ -123,7 +123,11 @@ typedef struct {
                                shard s = block % SHARDS; [s*STRIDE+0] += lanes that emitted LAST,
                                [s*STRIDE+1] += lanes that emitted FIRST.  Masks come from wavefront
                                ballots; one global atomic per workgroup per mask, spread over 256
-                               cache lines (a single hot word serialises ~12 ns per arrival).      */
+                               cache lines (a single hot word serialises ~12 ns per arrival).
+                               [s*STRIDE+2] += lane-steps whose action was outside the action_spec
+                               where the reference raises IndexError (bandit.py:61, catch.py:84,
+                               discounting_chain.py:80): the kernels clamp / clip instead of
+                               faulting and count the event here (error word).                  */
   void* hip_stream;         /* hipStream_t                                                       */
   const bsx_logging_t* logging; /* host pointer or NULL (ABI v2)                                     */
 } bsx_call_t;

@@ -86,3 +86,47 @@ def test_episode_counters_count_ballots_exactly():
     n_first += int((ts.step_type == 0).sum().item())
   c = env.episode_counters().cpu().numpy()
   assert (c[0], c[1]) == (n_last, n_first) == (2 * B, 2 * B)
+
+
+@pytest.mark.gpu
+def test_invalid_actions_are_clamped_and_counted():
+  """SURVEY §8b error word: where the reference raises IndexError the batched kernels clamp/clip and
+  count the lane-step; in-spec runs leave the counter at zero."""
+  from bsuite_amd.environments import bandit, catch, discounting_chain
+  B = 1000
+  bad = torch.zeros(B, dtype=torch.bool, device='cuda')
+  bad[::7] = True
+  n_bad = int(bad.sum())
+  # bandit: every non-reset call indexes the reward table
+  env = bandit.SimpleBandit(mapping_seed=1, batch=B, seed=0)
+  env.reset()
+  a = torch.where(bad, torch.tensor(11, device='cuda'), torch.tensor(3, device='cuda')).to(torch.int32)
+  ts = env.step(a)
+  assert int(env.invalid_action_count()) == n_bad
+  top = max(env._cfg.rewards[i] for i in range(11))
+  assert torch.equal(ts.reward[bad], torch.full((n_bad,), env._cfg.rewards[10], device='cuda', dtype=torch.float32))
+  del top
+  env.step(a)                                                  # auto-reset call: actions ignored, nothing counted
+  assert int(env.invalid_action_count()) == n_bad
+  env.step(torch.full((B,), -5, dtype=torch.int32, device='cuda'))
+  assert int(env.invalid_action_count()) == n_bad + B
+  # catch: the paddle moves by (action - 1) and is clipped
+  env = catch.Catch(batch=B, seed=0)
+  env.reset()
+  env.step(torch.where(bad, torch.tensor(3, device='cuda'), torch.tensor(1, device='cuda')).to(torch.int32))
+  assert int(env.invalid_action_count()) == n_bad
+  env.step(torch.full((B,), 2, dtype=torch.int32, device='cuda'))
+  assert int(env.invalid_action_count()) == n_bad
+  # discounting_chain: only the first action of an episode selects the chain
+  env = discounting_chain.DiscountingChain(mapping_seed=0, batch=B)
+  env.reset()
+  env.step(torch.where(bad, torch.tensor(9, device='cuda'), torch.tensor(2, device='cuda')).to(torch.int32))
+  env.step(torch.full((B,), 77, dtype=torch.int32, device='cuda'))      # later actions are not read
+  assert int(env.invalid_action_count()) == n_bad
+  # an in-spec random rollout never touches the word
+  env = catch.Catch(batch=B, seed=1)
+  g = torch.Generator(device='cuda').manual_seed(0)
+  for _ in range(30):
+    env.step(torch.randint(3, (B,), device='cuda', generator=g, dtype=torch.int32))
+  assert int(env.invalid_action_count()) == 0
+  assert int(env.episode_counters()[0]) == 3 * B               # three finished episodes per lane
