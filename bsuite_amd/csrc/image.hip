@@ -3,7 +3,7 @@
 // the Atari-like format), so the kernel is bound by HBM stores exactly like the deep_sea
 // observation stream; the source observation of a lane (<= 16 KiB) is staged in LDS.
 //
-// Work split: a workgroup owns one run of IMG_RUN consecutive floats of ONE lane's image, so the
+// Work split: a workgroup owns one run of IMG_K * 1024 consecutive floats of ONE lane's image, so the
 // per-axis interpolation tables (source indices + f64 weights, identical for every lane) and the
 // lane's observation are built once per workgroup in LDS; each thread then issues IMG_K
 // lane-interleaved 16-byte stores.
@@ -22,9 +22,6 @@
 #include "bsx_device.h"
 #include "bsx_host.h"
 
-#define IMG_K 4
-#define IMG_RUN (IMG_K * BSX_BLOCK * 4)          // floats per workgroup
-
 struct image_args {
   const float* obs; float* image; int64_t n_lanes;
   int32_t mode, in_rows, in_cols, out_rows, out_cols, tail;
@@ -32,6 +29,7 @@ struct image_args {
   uint32_t tail_magic, cols_magic;                // bsx_div_magic(tail), bsx_div_magic(out_cols)
   uint32_t blocks_per_lane;
 };
+
 
 // scipy ni_interpolation.c map_coordinate(), NI_EXTEND_MIRROR, for the (-0.5, len-0.5) range the
 // grid-mode zoom produces (one reflection suffices; the general fold is kept for safety).
@@ -112,7 +110,9 @@ __device__ __forceinline__ float img_pixel(const image_args& a, const img_tables
   return (float)t;
 }
 
+template <int IMG_K>
 __global__ void __launch_bounds__(BSX_BLOCK) bsx_image_kernel(const image_args a) {
+  constexpr uint32_t IMG_RUN = IMG_K * BSX_BLOCK * 4;
   extern __shared__ __attribute__((aligned(16))) unsigned char s_raw[];
   // LDS layout: y weights f64 [2*H] | x weights f64 [2*W] | y idx i32 [H] | x idx i32 [W] | obs f32
   double* s_yw = reinterpret_cast<double*>(s_raw);
@@ -203,10 +203,25 @@ extern "C" int bsx_image_observation(const bsx_image_t* cfg, int64_t n_lanes, co
   a.numel = (uint32_t)numel;
   a.tail_magic = bsx_div_magic((uint32_t)cfg->tail);
   a.cols_magic = bsx_div_magic((uint32_t)cfg->out_cols);
-  a.blocks_per_lane = (uint32_t)((numel + IMG_RUN - 1) / IMG_RUN);
+  // Run length per workgroup: every workgroup re-stages its lane's observation and rebuilds the axis
+  // tables before its first store, so large observations want longer runs (measured on 84x84x4,
+  // profiles/r01/ab_image_k.log: 10x5 input best at 4 KiB x 4, 30x30 at x16; images whose
+  // channel count is not a multiple of 4 evaluate up to four pixels per store and prefer x8).  BSX_IMAGE_K overrides.
+  static const int k_knob = bsx_env_int("BSX_IMAGE_K", 0);
+  const int k = (k_knob == 2 || k_knob == 4 || k_knob == 8 || k_knob == 16) ? k_knob
+                : (in_numel > 256 && (cfg->tail & 3) == 0 ? 16 : (in_numel > 64 ? 8 : 4));
+  const int64_t run = (int64_t)k * BSX_BLOCK * 4;
+  a.blocks_per_lane = (uint32_t)((numel + run - 1) / run);
   const int64_t blocks = n_lanes * (int64_t)a.blocks_per_lane;
   if (blocks > 0x7FFFFFFF) return BSX_EINVAL;
   const size_t lds = (size_t)(cfg->out_rows + cfg->out_cols) * (16 + 4) + (size_t)in_numel * 4;
-  bsx_image_kernel<<<dim3((unsigned)blocks), dim3(BSX_BLOCK), lds, (hipStream_t)hip_stream>>>(a);
+  const dim3 grid((unsigned)blocks), block(BSX_BLOCK);
+  hipStream_t st = (hipStream_t)hip_stream;
+  switch (k) {
+    case 2: bsx_image_kernel<2><<<grid, block, lds, st>>>(a); break;
+    case 8: bsx_image_kernel<8><<<grid, block, lds, st>>>(a); break;
+    case 16: bsx_image_kernel<16><<<grid, block, lds, st>>>(a); break;
+    default: bsx_image_kernel<4><<<grid, block, lds, st>>>(a); break;
+  }
   return bsx_launch_status();
 }
