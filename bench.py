@@ -182,6 +182,9 @@ def main():
   ap.add_argument('--workload', default='deep_sea', choices=sorted(WORKLOADS) + ['sweep'])
   ap.add_argument('--lanes', type=int, default=1 << 20, help='lanes per GPU')
   ap.add_argument('--no-cpu-baseline', action='store_true')
+  ap.add_argument('--observation-mode', default='dense', choices=['dense', 'delta'],
+                  help="'delta' (deep_sea, catch): persistent observation buffers patched in place; a "
+                       'separate mode with its own byte accounting, NOT the dense contract of the headline')
   ap.add_argument('--rollout', type=int, default=0,
                   help='advance this many steps per entry-point call with env.rollout(actions[T,B]) '
                        '(fused T-step kernel for the small-observation families)')
@@ -222,8 +225,12 @@ def main():
     """Times exactly args.steps step() calls of `workload` after args.warmup untimed ones."""
     bsuite_id, family, okw, obs_numel, state_bytes = WORKLOADS[workload]
     B = args.lanes
+    delta = args.observation_mode == 'delta'
+    if delta and family not in ('deep_sea', 'catch'):
+      raise SystemExit('--observation-mode delta exists for deep_sea and catch only')
     env = bsuite_amd.load_from_id(bsuite_id, batch=B, device=dev, seed=42, lane_offset=rank * B,
-                                  num_buffers=2, device_step_counter=bool(args.graph))
+                                  num_buffers=2, device_step_counter=bool(args.graph),
+                                  observation_mode=args.observation_mode)
     num_actions = env.action_spec().num_values
     gen = torch.Generator(device=dev)
     gen.manual_seed(1234 + rank)
@@ -279,8 +286,13 @@ def main():
       dist.all_reduce(t_wall, op=dist.ReduceOp.MAX)
       wall, kernel_ms = float(t_wall[0].item()), float(t_wall[1].item())
     bytes_per_step = algorithmic_bytes_per_step(obs_numel, state_bytes)
+    if delta:
+      # ACTUAL bytes of the delta mode (reported separately, never against the dense
+      # contract): scalars + state in/out + paint column in/out + the 4-byte cell stores
+      # (deep_sea: clear 1 + set 1; catch: up to 2 + 2).
+      bytes_per_step = 13 + state_bytes + 8 + 4 * (2 if family == 'deep_sea' else 4)
     achieved = bytes_per_step * B / (kernel_ms * 1e-3) / 1e9
-    traffic, traffic_src = pmc_traffic(workload, B)
+    traffic, traffic_src = pmc_traffic(workload + ('_delta' if delta else ''), B)
     del env, actions
     torch.cuda.empty_cache()
     return dict(bsuite_id=bsuite_id, family=family, okw=okw, num_actions=num_actions, wall=wall,
@@ -290,7 +302,7 @@ def main():
 
   m = measure(args.workload)
   also = None
-  if args.workload == 'deep_sea' and not (args.graph or args.rollout):
+  if args.workload == 'deep_sea' and not (args.graph or args.rollout) and args.observation_mode == 'dense':
     also = measure('catch')        # the other half of BASELINE.json's metric, same K/W, same box
 
   # Pure-store ceiling of THIS box (one 16-B store per thread over 2 GiB, no other work): context for
@@ -326,7 +338,10 @@ def main():
         'ms_per_step': m['wall'] / args.steps * 1e3, 'higher_is_better': True, 'scaling': 'weak',
         'vs_baseline': None, 'dtype': 'f32' if m['family'] in ('cartpole', 'mountain_car') else 'int32',
         'data': 'synthetic',
-        'config': {'workload': f"{m['bsuite_id']} ({m['family']} {m['okw']}) random-action rollout, dense TimeStep",
+        'config': {'workload': f"{m['bsuite_id']} ({m['family']} {m['okw']}) random-action rollout, "
+                               + ('dense TimeStep' if args.observation_mode == 'dense' else
+                                  'DELTA observation mode (persistent buffers patched in place; not the dense contract)'),
+                   'observation_mode': args.observation_mode,
                    'lanes_per_gpu': B, 'global_lanes': B * world, 'sharding': f'lanes x{world}',
                    'bytes_per_env_step': m['bytes_per_step']},
         'roofline': roofline(m),

@@ -378,6 +378,59 @@ __global__ void __launch_bounds__(BSX_BLOCK) bsx_hot_stream_group_kernel(
   bsx_hot_stream_body<HotFn, K, BSX_BLOCK>(g.obs, g.state, g.n_lanes, g.cells, g.cells_magic, g.dv, g.fn, w.block);
 }
 
+// Delta observation mode (bsx_call_t.obs_paint): the observation array persists between calls and
+// already shows the hot cells of the packed state recorded in `paint`; the thread that advances a
+// lane also clears the cells that went stale and sets the new ones — at most 4 scattered 4-byte
+// stores per lane instead of the whole board, in the same launch as the advance.  The array
+// afterwards is bit-identical to the dense mode's.
+template <class HotFn>
+__device__ __forceinline__ void bsx_patch_board(float* __restrict__ board, int32_t was, int32_t now, const HotFn& fn) {
+  if (now == was) return;
+  int a0 = -1, b0 = -1, a1, b1;
+  if (was != -1) fn(was, a0, b0);
+  fn(now, a1, b1);
+  if (a0 >= 0 && a0 != a1 && a0 != b1) board[a0] = 0.0f;
+  if (b0 >= 0 && b0 != a1 && b0 != b1) board[b0] = 0.0f;
+  if (a1 >= 0 && a1 != a0 && a1 != b0) board[a1] = 1.0f;
+  if (b1 >= 0 && b1 != a0 && b1 != b0) board[b1] = 1.0f;
+}
+
+template <class Fam, class HotFn>
+__global__ void __launch_bounds__(BSX_BLOCK) bsx_advance_delta_kernel(const typename Fam::args a, const HotFn fn,
+                                                                      int32_t* __restrict__ paint, const uint32_t cells) {
+  __shared__ typename Fam::shared s_fam;
+  __shared__ unsigned int s_cnt[2];
+  if (threadIdx.x < 2) s_cnt[threadIdx.x] = 0;
+  Fam::stage(a, s_fam);
+  __syncthreads();
+  const int64_t i = (int64_t)blockIdx.x * BSX_BLOCK + threadIdx.x;
+  int type = -1;
+  if (i < a.ctl.n_lanes) {
+    const uint64_t lane = a.ctl.lane_offset + (uint64_t)i;
+    const uint64_t step = bsx_step_of(a.ctl);
+    int32_t nst; double reward;
+    const int act = a.ctl.force_reset ? 0 : a.action[i];
+    const int32_t was = paint[i];
+    type = Fam::advance(a, s_fam, i, lane, step, a.state[i], act, nst, reward);
+    a.state[i] = nst;
+    bsx_patch_board(a.out.observation + i * (int64_t)cells, was, nst, fn);
+    paint[i] = nst;
+    bsx_emit(a.ctl, a.out, i, lane, step, type, reward);
+  }
+  bsx_count_types(a.ctl, type, s_cnt);
+  __syncthreads();
+  bsx_flush_counts(a.ctl, s_cnt, blockIdx.x);
+}
+
+template <class Fam, class HotFn>
+static inline int bsx_launch_advance_delta(const typename Fam::args& a, const HotFn& fn, int32_t* paint,
+                                           uint32_t cells, hipStream_t st) {
+  const int64_t blocks = (a.ctl.n_lanes + BSX_BLOCK - 1) / BSX_BLOCK;
+  if (blocks > 0x7FFFFFFF) return BSX_EINVAL;
+  bsx_advance_delta_kernel<Fam, HotFn><<<dim3((unsigned)blocks), dim3(BSX_BLOCK), 0, st>>>(a, fn, paint, cells);
+  return 0;
+}
+
 // Degenerate boards (cells < 4: a 16-byte chunk spans several lanes): one float per thread.
 template <class HotFn>
 __global__ void __launch_bounds__(BSX_BLOCK) bsx_hot_stream_tiny_kernel(float* __restrict__ obs,

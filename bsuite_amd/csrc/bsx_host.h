@@ -9,8 +9,10 @@
 
 #include "bsx_device.h"
 
-static inline int bsx_check_call(const bsx_call_t* call, const void* action, const bsx_timestep_t& out) {
+static inline int bsx_check_call(const bsx_call_t* call, const void* action, const bsx_timestep_t& out,
+                                 bool delta_ok = false) {
   if (call == nullptr) return BSX_ENULL;
+  if (call->obs_paint != nullptr && (!delta_ok || call->n_steps > 1)) return BSX_EMODE;
   if (call->n_lanes < 0 || call->n_lanes > ((int64_t)1 << 40)) return BSX_EINVAL;
   if (call->n_lanes == 0) return 0;
   if (out.reward == nullptr || out.discount == nullptr || out.step_type == nullptr ||
@@ -183,6 +185,7 @@ static inline int bsx_group_check_set(bsx_group* g, int32_t family, int32_t inde
   if (g->committed || g->family != family || index < 0 || index >= g->n) return BSX_EINVAL;
   if (call->stream.step_base == nullptr || call->force_reset || call->n_steps > 1 || call->n_lanes < 1)
     return BSX_EINVAL;                 // static arguments need a device-resident call counter
+  if (call->obs_paint != nullptr) return BSX_EMODE;
   if (g->klass >= 0 && g->klass != klass) return BSX_EINVAL;
   g->klass = klass;
   if (g->args.empty()) {

@@ -70,7 +70,7 @@ struct catch_hot {
 static int catch_make(const bsx_catch_t* cfg, const bsx_call_t* call, const int32_t* action, int32_t* state,
                       bsx_timestep_t out, double* info, catch_fam::args* a) {
   if (cfg == nullptr) return BSX_ENULL;
-  int rc = bsx_check_call(call, action, out);
+  int rc = bsx_check_call(call, action, out, /*delta_ok=*/true);
   if (rc != 0) return rc;
   if (cfg->rows < 2 || cfg->rows > 64 || cfg->columns < 1 || cfg->columns > 64) return BSX_ERANGE;
   if (call->n_lanes > 0 && (state == nullptr || info == nullptr)) return BSX_ENULL;
@@ -96,9 +96,14 @@ extern "C" int bsx_catch_step(const bsx_catch_t* cfg, const bsx_call_t* call, co
     a.action = action ? action + off : action;
     a.out.reward = out.reward + off; a.out.discount = out.discount + off; a.out.step_type = out.step_type + off;
     a.out.observation = out.observation + off * (int64_t)cells;
-    rc = bsx_launch_advance<catch_fam>(a, st);
-    if (rc != 0) return rc;
-    rc = bsx_launch_hot_stream(a.out.observation, state, call->n_lanes, cells, bsx_div_magic(cells), fn, st, 2);
+    if (call->obs_paint != nullptr) {           // delta mode: advance + in-place patch in one launch
+      rc = bsx_launch_advance_delta<catch_fam, catch_hot>(a, fn, call->obs_paint, cells, st);
+    } else {
+      rc = bsx_launch_advance<catch_fam>(a, st);
+      if (rc != 0) return rc;
+      // stores/thread x 256 threads: a sharp optimum per family (profiles/r01/sweep_stream_*.log)
+      rc = bsx_launch_hot_stream(a.out.observation, state, call->n_lanes, cells, bsx_div_magic(cells), fn, st, 2);
+    }
     if (rc != 0) return rc;
   }
   return bsx_launch_status();

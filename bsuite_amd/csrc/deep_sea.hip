@@ -98,7 +98,7 @@ struct deep_sea_hot {
 static int deep_sea_make(const bsx_deep_sea_t* cfg, const bsx_call_t* call, const int32_t* action,
                          int32_t* state, bsx_timestep_t out, double* info, deep_sea_fam::args* a) {
   if (cfg == nullptr) return BSX_ENULL;
-  int rc = bsx_check_call(call, action, out);
+  int rc = bsx_check_call(call, action, out, /*delta_ok=*/true);
   if (rc != 0) return rc;
   if (cfg->size < 1 || cfg->size > BSX_DEEP_SEA_MAX_SIZE) return BSX_ERANGE;
   if (call->stream.mt_state != nullptr && !cfg->deterministic) return BSX_EMODE;   // needs randn
@@ -129,10 +129,14 @@ extern "C" int bsx_deep_sea_step(const bsx_deep_sea_t* cfg, const bsx_call_t* ca
     a.action = action ? action + off : action;
     a.out.reward = out.reward + off; a.out.discount = out.discount + off; a.out.step_type = out.step_type + off;
     a.out.observation = out.observation + off * (int64_t)cells;
-    rc = bsx_launch_advance<deep_sea_fam>(a, st);
-    if (rc != 0) return rc;
-    // K = 4 stores/thread x 256 threads is a sharp optimum (profiles/r01/sweep_stream_*.log)
-    rc = bsx_launch_hot_stream(a.out.observation, state, call->n_lanes, cells, bsx_div_magic(cells), fn, st, 4);
+    if (call->obs_paint != nullptr) {           // delta mode: advance + in-place patch in one launch
+      rc = bsx_launch_advance_delta<deep_sea_fam, deep_sea_hot>(a, fn, call->obs_paint, cells, st);
+    } else {
+      rc = bsx_launch_advance<deep_sea_fam>(a, st);
+      if (rc != 0) return rc;
+      // stores/thread x 256 threads: a sharp optimum per family (profiles/r01/sweep_stream_*.log)
+      rc = bsx_launch_hot_stream(a.out.observation, state, call->n_lanes, cells, bsx_div_magic(cells), fn, st, 4);
+    }
     if (rc != 0) return rc;
   }
   return bsx_launch_status();

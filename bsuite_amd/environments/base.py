@@ -50,12 +50,13 @@ class Environment(dm_env.EnvironmentBase):
   bsuite_num_episodes: int
 
   # Subclass constants.
+  _supports_delta = False  # families whose observation is a board with <= 2 hot cells
   _info_keys = ()          # names of the f64 info columns, in native column order
   _info_int_keys = ()      # keys the reference reports as Python ints
 
   def __init__(self, obs_shape, num_actions, *, seed=None, batch=None, device=None,
                lane_offset=0, num_buffers=2, device_step_counter=False, shared_step_counter=None,
-               rng='philox'):
+               rng='philox', observation_mode='dense'):
     self._scalar = batch is None
     self._batch = 1 if batch is None else int(batch)
     if self._batch < 1:
@@ -77,6 +78,16 @@ class Environment(dm_env.EnvironmentBase):
     # MT19937 + numpy's legacy samplers) in HBM, so seeded runs reproduce the reference without any
     # replay shim.  `seed` may be a sequence of B seeds; an int s seeds lane i with
     # s + i.  2.5 KB of state per lane: meant for small batches.
+    # observation_mode='delta' (deep_sea, catch): the engine keeps its observation buffers persistent
+    # and per call only clears the cells that went stale and sets the new hot cells (a few 4-byte
+    # stores per lane instead of the whole board).  The tensors returned are identical to the dense
+    # mode's; the caller must treat them as read-only.  Its throughput is reported separately from
+    # the dense contract (bench.py --observation-mode delta).
+    if observation_mode not in ('dense', 'delta'):
+      raise ValueError("observation_mode must be 'dense' or 'delta'")
+    if observation_mode == 'delta' and not self._supports_delta:
+      raise ValueError(f'{type(self).__name__} has no delta observation mode (its observations are small and dense)')
+    self._delta = observation_mode == 'delta'
     if rng not in ('philox', 'mt19937'):
       raise ValueError("rng must be 'philox' or 'mt19937'")
     self._rng_mode = rng
@@ -143,6 +154,8 @@ class Environment(dm_env.EnvironmentBase):
     self._ensure_allocated()
     if not self._device_step_counter:
       raise ValueError('grouped launches need device_step_counter / shared_step_counter')
+    if self._delta:
+      raise ValueError("grouped launches write dense observations; use observation_mode='dense'")
     call = self._call_desc
     call.force_reset, call.n_steps = 0, 0
     kind, param, wseed = self._wrap
@@ -184,11 +197,15 @@ class Environment(dm_env.EnvironmentBase):
             reward=torch.empty(B, dtype=torch.float32, **place),
             discount=torch.empty(B, dtype=torch.float32, **place),
             step_type=torch.empty(B, dtype=torch.int8, **place),
-            observation=torch.empty((B,) + self._obs_shape, dtype=torch.float32, **place))
+            observation=(torch.zeros if self._delta else torch.empty)(
+                (B,) + self._obs_shape, dtype=torch.float32, **place))
         self._out.append(o)
         self._out_ptrs.append(_native.TimeStepPtrs(
             o['reward'].data_ptr(), o['discount'].data_ptr(), o['step_type'].data_ptr(),
             o['observation'].data_ptr()))
+      # delta mode: per buffer, the packed state whose hot cells the buffer currently shows (-1: none)
+      self._paint = ([torch.full((B,), -1, dtype=torch.int32, device=dev) for _ in range(self._num_buffers)]
+                     if self._delta else None)
       self._scalar_action = torch.zeros(1, dtype=torch.int32, **place)
       self._out_np = [{k: v.numpy() for k, v in o.items()} for o in self._out] if self._host_out else None
     mt_state_ptr = mt_pos_ptr = None
@@ -219,6 +236,8 @@ class Environment(dm_env.EnvironmentBase):
   def _call(self, action_ptr: int, force_reset: bool):
     out_ptrs = self._out_ptrs[self._buf]
     out = self._out[self._buf]
+    if self._delta:
+      self._call_desc.obs_paint = self._paint[self._buf].data_ptr()
     self._buf = (self._buf + 1) % self._num_buffers
     call = self._call_desc
     call.force_reset = 1 if force_reset else 0
@@ -348,6 +367,8 @@ class Environment(dm_env.EnvironmentBase):
     overwritten by the next rollout of the same length."""
     if self._scalar:
       raise TypeError('rollout() needs the batched view (batch=B)')
+    if self._delta:
+      raise ValueError("rollout() writes T separate observation arrays; use observation_mode='dense'")
     self._ensure_allocated()
     if not torch.is_tensor(actions) or actions.dim() != 2 or actions.shape[1] != self._batch:
       raise ValueError(f'expected actions of shape (T, {self._batch})')

@@ -32,6 +32,7 @@ class Catch(base.Environment):
     return dict(state=torch.full((self._batch,), 1 << 24, dtype=torch.int32, device=self._device))
 
   _abi_name = 'catch'
+  _supports_delta = True
 
   def _native_args(self, call, action_ptr, out):
     return (ctypes.byref(self._cfg), ctypes.byref(call), action_ptr, self._state['state'].data_ptr(), out, self._info.data_ptr())

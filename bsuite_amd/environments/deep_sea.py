@@ -70,6 +70,7 @@ class DeepSea(base.Environment):
     return dict(state=torch.full((self._batch,), 1 << 17, dtype=torch.int32, device=self._device))
 
   _abi_name = 'deep_sea'
+  _supports_delta = True
 
   def _native_args(self, call, action_ptr, out):
     return (ctypes.byref(self._cfg), ctypes.byref(call), action_ptr, self._state['state'].data_ptr(), out, self._info.data_ptr())

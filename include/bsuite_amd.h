@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define BSX_ABI_VERSION 6
+#define BSX_ABI_VERSION 7
 
 #define BSX_FIRST 0
 #define BSX_MID 1
@@ -130,6 +130,18 @@ typedef struct {
                                faulting and count the event here (error word).                  */
   void* hip_stream;         /* hipStream_t                                                       */
   const bsx_logging_t* logging; /* host pointer or NULL (ABI v2)                                     */
+  int32_t* obs_paint;       /* device [B] int32 or NULL (ABI v7).  NULL: the observation array is written
+                               in full every call (dense contract).  Non-NULL selects the DELTA
+                               observation mode of deep_sea / catch (SURVEY §7 hard part 1): the
+                               caller keeps `out.observation` persistent between the calls that use it
+                               and never writes to it; obs_paint[i] is the packed state whose hot
+                               cells are currently 1.0 in lane i's board (-1: the board is all
+                               zeros, the initial value next to a zero-filled array).  The call then
+                               only clears the stale cells and sets the new ones (<= 4 four-byte
+                               stores per lane instead of 4*N*N bytes) and updates obs_paint; the
+                               array contents after the call are identical to the dense mode's.
+                               One obs_paint column per observation buffer.  Not available with
+                               n_steps > 1, in groups, or for the other families (BSX_EMODE).   */
 } bsx_call_t;
 
 /* ---- deep_sea : bsuite/environments/deep_sea.py:51-155 ------------------------------------ */
