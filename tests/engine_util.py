@@ -14,14 +14,14 @@ CTORS = dict(
     mnist=mnist.MNISTBandit)
 
 
-def make_env(family, kwargs, batch, lane_offset, seed, wrap=None, num_buffers=1):
+def make_env(family, kwargs, batch, lane_offset, seed, wrap=None, num_buffers=1, **engine_kwargs):
   import warnings
   kw = dict(kwargs)
   kw.pop('seed', None)
   with warnings.catch_warnings():
     warnings.simplefilter('ignore')
     env = CTORS[family](**kw, seed=seed, batch=batch, lane_offset=lane_offset,
-                        num_buffers=num_buffers)
+                        num_buffers=num_buffers, **engine_kwargs)
   if wrap:
     kind, param = wrap
     if kind == 'noise':

@@ -57,7 +57,11 @@ def run_case(rng, case_id):
   step0 = int(rng.choice([0, (1 << 32) - 3, (1 << 33) + 1]))
   phys = fam in ('cartpole', 'cartpole_swingup', 'mountain_car')
   by_step = bool(rng.integers(2))
-  env = eu.make_env(fam, kw, batch=B, lane_offset=off, seed=seed, wrap=wrap)
+  # deep_sea / catch: half of the cases run the delta observation mode (persistent buffers patched in
+  # place, no rollouts there), with 1-3 observation buffers
+  delta = fam in ('deep_sea', 'catch') and bool(rng.integers(2))
+  env = eu.make_env(fam, kw, batch=B, lane_offset=off, seed=seed, wrap=wrap, num_buffers=int(rng.integers(1, 4)),
+                    observation_mode='delta' if delta else 'dense')
   raw = eu.raw(env)
   raw._step_index = step0
   log = wrappers.Logging(env, None, log_by_step=by_step, max_rows=400)
@@ -70,7 +74,7 @@ def run_case(rng, case_id):
     n = 1
     if mode < 0.1:
       ts = log.reset(); force = True; acts = np.zeros((1, B), np.int32)
-    elif mode < 0.3 and not phys:
+    elif mode < 0.3 and not phys and not delta:
       n = int(rng.integers(2, 7))
       acts = rng.integers(0, orc.num_actions, size=(n, B)).astype(np.int32)
       ro = log.rollout(torch.from_numpy(acts).cuda()); force = False
@@ -98,7 +102,16 @@ def run_case(rng, case_id):
       if phys:
         same = gst == st
         assert (~same).sum() <= 1, (case_id, fam, kw, 'step_type flips', int((~same).sum()))
-        np.testing.assert_allclose(go[same], o[same], rtol=1e-6, atol=1e-6)
+        if fam == 'cartpole_swingup':
+          # obs[6], obs[7] are sign flags of |x| < x_reward_threshold, |theta_dot| < 1 (swingup:147-149):
+          # an f32 state within rounding of a threshold may flip one, like a step_type tie
+          flips = (go[..., 6:] != o[..., 6:]).reshape(len(st), -1).any(axis=1) & same
+          assert flips.sum() <= 1, (case_id, fam, kw, 'sign-flag flips', int(flips.sum()))
+          np.testing.assert_allclose(go[same][..., :6], o[same][..., :6], rtol=1e-6, atol=1e-6)
+          if flips.any():
+            return 'tie'
+        else:
+          np.testing.assert_allclose(go[same], o[same], rtol=1e-6, atol=1e-6)
         np.testing.assert_allclose(gr[live & same], r[live & same], rtol=1e-6, atol=1e-6)
         if not same.all():
           return 'tie'
