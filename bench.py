@@ -73,9 +73,8 @@ def _oracle_loop(family, kwargs, num_actions, lanes, lane0, budget_s):
 
 def cpu_baseline(family, kwargs, num_actions, budget_s=12.0, all_cores_budget_s=4.0):
   """The oracle (C restatement of the reference's numpy step) on ONE host core, bounded sample; plus
-  the same loop on every host core at once (one OracleEnv per thread; the C call drops the GIL) —
+  the same loop on every host core at once (one process per core, each with its own OracleEnv) —
   the analogue of the reference's one-process-per-bsuite_id pool (bsuite/baselines/utils/pool.py:48)."""
-  import threading
   lanes = 4096
   steps, dt = _oracle_loop(family, kwargs, num_actions, lanes, 0, budget_s)
   out = dict(value=steps / dt, unit='env-steps/s', cores=1, kind='port',
@@ -83,16 +82,28 @@ def cpu_baseline(family, kwargs, num_actions, budget_s=12.0, all_cores_budget_s=
                     f'oracle/oracle.c (gcc -O2, single thread, {dt:.1f} s)')
   cores = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
   if cores > 1 and all_cores_budget_s > 0:
-    res = [None] * cores
-    def work(j):
-      res[j] = _oracle_loop(family, kwargs, num_actions, lanes, (j + 1) * lanes, all_cores_budget_s)
+    # one PROCESS per core (threads would serialise on the interpreter lock between the short C calls)
+    import subprocess
+    code = ('import sys, json; sys.path.insert(0, %r); import bench; '
+            'f, kw, na, lanes, lane0, b = sys.argv[1], json.loads(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4]), '
+            'int(sys.argv[5]), float(sys.argv[6]); print(*bench._oracle_loop(f, kw, na, lanes, lane0, b))' % ROOT)
     t0 = time.perf_counter()
-    ths = [threading.Thread(target=work, args=(j,)) for j in range(cores)]
-    for th in ths: th.start()
-    for th in ths: th.join()
+    procs = [subprocess.Popen([sys.executable, '-c', code, family, json.dumps(kwargs), str(num_actions), str(lanes),
+                               str((j + 1) * lanes), str(all_cores_budget_s)],
+                              stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True) for j in range(cores)]
+    res = []
+    for pr in procs:
+      o, _ = pr.communicate()
+      try:
+        a, b = o.split()
+        res.append((float(a), float(b)))
+      except ValueError:
+        pass
     wall = time.perf_counter() - t0
-    out['all_cores'] = dict(value=sum(r[0] for r in res) / max(r[1] for r in res), cores=cores,
-                            sample=f'{cores} threads x {lanes} lanes, {wall:.1f} s wall')
+    if res:
+      out['all_cores'] = dict(value=sum(r[0] for r in res) / max(r[1] for r in res), cores=len(res),
+                              sample=f'{len(res)} processes x {lanes} lanes x {all_cores_budget_s:.0f} s each, '
+                                     f'{wall:.1f} s wall incl. start-up')
   return out
 
 
