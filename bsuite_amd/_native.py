@@ -12,7 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 SO_PATH = os.path.join(_HERE, '_lib', 'libbsuite_amd.so')
 
 FIRST, MID, LAST = 0, 1, 2
-BSX_EINVAL, BSX_ENULL, BSX_EALIGN, BSX_ERANGE, BSX_EMODE = -1, -2, -3, -4, -5
+BSX_EINVAL, BSX_ENULL, BSX_EALIGN, BSX_ERANGE, BSX_EMODE, BSX_ENOMEM = -1, -2, -3, -4, -5, -6
 WRAP_NONE, WRAP_SCALE, WRAP_NOISE = 0, 1, 2
 COUNTER_SHARDS, COUNTER_STRIDE = 256, 16
 DEEP_SEA_MAX_SIZE = 64

@@ -11,7 +11,8 @@ extern "C" const char* bsx_strerror(int code) {
     case BSX_ENULL: return "required pointer is NULL";
     case BSX_EALIGN: return "observation buffer is not 16-byte aligned";
     case BSX_ERANGE: return "parameter outside the supported range of this family";
-    case BSX_EMODE: return "not available in MT19937-exact mode (RewardNoise / stochastic deep_sea need randn)";
+    case BSX_EMODE: return "combination not available (randn in MT19937-exact mode; obs_paint with a rollout, a group or a family without a board)";
+    case BSX_ENOMEM: return "host allocation failed";
     default: return code > 0 ? hipGetErrorString((hipError_t)code) : "unknown bsx error";
   }
 }
@@ -79,11 +80,25 @@ extern "C" int bsx_stream_dump(uint64_t seed, uint64_t lane0, int64_t n_lanes, u
 extern "C" int bsx_group_create(int32_t family, int32_t n_segments, bsx_group_t** group) {
   if (group == nullptr) return BSX_ENULL;
   if (family < BSX_FAM_DEEP_SEA || family > BSX_FAM_SMALL_MIXED || n_segments < 1 || n_segments > (1 << 20)) return BSX_EINVAL;
-  bsx_group* g = new bsx_group();
-  g->family = family; g->n = n_segments;
-  g->blocks.assign(n_segments, 0); g->blocks2.assign(n_segments, 0); g->is_set.assign(n_segments, 0);
+  bsx_group* g = nullptr;
+  try {                                   // no C++ exception may cross the C boundary
+    g = new bsx_group();
+    g->family = family; g->n = n_segments;
+    g->blocks.assign(n_segments, 0); g->blocks2.assign(n_segments, 0); g->is_set.assign(n_segments, 0);
+  } catch (...) {
+    delete g;
+    return BSX_ENOMEM;
+  }
   *group = g;
   return 0;
+}
+
+static void group_free_device(bsx_group* g) {
+  void** ptrs[] = {&g->d_args, &g->d_args2, (void**)&g->d_start, (void**)&g->d_start2, (void**)&g->d_map, (void**)&g->d_map2};
+  for (void** p : ptrs) {
+    if (*p) (void)hipFree(*p);
+    *p = nullptr;
+  }
 }
 
 static int upload(const void* src, size_t bytes, void** dst) {
@@ -93,9 +108,22 @@ static int upload(const void* src, size_t bytes, void** dst) {
   return (int)hipMemcpy(*dst, src, bytes, hipMemcpyHostToDevice);
 }
 
+static int group_commit(bsx_group* g);
+
 extern "C" int bsx_group_commit(bsx_group_t* g) {
   if (g == nullptr) return BSX_ENULL;
   if (g->committed || g->launch == nullptr) return BSX_EINVAL;
+  int rc;
+  try {
+    rc = group_commit(g);
+  } catch (...) {
+    rc = BSX_ENOMEM;
+  }
+  if (rc != 0) group_free_device(g);      // a failed commit leaves nothing behind and may be retried
+  return rc;
+}
+
+static int group_commit(bsx_group* g) {
   for (int i = 0; i < g->n; ++i) if (!g->is_set[i]) return BSX_EINVAL;
   std::vector<int32_t> start(g->n + 1, 0), start2(g->n + 1, 0);
   int64_t t1 = 0, t2 = 0;
@@ -136,12 +164,7 @@ extern "C" int bsx_group_step(bsx_group_t* g, void* hip_stream) {
 
 extern "C" int bsx_group_destroy(bsx_group_t* g) {
   if (g == nullptr) return 0;
-  if (g->d_args) (void)hipFree(g->d_args);
-  if (g->d_args2) (void)hipFree(g->d_args2);
-  if (g->d_start) (void)hipFree(g->d_start);
-  if (g->d_start2) (void)hipFree(g->d_start2);
-  if (g->d_map) (void)hipFree(g->d_map);
-  if (g->d_map2) (void)hipFree(g->d_map2);
+  group_free_device(g);
   delete g;
   return 0;
 }

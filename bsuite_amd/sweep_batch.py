@@ -132,6 +132,7 @@ class SweepBatch:
     from bsuite_amd import _native  # pylint: disable=import-outside-toplevel
     from bsuite_amd import dm_env_compat as dm_env  # pylint: disable=import-outside-toplevel
     self.release_groups()
+    torch.cuda.set_device(self.device)       # the argument tables are allocated on the current device
     buckets = {}
     for k, env in enumerate(self.envs):
       raw = env.raw_env if hasattr(env, 'raw_env') else env

@@ -37,7 +37,8 @@ extern "C" {
 #define BSX_ENULL (-2)      /* a required pointer is NULL                          */
 #define BSX_EALIGN (-3)     /* observation pointer not 16-byte aligned             */
 #define BSX_ERANGE (-4)     /* parameter outside the supported range of the family */
-#define BSX_EMODE (-5)      /* combination not available in MT19937-exact mode (needs randn) */
+#define BSX_EMODE (-5)      /* combination not available (randn in MT19937-exact mode, obs_paint with a rollout / group / other family) */
+#define BSX_ENOMEM (-6)     /* host allocation failed (group bookkeeping)          */
 
 /* Random stream coordinates of one call (include/bsx_stream.h).  The reference gives every env its
  * own np.random.RandomState (e.g. deep_sea.py:77, catch.py:58); here a lane's draws are a pure
