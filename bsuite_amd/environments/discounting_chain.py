@@ -15,17 +15,15 @@ class DiscountingChain(base.Environment):
   """Five chains paying at t in {1,3,10,30,100}; one pays 10% more (discounting_chain.py:37-61)."""
 
   def __init__(self, mapping_seed: Optional[int] = None, **engine_kwargs):
-    super().__init__(obs_shape=(1, 2), num_actions=5, **engine_kwargs)
-    self._episode_len = 100
-    self._reward_timestep = [1, 3, 10, 30, 100]
-    self._n_actions = len(self._reward_timestep)
-    if mapping_seed is None:
-      mapping_seed = np.random.randint(0, self._n_actions)
-    else:
-      mapping_seed = mapping_seed % self._n_actions
-    self._rewards = np.ones(self._n_actions)
-    self._rewards[mapping_seed] += 0.1
-    self._cfg = _native.DiscountingChainCfg(int(mapping_seed), 0)
+    pay_times = (1, 3, 10, 30, 100)                  # discounting_chain.py:49
+    super().__init__(obs_shape=(1, 2), num_actions=len(pay_times), **engine_kwargs)
+    # the chain that pays 10 % more: mapping_seed mod 5, a host-side random pick when unseeded (:50-58)
+    bonus = int(np.random.randint(0, len(pay_times))) if mapping_seed is None else int(mapping_seed) % len(pay_times)
+    rewards = np.ones(len(pay_times))
+    rewards[bonus] += 0.1
+    self._reward_timestep, self._n_actions, self._episode_len = list(pay_times), len(pay_times), pay_times[-1]
+    self._rewards = rewards
+    self._cfg = _native.DiscountingChainCfg(bonus, 0)
     self.bsuite_num_episodes = NUM_EPISODES
 
   def _state_tensors(self):

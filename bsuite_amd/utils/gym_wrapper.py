@@ -108,48 +108,54 @@ class GymFromDMEnv(_EnvBase):
       return self.viewer.isopen
     return None
 
+  @staticmethod
+  def _bounds(spec):
+    """(low, high) of a spec: its own bounds when it has them, else the whole real line."""
+    if isinstance(spec, specs.BoundedArray):
+      return spec.minimum, spec.maximum
+    return -float('inf'), float('inf')
+
+  @property
+  def observation_space(self):
+    spec = self._env.observation_spec()
+    lo, hi = self._bounds(spec)
+    return spaces.Box(low=float(lo), high=float(hi), shape=spec.shape, dtype=spec.dtype)
+
   @property
   def action_space(self):
     return spaces.Discrete(self._env.action_spec().num_values)
 
   @property
-  def observation_space(self):
-    spec = self._env.observation_spec()
-    lo, hi = -float('inf'), float('inf')
-    if isinstance(spec, specs.BoundedArray):
-      lo, hi = float(spec.minimum), float(spec.maximum)
-    return spaces.Box(low=lo, high=hi, shape=spec.shape, dtype=spec.dtype)
-
-  @property
   def reward_range(self) -> Tuple[float, float]:
-    spec = self._env.reward_spec()
-    if isinstance(spec, specs.BoundedArray):
-      return spec.minimum, spec.maximum
-    return -float('inf'), float('inf')
+    return self._bounds(self._env.reward_spec())
 
   def __getattr__(self, attr):
     """Delegate attribute access to underlying environment."""
     return getattr(self._env, attr)
 
 
+def _bounded(space, lo, hi, name):
+  return specs.BoundedArray(shape=space.shape, dtype=space.dtype, minimum=lo, maximum=hi, name=name)
+
+
+# gym space class name -> spec constructor (gym_wrapper.py:103-139); dispatch is by NAME so that gym's
+# classes and the stand-ins above are treated alike.
+_SPACE_TO_SPEC = {
+    'Discrete': lambda sp, name: specs.DiscreteArray(num_values=sp.n, dtype=sp.dtype, name=name),
+    'Box': lambda sp, name: _bounded(sp, sp.low, sp.high, name),
+    'MultiBinary': lambda sp, name: _bounded(sp, 0.0, 1.0, name),
+    'MultiDiscrete': lambda sp, name: _bounded(sp, np.zeros(sp.shape), sp.nvec, name),
+    'Tuple': lambda sp, name: tuple(space2spec(child, name) for child in sp.spaces),
+    'Dict': lambda sp, name: {key: space2spec(child, name) for key, child in sp.spaces.items()},
+}
+
+
 def space2spec(space, name: Optional[str] = None):
-  """gym space -> dm_env spec (nested for Tuple / Dict spaces), gym_wrapper.py:103-139."""
-  kind = type(space).__name__.lstrip('_')
-  if kind == 'Discrete':
-    return specs.DiscreteArray(num_values=space.n, dtype=space.dtype, name=name)
-  if kind == 'Box':
-    return specs.BoundedArray(shape=space.shape, dtype=space.dtype, minimum=space.low,
-                              maximum=space.high, name=name)
-  if kind == 'MultiBinary':
-    return specs.BoundedArray(shape=space.shape, dtype=space.dtype, minimum=0.0, maximum=1.0, name=name)
-  if kind == 'MultiDiscrete':
-    return specs.BoundedArray(shape=space.shape, dtype=space.dtype, minimum=np.zeros(space.shape),
-                              maximum=space.nvec, name=name)
-  if kind == 'Tuple':
-    return tuple(space2spec(s, name) for s in space.spaces)
-  if kind == 'Dict':
-    return {k: space2spec(v, name) for k, v in space.spaces.items()}
-  raise ValueError('Unexpected gym space: {}'.format(space))
+  """gym space -> dm_env spec; Tuple / Dict spaces map to nested tuples / dicts of specs."""
+  convert = _SPACE_TO_SPEC.get(type(space).__name__.lstrip('_'))
+  if convert is None:
+    raise ValueError('Unexpected gym space: {}'.format(space))
+  return convert(space, name)
 
 
 class DMEnvFromGym(dm_env.EnvironmentBase):
@@ -157,9 +163,15 @@ class DMEnvFromGym(dm_env.EnvironmentBase):
 
   def __init__(self, gym_env):
     self.gym_env = gym_env
-    self._observation_spec = space2spec(gym_env.observation_space, name='observations')
-    self._action_spec = space2spec(gym_env.action_space, name='actions')
-    self._reset_next_step = True
+    self._specs = (space2spec(gym_env.observation_space, name='observations'),
+                   space2spec(gym_env.action_space, name='actions'))
+    self._reset_next_step = True      # like every bsuite environment, the first step() is a reset
+
+  def observation_spec(self):
+    return self._specs[0]
+
+  def action_spec(self):
+    return self._specs[1]
 
   def reset(self):
     self._reset_next_step = False
@@ -169,18 +181,12 @@ class DMEnvFromGym(dm_env.EnvironmentBase):
     if self._reset_next_step:
       return self.reset()
     observation, reward, done, info = self.gym_env.step(action)
-    self._reset_next_step = done
+    self._reset_next_step = bool(done)
     if not done:
       return dm_env.transition(reward, observation)
-    if info.get('TimeLimit.truncated', False):
-      return dm_env.truncation(reward, observation)
-    return dm_env.termination(reward, observation)
+    # a time-limit cut keeps the discount at 1 (truncation), a real end of episode sets it to 0
+    ended = dm_env.truncation if info.get('TimeLimit.truncated', False) else dm_env.termination
+    return ended(reward, observation)
 
   def close(self):
     self.gym_env.close()
-
-  def observation_spec(self):
-    return self._observation_spec
-
-  def action_spec(self):
-    return self._action_spec
