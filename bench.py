@@ -193,6 +193,8 @@ def main():
   ap.add_argument('--workload', default='deep_sea', choices=sorted(WORKLOADS) + ['sweep'])
   ap.add_argument('--lanes', type=int, default=1 << 20, help='lanes per GPU')
   ap.add_argument('--no-cpu-baseline', action='store_true')
+  ap.add_argument('--logging', action='store_true',
+                  help='wrap the environment in the batched Logging wrapper (bookkeeping fused into the kernels)')
   ap.add_argument('--observation-mode', default='dense', choices=['dense', 'delta'],
                   help="'delta' (deep_sea, catch): persistent observation buffers patched in place; a "
                        'separate mode with its own byte accounting, NOT the dense contract of the headline')
@@ -242,6 +244,11 @@ def main():
     env = bsuite_amd.load_from_id(bsuite_id, batch=B, device=dev, seed=42, lane_offset=rank * B,
                                   num_buffers=2, device_step_counter=bool(args.graph),
                                   observation_mode=args.observation_mode)
+    if args.logging:
+      # the Logging wrapper's per-lane bookkeeping + log-spaced snapshot rows, fused
+      # into the same kernels (no logger object: rows stay in the device buffer)
+      from bsuite_amd.utils import wrappers as _wrappers
+      env = _wrappers.Logging(env, None)
     num_actions = env.action_spec().num_values
     gen = torch.Generator(device=dev)
     gen.manual_seed(1234 + rank)
@@ -352,7 +359,7 @@ def main():
         'config': {'workload': f"{m['bsuite_id']} ({m['family']} {m['okw']}) random-action rollout, "
                                + ('dense TimeStep' if args.observation_mode == 'dense' else
                                   'DELTA observation mode (persistent buffers patched in place; not the dense contract)'),
-                   'observation_mode': args.observation_mode,
+                   'observation_mode': args.observation_mode, 'logging_wrapper': bool(args.logging),
                    'lanes_per_gpu': B, 'global_lanes': B * world, 'sharding': f'lanes x{world}',
                    'bytes_per_env_step': m['bytes_per_step']},
         'roofline': roofline(m),
