@@ -33,7 +33,15 @@ WORKLOADS = {
     'memory_len': ('memory_len/10', 'memory_chain', dict(memory_length=12, num_bits=1), 3, 24),
     'umbrella_length': ('umbrella_length/10', 'umbrella_chain', dict(chain_length=12, n_distractor=20), 23, 8),
     'discounting_chain': ('discounting_chain/0', 'discounting_chain', dict(mapping_seed=0), 2, 8),
+    # the MNIST files cannot be fetched here: tests/golden/mnist_synthetic_dataset.npz (same idx wire format)
+    'mnist': ('mnist/0', 'mnist', dict(), 784, 8),
 }
+
+
+def _synthetic_mnist():
+  import numpy as np
+  d = np.load(os.path.join(ROOT, 'tests', 'golden', 'mnist_synthetic_dataset.npz'))
+  return d['images_u8'].view(np.int8), d['labels']
 
 
 def algorithmic_bytes_per_step(obs_numel, state_bytes):
@@ -57,6 +65,9 @@ def _oracle_loop(family, kwargs, num_actions, lanes, lane0, budget_s):
   """Steps one OracleEnv (its own lanes) for budget_s seconds; returns (env-steps, seconds)."""
   import numpy as np
   from oracle import coracle
+  if family == 'mnist' and 'images' not in kwargs:
+    kwargs = dict(kwargs)
+    kwargs['images'], kwargs['labels'] = _synthetic_mnist()
   env = coracle.OracleEnv(family, kwargs, np.arange(lane0, lane0 + lanes, dtype=np.uint64), seed=42)
   rng = np.random.default_rng(lane0)
   acts = rng.integers(0, num_actions, size=(64, lanes)).astype(np.int32)
@@ -241,9 +252,12 @@ def main():
     delta = args.observation_mode == 'delta'
     if delta and family not in ('deep_sea', 'catch'):
       raise SystemExit('--observation-mode delta exists for deep_sea and catch only')
+    extra = {}
+    if family == 'mnist':
+      extra['images'], extra['labels'] = _synthetic_mnist()
     env = bsuite_amd.load_from_id(bsuite_id, batch=B, device=dev, seed=42, lane_offset=rank * B,
                                   num_buffers=2, device_step_counter=bool(args.graph),
-                                  observation_mode=args.observation_mode)
+                                  observation_mode=args.observation_mode, **extra)
     if args.logging:
       # the Logging wrapper's per-lane bookkeeping + log-spaced snapshot rows, fused
       # into the same kernels (no logger object: rows stay in the device buffer)
@@ -303,7 +317,10 @@ def main():
                             device=dev if dist.get_backend() == 'nccl' else 'cpu')
       dist.all_reduce(t_wall, op=dist.ReduceOp.MAX)
       wall, kernel_ms = float(t_wall[0].item()), float(t_wall[1].item())
-    bytes_per_step = algorithmic_bytes_per_step(obs_numel, state_bytes)
+    # state in/out counts once per T fused steps; only the small-observation families
+    # fuse a rollout into one launch (their state then stays in L2 between the T steps)
+    fused_T = args.rollout if (args.rollout and family not in ('deep_sea', 'catch', 'mnist')) else 1
+    bytes_per_step = algorithmic_bytes_per_step(obs_numel, state_bytes / fused_T)
     if delta:
       # ACTUAL bytes of the delta mode (reported separately, never against the dense
       # contract): scalars + state in/out + paint column in/out + the 4-byte cell stores
