@@ -203,6 +203,9 @@ def main():
   ap.add_argument('--warmup', type=int, default=20)
   ap.add_argument('--workload', default='deep_sea', choices=sorted(WORKLOADS) + ['sweep'])
   ap.add_argument('--lanes', type=int, default=1 << 20, help='lanes per GPU')
+  ap.add_argument('--strong', action='store_true',
+                  help='strong scaling (SURVEY §8d): --lanes is the GLOBAL lane count, split evenly over the ranks '
+                       '(default: weak scaling, --lanes per GPU)')
   ap.add_argument('--no-cpu-baseline', action='store_true')
   ap.add_argument('--logging', action='store_true',
                   help='wrap the environment in the batched Logging wrapper (bookkeeping fused into the kernels)')
@@ -222,6 +225,10 @@ def main():
   import bsuite_amd
 
   world = int(os.environ.get('WORLD_SIZE', '1'))
+  if args.strong and args.workload != 'sweep':
+    if args.lanes % world:
+      raise SystemExit('--strong needs --lanes divisible by the number of ranks')
+    args.lanes //= world
   rank = int(os.environ.get('RANK', '0'))
   local_rank = int(os.environ.get('LOCAL_RANK', '0'))
   # Test hooks (single-GPU boxes): BSX_BENCH_BACKEND=gloo + BSX_BENCH_SINGLE_DEVICE=1 run all ranks
@@ -370,7 +377,7 @@ def main():
     line = {
         'metric': 'env-steps/sec', 'value': m['value'], 'unit': 'env-steps/s',
         'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
-        'ms_per_step': m['wall'] / args.steps * 1e3, 'higher_is_better': True, 'scaling': 'weak',
+        'ms_per_step': m['wall'] / args.steps * 1e3, 'higher_is_better': True, 'scaling': 'strong' if args.strong else 'weak',
         'vs_baseline': None, 'dtype': 'f32' if m['family'] in ('cartpole', 'mountain_car') else 'int32',
         'data': 'synthetic',
         'config': {'workload': f"{m['bsuite_id']} ({m['family']} {m['okw']}) random-action rollout, "
