@@ -10,6 +10,8 @@
 //   observe  bsx_hot_stream_kernel<deep_sea_hot,4,256>: a pure store stream over [B x N*N] f32 —
 //            block b writes floats [b*4096,(b+1)*4096) as 4 lane-interleaved 16-byte stores per
 //            thread, hot cells recomputed from the packed state column (4 B/lane, L2-resident).
+// (With bsx_call_t.obs_paint — the delta observation mode — the call is ONE launch instead,
+//  bsx_advance_delta_kernel: the advancing thread patches its lane's persistent board in place.)
 // Decoupling the two is what makes the store stream fast: single-kernel variants that advance
 // lanes, synchronise and then store (per-block 230 KB tiles, or flat 16 KiB runs with ping-pong
 // state) measured 5.1-5.5 TB/s against 6.2-6.4 TB/s for this pair (profiles/r01/ab_*.log).
