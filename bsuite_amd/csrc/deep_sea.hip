@@ -65,8 +65,15 @@ struct deep_sea_fam {
       if (!a.deterministic && row == N - 1 && (col == 0 || col == N - 1))   // :124-126
         reward += bsx_normal(&d);
       if (right) {                                              // :129-132
-        const double u = bsx_uniform(&d);                       // drawn even when deterministic
-        if (u > a.inv_size || a.deterministic) col = col + 1 > N - 1 ? N - 1 : col + 1;
+        // The reference draws rand() here even when deterministic (the value is then unused).  The
+        // counter-based stream restarts at every call, so an unused draw leaves no trace and is
+        // skipped; the lane's own MT19937 generator (exact mode) must advance, so there it is drawn.
+        bool moves = true;
+        if (!a.deterministic || a.ctl.mt_state != nullptr) {
+          const double u = bsx_uniform(&d);
+          moves = (u > a.inv_size) || a.deterministic;
+        }
+        if (moves) col = col + 1 > N - 1 ? N - 1 : col + 1;
         reward -= a.move_cost;
       } else {                                                  // :133-136
         if (row == col) bad = 1;
