@@ -62,6 +62,8 @@ class Environment(dm_env.EnvironmentBase):
     if self._batch < 1:
       raise ValueError('batch must be >= 1')
     self._device = torch.device('cuda:0' if device is None else device)
+    if self._device.type == 'cuda' and self._device.index is None:
+      self._device = torch.device('cuda', torch.cuda.current_device() if torch.cuda.is_available() else 0)
     self._lane_offset = int(lane_offset)
     self._seed = _resolve_seed(seed if seed is None or isinstance(seed, (int, np.integer)) else 0)
     self._obs_shape = tuple(int(d) for d in obs_shape)
@@ -234,6 +236,11 @@ class Environment(dm_env.EnvironmentBase):
   # ----------------------------------------------------------------------------------------
   # the hot path
   def _call(self, action_ptr: int, force_reset: bool):
+    if torch.cuda.current_device() != self._device.index:
+      # kernels launch in the current device's context: step an environment that lives elsewhere
+      # (several GPUs driven from one process) under its own device
+      with torch.cuda.device(self._device):
+        return self._call(action_ptr, force_reset)
     out_ptrs = self._out_ptrs[self._buf]
     out = self._out[self._buf]
     if self._delta:
@@ -367,6 +374,9 @@ class Environment(dm_env.EnvironmentBase):
     overwritten by the next rollout of the same length."""
     if self._scalar:
       raise TypeError('rollout() needs the batched view (batch=B)')
+    if torch.cuda.is_available() and torch.cuda.current_device() != self._device.index:
+      with torch.cuda.device(self._device):
+        return self.rollout(actions)
     if self._delta:
       raise ValueError("rollout() writes T separate observation arrays; use observation_mode='dense'")
     self._ensure_allocated()
