@@ -1,14 +1,25 @@
 """bench.py — env-steps/sec of the batched bsuite step() path on MI355X.
 
-  python bench.py [--gpus N] [--steps K] [--warmup W] [--workload deep_sea|catch|...] [--lanes B]
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--workload deep_sea|catch|...|sweep] [--lanes B]
 
 One "step" = one env.step(actions) call on every lane of the batch (auto-reset calls included,
 they are real API calls: bsuite/environments/base.py:61-62).  Default workload is BASELINE.json
 configs[1]: deep_sea size=30 (bsuite_id deep_sea/10), 2^20 lanes per GPU, uniform random actions
 pre-generated on the device (the batched analogue of bsuite/baselines/random/agent.py:35-37).
-Every TimeStep field is materialised in HBM on every step (dense contract).  For N>1 the driver
-launches one process per GPU (torch.distributed, backend nccl = RCCL); lanes shard with no
+Every TimeStep field is materialised in HBM on every step (dense contract).  Before the warm-up the
+lanes are put at staggered episode phases, so that every timed call carries the steady-state mix of
+FIRST / MID / LAST lanes whatever K is.
+
+The default line also carries the other BASELINE configs as sub-records under "also": catch/0
+(configs[2]), cartpole/0 and mountain_car/0 (configs[3]; eager step(), a HIP graph of 16 step()
+launches, and the fused rollout(T=16)), and the 468-id sweep (configs[4]).
+
+Multi-GPU: one process per GPU (torch.distributed, backend nccl = RCCL); lanes shard with no
 data-path collective; the only collective is the end-of-rollout all-gather of per-rank summaries.
+Either launch the ranks yourself (`python -m torch.distributed.run --nproc-per-node N bench.py
+--gpus N`), or run `python bench.py --gpus N` and this script spawns them itself (the reference's
+own parallel entry is self-launching too: bsuite/baselines/utils/pool.py:28-54).  With N > 1 the
+main record is weak scaling (2^20 lanes per GPU); "strong" sub-records split 2^20 lanes over the ranks.
 Prints ONE JSON line on rank 0.
 """
 import argparse
@@ -23,18 +34,19 @@ if ROOT not in sys.path:
 
 HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
 
-# workload -> (bsuite_id, oracle family, oracle kwargs, obs_numel, state bytes in+out per lane)
+# workload -> (bsuite_id, oracle family, oracle kwargs, obs_numel, state bytes in+out per lane,
+#              episode period in calls used to stagger the lanes' phases)
 WORKLOADS = {
-    'deep_sea': ('deep_sea/10', 'deep_sea', dict(size=30, mapping_seed=42), 900, 8),
-    'catch': ('catch/0', 'catch', dict(), 50, 8),
-    'cartpole': ('cartpole/0', 'cartpole', dict(), 6, 48),
-    'mountain_car': ('mountain_car/0', 'mountain_car', dict(), 3, 24),
-    'bandit': ('bandit/0', 'bandit', dict(mapping_seed=0), 1, 8),
-    'memory_len': ('memory_len/10', 'memory_chain', dict(memory_length=12, num_bits=1), 3, 24),
-    'umbrella_length': ('umbrella_length/10', 'umbrella_chain', dict(chain_length=12, n_distractor=20), 23, 8),
-    'discounting_chain': ('discounting_chain/0', 'discounting_chain', dict(mapping_seed=0), 2, 8),
+    'deep_sea': ('deep_sea/10', 'deep_sea', dict(size=30, mapping_seed=42), 900, 8, 31),
+    'catch': ('catch/0', 'catch', dict(), 50, 8, 10),
+    'cartpole': ('cartpole/0', 'cartpole', dict(), 6, 48, 128),
+    'mountain_car': ('mountain_car/0', 'mountain_car', dict(), 3, 24, 1001),
+    'bandit': ('bandit/0', 'bandit', dict(mapping_seed=0), 1, 8, 2),
+    'memory_len': ('memory_len/10', 'memory_chain', dict(memory_length=12, num_bits=1), 3, 24, 14),
+    'umbrella_length': ('umbrella_length/10', 'umbrella_chain', dict(chain_length=12, n_distractor=20), 23, 8, 13),
+    'discounting_chain': ('discounting_chain/0', 'discounting_chain', dict(mapping_seed=0), 2, 8, 101),
     # the MNIST files cannot be fetched here: tests/golden/mnist_synthetic_dataset.npz (same idx wire format)
-    'mnist': ('mnist/0', 'mnist', dict(), 784, 8),
+    'mnist': ('mnist/0', 'mnist', dict(), 784, 8, 2),
 }
 
 
@@ -61,6 +73,7 @@ def pmc_traffic(workload, lanes):
   return d['per_launch']['hbm_bytes'], os.path.relpath(hits[-1], ROOT)
 
 
+# ------------------------------------------------------------------------------------ CPU baselines
 def _oracle_loop(family, kwargs, num_actions, lanes, lane0, budget_s):
   """Steps one OracleEnv (its own lanes) for budget_s seconds; returns (env-steps, seconds)."""
   import numpy as np
@@ -82,15 +95,15 @@ def _oracle_loop(family, kwargs, num_actions, lanes, lane0, budget_s):
   return lanes * n, time.perf_counter() - t0
 
 
-def cpu_baseline(family, kwargs, num_actions, budget_s=12.0, all_cores_budget_s=4.0):
-  """The oracle (C restatement of the reference's numpy step) on ONE host core, bounded sample; plus
-  the same loop on every host core at once (one process per core, each with its own OracleEnv) —
-  the analogue of the reference's one-process-per-bsuite_id pool (bsuite/baselines/utils/pool.py:48)."""
+def cpu_port_baseline(family, kwargs, num_actions, budget_s=12.0, all_cores_budget_s=4.0):
+  """The oracle (C restatement of the reference's numpy step) on ONE host core of THIS box, bounded
+  sample; plus the same loop on every host core at once (one process per core, each with its own
+  OracleEnv) — the analogue of the reference's one-process-per-bsuite_id pool (pool.py:48)."""
   lanes = 4096
   steps, dt = _oracle_loop(family, kwargs, num_actions, lanes, 0, budget_s)
   out = dict(value=steps / dt, unit='env-steps/s', cores=1, kind='port',
              sample=f'{lanes} lanes x {steps // lanes} step() calls of {family} {kwargs} through '
-                    f'oracle/oracle.c (gcc -O2, single thread, {dt:.1f} s)')
+                    f'oracle/oracle.c (gcc -O2, single thread, {dt:.1f} s) on this box')
   cores = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
   if cores > 1 and all_cores_budget_s > 0:
     # one PROCESS per core (threads would serialise on the interpreter lock between the short C calls)
@@ -118,82 +131,451 @@ def cpu_baseline(family, kwargs, num_actions, budget_s=12.0, all_cores_budget_s=
   return out
 
 
-def bench_sweep(args, torch, dist, dev, rank, world):
-  """BASELINE config 5: all 468 bsuite_ids as lane segments (2^20 lanes in total, split evenly per id,
-  whole segments bin-packed over the ranks), one captured HIP graph per sweep step."""
-  import tempfile
-  import numpy as np
-  from bsuite_amd import sweep_batch as sb
-  from bsuite_amd.utils import datasets
-  d = np.load(os.path.join(ROOT, 'tests', 'golden', 'mnist_synthetic_dataset.npz'))
-  tmp = tempfile.mkdtemp(prefix='bsx_mnist_')
-  datasets.write_idx_files(tmp, d['images_u8'], d['labels'])      # synthetic stand-in (no network)
-  mn = dict(data_dir=tmp)
-  batch = sb.SweepBatch(None, args.lanes, device=dev, seed=42, rank=rank, world_size=world,
-                        num_streams=int(os.environ.get('BSX_SWEEP_STREAMS', '32')),
-                        env_kwargs=dict(mnist=mn, mnist_noise=mn, mnist_scale=mn))
-  acts = batch.random_actions(seed=1 + rank)
-  mode = os.environ.get('BSX_SWEEP_MODE', 'grouped_graph')
-  grouped = mode in ('grouped', 'grouped_graph')
-  if grouped:
-    batch.prepare_groups(acts, mix_small=os.environ.get('BSX_SWEEP_MIX_SMALL', '1') != '0')
-    if mode == 'grouped_graph':              # group launches as concurrent branches of one HIP graph
-      batch.capture_grouped(int(os.environ.get('BSX_SWEEP_STREAMS', '2')))
-      batch.replay = batch.replay_grouped
+def cpu_baseline(bsuite_id, family, kwargs, num_actions):
+  """`cpu_baseline` of the JSON line.  The reference's own numpy path (`kind: "reference"`) is the
+  unmodified bsuite package timed by tools/cpu_reference_numpy.py in the build container — it cannot
+  travel to the GPU box (no /root/reference there), so its numbers are read from the committed
+  profiles/rNN/cpu_reference_numpy.json with the measuring host stated; the C port of the same step
+  is timed live on this box's cores and reported under "port"."""
+  import glob
+  port = cpu_port_baseline(family, kwargs, num_actions)
+  hits = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*', 'cpu_reference_numpy.json')))
+  if not hits:
+    return port
+  with open(hits[-1]) as f:
+    d = json.load(f)
+  rec = d['results'].get(bsuite_id)
+  if rec is None:
+    return port
+  one, allc = rec['single_core'], rec['all_cores']
+  return dict(
+      value=one['value'], unit='env-steps/s', cores=1, kind='reference',
+      sample=f"unmodified reference bsuite.load_from_id('{bsuite_id}') + inlined random agent, {one['calls']} "
+             f"reset()/step() calls in {one['seconds']:.1f} s on one core",
+      provenance=dict(file=os.path.relpath(hits[-1], ROOT), script=d['script'], host=d['host'],
+                      note='measured in the build container: the reference tree cannot travel to the GPU box; '
+                           'the live same-box CPU number is "port"'),
+      all_cores=dict(value=allc['value'], cores=allc['cores'],
+                     sample=f"{allc['cores']} processes (one reference env each, pool.py:35,48 style), {allc['seconds']:.1f} s"),
+      port=port)
+
+
+# ------------------------------------------------------------------------------------ helpers
+def _raw(env):
+  return env.raw_env if hasattr(env, 'raw_env') else env
+
+
+def stagger_phases(env, actions, period):
+  """Puts lane i at episode phase i % period: steps the batch `period` times and keeps, for each
+  lane, the state it had after (i % period) + 1 calls (per-lane columns of state_dict(); the draw
+  stream is keyed by (lane, call index), so any such mix is a valid engine state).  Afterwards every
+  call sees the steady-state mix of FIRST / MID / LAST lanes instead of all lanes terminating on
+  the same call."""
+  import torch
+  raw = _raw(env)
+  B = raw.batch_size
+  phase = (torch.arange(B, device=raw.device) + raw.lane_offset) % period     # keyed by GLOBAL lane id
+  final = None
+  for k in range(period):
+    env.step(actions[k % actions.shape[0]])
+    sd = raw.state_dict()
+    if final is None:
+      final = sd
+      continue
+    take = phase == k
+    for key, val in sd.items():
+      if torch.is_tensor(val) and val.dim() >= 1 and val.shape[-1] == B and key != '__counters':
+        final[key] = torch.where(take, val, final[key])
+      else:
+        final[key] = val
+  raw.load_state_dict(final)
+
+
+def synthetic_actions(torch, num_actions, n_steps, lane0, lanes, dev, salt=0):
+  """int32 [n_steps, lanes] uniform actions as a pure function of (global lane id, t): an integer hash
+  evaluated on the device, so any sharding of the lanes feeds every lane the same action sequence
+  (the batched, shardable analogue of bsuite/baselines/random/agent.py:35-37)."""
+  lane = torch.arange(lane0, lane0 + lanes, dtype=torch.int64, device=dev)[None, :]
+  t = torch.arange(n_steps, dtype=torch.int64, device=dev)[:, None]
+  x = (lane * 2654435761 + t * 40503 + (salt * 7919 + 12345)) & 0xFFFFFFFF
+  x = ((x ^ (x >> 15)) * 2246822519) & 0xFFFFFFFF
+  x = ((x ^ (x >> 13)) * 3266489917) & 0xFFFFFFFF
+  x = x ^ (x >> 16)
+  return ((x * num_actions) >> 32).to(torch.int32)
+
+
+def _free_port():
+  import socket
+  s = socket.socket()
+  s.bind(('127.0.0.1', 0))
+  p = s.getsockname()[1]
+  s.close()
+  return p
+
+
+def self_launch(args):
+  """`python bench.py --gpus N` with no WORLD_SIZE in the environment: spawn the N ranks ourselves
+  (one per device, torch.distributed.run on 127.0.0.1) and pass their output through."""
+  import subprocess
+  import torch
+  single = bool(os.environ.get('BSX_BENCH_SINGLE_DEVICE'))
+  have = torch.cuda.device_count()
+  if have < args.gpus and not single:
+    raise SystemExit(f'--gpus {args.gpus} but only {have} HIP device(s) visible '
+                     '(BSX_BENCH_SINGLE_DEVICE=1 BSX_BENCH_BACKEND=gloo runs all ranks on cuda:0 for testing)')
+  env = dict(os.environ)
+  env.setdefault('OMP_NUM_THREADS', '4')
+  env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+  cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={args.gpus}',
+         '--master-addr', '127.0.0.1', '--master-port', str(_free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+  return subprocess.call(cmd, env=env)
+
+
+# ------------------------------------------------------------------------------------ one rank
+class Rank:
+  """Everything one process (one GPU) measures."""
+
+  def __init__(self, args):
+    import torch
+    import torch.distributed as dist
+    import bsuite_amd
+    self.torch, self.dist, self.bsuite_amd, self.args = torch, dist, bsuite_amd, args
+    self.world = int(os.environ.get('WORLD_SIZE', '1'))
+    self.rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    # Test hooks (single-GPU boxes): BSX_BENCH_BACKEND=gloo + BSX_BENCH_SINGLE_DEVICE=1 run all ranks
+    # on cuda:0 so the multi-rank control flow can be exercised without a multi-GPU node.
+    backend = os.environ.get('BSX_BENCH_BACKEND', 'nccl')
+    if os.environ.get('BSX_BENCH_SINGLE_DEVICE'):
+      local_rank = 0
+    if self.world > 1:
+      os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+      dist.init_process_group(backend)
+    if args.gpus != self.world:
+      raise SystemExit(f'--gpus {args.gpus} but WORLD_SIZE={self.world}')
+    torch.cuda.set_device(local_rank)
+    self.dev = torch.device('cuda', local_rank)
+    self._ceiling = None
+
+  def sync_all(self):
+    self.torch.cuda.synchronize(self.dev)
+    if self.world > 1:
+      self.dist.barrier()
+      self.torch.cuda.synchronize(self.dev)
+
+  def reduce_times(self, *vals):
+    """MAX over ranks of host-side floats."""
+    if self.world == 1:
+      return vals
+    t = self.torch.tensor(list(vals), dtype=self.torch.float64,
+                          device=self.dev if self.dist.get_backend() == 'nccl' else 'cpu')
+    self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+    return tuple(float(x) for x in t.tolist())
+
+  def timed(self, run, steps, warmup):
+    """W untimed + exactly K timed steps, bracketed by barrier + synchronize on both sides; returns
+    (wall seconds, ms per step by HIP events on the launch stream), MAX over ranks."""
+    torch = self.torch
+    run(warmup)
+    self.sync_all()
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    ev0.record()
+    run(steps)
+    ev1.record()
+    torch.cuda.synchronize(self.dev)
+    wall = time.perf_counter() - t0
+    self.sync_all()
+    return self.reduce_times(wall, ev0.elapsed_time(ev1) / steps)
+
+  # -------------------------------------------------------------------------------------------
+  def measure(self, workload, lanes, steps, warmup, mode='eager', chunk=0, observation_mode='dense',
+              logging=False, stagger=True):
+    """Times `steps` step() calls of `workload` on `lanes` lanes per rank.  mode: 'eager' (one
+    entry-point call per step), 'graph' (HIP graph of `chunk` step() launches), 'rollout' (fused
+    rollout(actions[chunk, B]))."""
+    torch, args = self.torch, self.args
+    bsuite_id, family, okw, obs_numel, state_bytes, period = WORKLOADS[workload]
+    B = lanes
+    delta = observation_mode == 'delta'
+    if delta and family not in ('deep_sea', 'catch'):
+      raise SystemExit('--observation-mode delta exists for deep_sea and catch only')
+    extra = {}
+    if family == 'mnist':
+      extra['images'], extra['labels'] = _synthetic_mnist()
+    env = self.bsuite_amd.load_from_id(bsuite_id, batch=B, device=self.dev, seed=42, lane_offset=self.rank * B,
+                                       num_buffers=2, device_step_counter=(mode == 'graph'),
+                                       observation_mode=observation_mode, **extra)
+    if logging:
+      # SURVEY §8 f-1: the Logging wrapper's per-lane bookkeeping + log-spaced snapshot rows, fused
+      # into the same kernels (no logger object: rows stay in the device buffer)
+      from bsuite_amd.utils import wrappers as _wrappers
+      env = _wrappers.Logging(env, None)
+    num_actions = env.action_spec().num_values
+    n_act = max(32, chunk)
+    actions = synthetic_actions(torch, num_actions, n_act, self.rank * B, B, self.dev)
+    if stagger and not args.no_stagger and not delta and not logging:
+      stagger_phases(env, actions, period)
     else:
-      batch.replay = batch.step_grouped
-  else:
-    batch.capture(acts)
+      env.step(actions[0])
 
-  def sync_all():
-    torch.cuda.synchronize(dev)
-    if world > 1:
-      dist.barrier()
-      torch.cuda.synchronize(dev)
+    if mode == 'graph':
+      assert steps % chunk == 0 and warmup % chunk == 0, '--steps/--warmup must be multiples of --graph'
+      side = torch.cuda.Stream(device=self.dev)
+      side.wait_stream(torch.cuda.current_stream(self.dev))
+      graph = torch.cuda.CUDAGraph()
+      with torch.cuda.stream(side):
+        with torch.cuda.graph(graph, stream=side):
+          for t in range(chunk):
+            env.step(actions[t])
+      torch.cuda.current_stream(self.dev).wait_stream(side)
 
-  for _ in range(args.warmup):
-    batch.replay()
-  sync_all()
-  ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-  t0 = time.perf_counter()
-  ev0.record()
-  for _ in range(args.steps):
-    batch.replay()
-  ev1.record()
-  torch.cuda.synchronize(dev)
-  wall = time.perf_counter() - t0
-  sync_all()
-  step_ms = ev0.elapsed_time(ev1) / args.steps
-  local_bytes = sum(l * sb.bytes_per_step(int(np.prod(e.observation_spec().shape)))
-                    for e, (_, _, l) in zip(batch.envs, batch.segments))
-  if world > 1:
-    t = torch.tensor([wall, step_ms, float(local_bytes)], dtype=torch.float64,
-                     device=dev if dist.get_backend() == 'nccl' else 'cpu')
-    mx = t.clone()
-    dist.all_reduce(mx, op=dist.ReduceOp.MAX)
-    dist.all_reduce(t, op=dist.ReduceOp.SUM)
-    wall, step_ms, total_bytes = float(mx[0]), float(mx[1]), float(t[2])
-  else:
-    total_bytes = float(local_bytes)
-  if rank == 0:
-    achieved = total_bytes / world / (step_ms * 1e-3) / 1e9
-    print(json.dumps({
-        'metric': 'env-steps/sec', 'value': args.lanes * args.steps / wall, 'unit': 'env-steps/s',
-        'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': wall / args.steps * 1e3,
-        'higher_is_better': True, 'scaling': 'strong', 'vs_baseline': None, 'dtype': 'int32+f32',
-        'data': 'synthetic (MNIST ids on a synthetic stand-in dataset)',
-        'config': {'workload': 'sweep.SWEEP: 468 bsuite_ids as lane segments, random-action rollout, dense TimeStep',
-                   'global_lanes': args.lanes, 'segments_on_rank0': len(batch.envs),
-                   'sharding': f'whole segments bin-packed over {world} rank(s)'},
+      def run(n_steps):
+        for _ in range(n_steps // chunk):
+          graph.replay()
+    elif mode == 'rollout':
+      assert steps % chunk == 0 and warmup % chunk == 0, '--steps/--warmup must be multiples of --rollout'
+
+      def run(n_steps):
+        for _ in range(n_steps // chunk):
+          env.rollout(actions[:chunk])
+    else:
+      def run(n_steps):
+        for t in range(n_steps):
+          env.step(actions[t % n_act])
+
+    before = _raw(env).episode_counters().clone()
+    wall, kernel_ms = self.timed(run, steps, warmup)
+    ended = (_raw(env).episode_counters() - before).to(torch.float64)
+
+    # end-of-rollout summary: the only collective on the path (RCCL all-gather over xGMI)
+    from bsuite_amd import distributed as bdist
+    vec, names = bdist.local_summary(env)
+    vec = torch.cat([vec, ended])
+    summary = bdist.reduce_summary(bdist.all_gather_summary(vec), names + ('timed_last', 'timed_first'))
+    # SURVEY §8(d): state in/out counts once per T fused steps; only the small-observation families
+    # fuse a rollout into one launch (their state then stays in L2 between the T steps)
+    fused_T = chunk if (mode == 'rollout' and family not in ('deep_sea', 'catch', 'mnist')) else 1
+    bytes_per_step = algorithmic_bytes_per_step(obs_numel, state_bytes / fused_T)
+    if delta:
+      # ACTUAL bytes of the delta mode (SURVEY §8d: reported separately, never against the dense
+      # contract): scalars + state in/out + paint column in/out + the 4-byte cell stores
+      # (deep_sea: clear 1 + set 1; catch: up to 2 + 2).
+      bytes_per_step = 13 + state_bytes + 8 + 4 * (2 if family == 'deep_sea' else 4)
+    achieved = bytes_per_step * B / (kernel_ms * 1e-3) / 1e9
+    traffic, traffic_src = pmc_traffic(workload + ('_delta' if delta else ''), B) if mode == 'eager' else (None, None)
+    del env, actions
+    torch.cuda.empty_cache()
+    calls = steps * B * self.world
+    return dict(workload=workload, bsuite_id=bsuite_id, family=family, okw=okw, num_actions=num_actions, lanes=B,
+                steps=steps, wall=wall, kernel_ms=kernel_ms, value=calls / wall, bytes_per_step=bytes_per_step,
+                achieved=achieved, traffic=traffic, traffic_src=traffic_src, mode=mode, chunk=chunk,
+                episodes_finished=summary['episodes_finished'],
+                info_sums={k: v for k, v in summary.items()
+                           if k not in ('lanes', 'episodes_finished', 'episodes_started', 'timed_last', 'timed_first')},
+                timed_mix=dict(last=summary['timed_last'] / calls, first=summary['timed_first'] / calls))
+
+  def store_ceiling(self):
+    """Pure-store ceiling of THIS box (one 16-B store per thread over 2 GiB, no other work): context for
+    the roofline fraction of the store-bound families.  Not part of any timed region."""
+    if self._ceiling is None:
+      torch = self.torch
+      from bsuite_amd import _native
+      scratch = torch.empty(1 << 31, dtype=torch.uint8, device=self.dev)   # 2 GiB: far beyond L2 + Infinity Cache
+      nbytes = scratch.numel()
+      stream_h = torch.cuda.current_stream(self.dev).cuda_stream
+      for _ in range(3):
+        _native.lib.bsx_calib_fill(scratch.data_ptr(), nbytes, 0, stream_h)
+      c0, c1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+      c0.record()
+      for _ in range(10):
+        _native.lib.bsx_calib_fill(scratch.data_ptr(), nbytes, 0, stream_h)
+      c1.record()
+      torch.cuda.synchronize(self.dev)
+      self._ceiling = nbytes * 10 / (c0.elapsed_time(c1) * 1e-3) / 1e9
+      del scratch
+      torch.cuda.empty_cache()
+    return self._ceiling
+
+  def roofline(self, r):
+    ceiling = self.store_ceiling()
+    return {'bound': 'hbm', 'achieved': r['achieved'], 'peak': HBM_PEAK_GBPS, 'unit': 'GB/s',
+            'frac': r['achieved'] / HBM_PEAK_GBPS, 'traffic': r['traffic'],
+            'traffic_source': r['traffic_src'],
+            'algorithmic_bytes_per_launch': r['bytes_per_step'] * r['lanes'],
+            'kernel_ms': r['kernel_ms'], 'box_store_ceiling_GBps': ceiling,
+            'frac_of_box_store_ceiling': r['achieved'] / ceiling}
+
+  def sub_record(self, r):
+    launch = ('eager step()' if r['mode'] == 'eager' else
+              f"hipGraph of {r['chunk']} step() launches" if r['mode'] == 'graph' else
+              f"rollout(T={r['chunk']}) per call")
+    return {'value': r['value'], 'unit': 'env-steps/s', 'ms_per_step': r['wall'] / r['steps'] * 1e3,
+            'workload': f"{r['bsuite_id']} ({r['family']}) random-action rollout, dense TimeStep, "
+                        f"{r['lanes']} lanes per GPU x {self.world} GPU(s)",
+            'launch': launch, 'bytes_per_env_step': r['bytes_per_step'], 'timed_mix': r['timed_mix'],
+            'episodes_finished': r['episodes_finished'], 'bsuite_info_sums': r['info_sums'],
+            'roofline': self.roofline(r)}
+
+  # -------------------------------------------------------------------------------------------
+  def measure_sweep(self, lanes, steps, warmup):
+    """BASELINE config 5: all 468 bsuite_ids as lane segments (`lanes` in total, split evenly per id,
+    whole segments bin-packed over the ranks), grouped launches, one captured HIP graph per sweep step."""
+    import tempfile
+    import numpy as np
+    torch = self.torch
+    from bsuite_amd import sweep_batch as sb
+    from bsuite_amd.utils import datasets
+    d = np.load(os.path.join(ROOT, 'tests', 'golden', 'mnist_synthetic_dataset.npz'))
+    tmp = tempfile.mkdtemp(prefix='bsx_mnist_')
+    datasets.write_idx_files(tmp, d['images_u8'], d['labels'])      # synthetic stand-in (no network)
+    mn = dict(data_dir=tmp)
+    batch = sb.SweepBatch(None, lanes, device=self.dev, seed=42, rank=self.rank, world_size=self.world,
+                          num_streams=int(os.environ.get('BSX_SWEEP_STREAMS', '32')),
+                          env_kwargs=dict(mnist=mn, mnist_noise=mn, mnist_scale=mn))
+    acts = batch.random_actions(seed=1)          # keyed by segment: independent of the rank assignment
+    mode = os.environ.get('BSX_SWEEP_MODE', 'grouped_graph')
+    grouped = mode in ('grouped', 'grouped_graph')
+    if grouped:
+      batch.prepare_groups(acts, mix_small=os.environ.get('BSX_SWEEP_MIX_SMALL', '1') != '0')
+      if mode == 'grouped_graph':              # group launches as concurrent branches of one HIP graph
+        batch.capture_grouped(int(os.environ.get('BSX_SWEEP_STREAMS', '2')))
+        replay = batch.replay_grouped
+      else:
+        replay = batch.step_grouped
+    else:
+      batch.capture(acts)
+      replay = batch.replay
+
+    def run(n):
+      for _ in range(n):
+        replay()
+
+    wall, step_ms = self.timed(run, steps, warmup)
+    local_bytes = float(sum(l * sb.bytes_per_step(int(np.prod(e.observation_spec().shape)))
+                            for e, (_, _, l) in zip(batch.envs, batch.segments)))
+    # the only collective: all-gather of the per-rank summaries (here: bytes + lanes + episode counters)
+    from bsuite_amd import distributed as bdist
+    summ = batch.summary()
+    vec = torch.tensor([local_bytes, float(batch.lanes()), float(len(batch.envs)),
+                        sum(v['episodes_finished'] for v in summ.values())], dtype=torch.float64, device=self.dev)
+    g = bdist.all_gather_summary(vec)
+    total_bytes, total_lanes = float(g[:, 0].sum()), float(g[:, 1].sum())
+    max_rank_bytes = float(g[:, 0].max())
+    achieved = max_rank_bytes / (step_ms * 1e-3) / 1e9          # the busiest rank's stream
+    rec = {
+        'value': total_lanes * steps / wall, 'unit': 'env-steps/s', 'ms_per_step': wall / steps * 1e3,
+        'workload': 'sweep.SWEEP: 468 bsuite_ids as lane segments (MNIST ids on a synthetic stand-in dataset), '
+                    'random-action rollout, dense TimeStep',
+        'global_lanes': int(total_lanes), 'segments_per_rank': [int(x) for x in g[:, 2].tolist()],
+        'sharding': f'whole segments bin-packed over {self.world} rank(s) by lanes x bytes/step',
+        'scaling': 'strong',
+        'episodes_finished': float(g[:, 3].sum()),
         'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBPS, 'unit': 'GB/s',
                      'frac': achieved / HBM_PEAK_GBPS, 'traffic': None, 'kernel_ms': step_ms,
-                     'algorithmic_bytes_per_launch': total_bytes / world},
-        'launch': (f'{len(batch._groups)} grouped launches per sweep step ({len(batch.envs)} segments)'
+                     'algorithmic_bytes_per_launch': max_rank_bytes,
+                     'algorithmic_bytes_all_ranks': total_bytes},
+        'launch': (f'{len(batch._groups)} grouped launches per sweep step ({len(batch.envs)} segments on rank 0)'
                    + (' as concurrent branches of one HIP graph' if mode == 'grouped_graph' else '') if grouped else
-                   f'one hipGraph per sweep step ({len(batch.envs)} segments over {batch.num_streams} streams)')}),
-          flush=True)
-  if world > 1:
-    dist.destroy_process_group()
+                   f'one hipGraph per sweep step ({len(batch.envs)} segments over {batch.num_streams} streams)')}
+    batch.release_groups()
+    del batch, acts
+    torch.cuda.empty_cache()
+    return rec
+
+  # -------------------------------------------------------------------------------------------
+  def guarded(self, name, fn):
+    """An auxiliary measurement must never cost the headline line: record the error instead."""
+    try:
+      return fn()
+    except SystemExit:
+      raise
+    except Exception as e:  # pylint: disable=broad-except
+      if self.world > 1:
+        raise                      # ranks must stay in step: a lone rank skipping a collective would hang
+      return {'error': f'{type(e).__name__}: {e}'}
+
+  def run(self):
+    args, world = self.args, self.world
+    lanes = args.lanes
+    if args.strong and args.workload != 'sweep':
+      if lanes % world:
+        raise SystemExit('--strong needs --lanes divisible by the number of ranks')
+      lanes //= world
+
+    if args.workload == 'sweep':
+      rec = self.measure_sweep(args.lanes, args.steps, args.warmup)
+      if self.rank == 0:
+        line = {'metric': 'env-steps/sec', 'value': rec['value'], 'unit': 'env-steps/s', 'n_gpus': world,
+                'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': rec['ms_per_step'],
+                'higher_is_better': True, 'scaling': 'strong', 'vs_baseline': None, 'dtype': 'int32+f32',
+                'data': 'synthetic (MNIST ids on a synthetic stand-in dataset)',
+                'config': {'workload': rec['workload'], 'global_lanes': rec['global_lanes'],
+                           'segments_per_rank': rec['segments_per_rank'], 'sharding': rec['sharding']},
+                'roofline': rec['roofline'], 'launch': rec['launch'], 'episodes_finished': rec['episodes_finished']}
+        print(json.dumps(line), flush=True)
+      return
+
+    mode, chunk = ('graph', args.graph) if args.graph else ('rollout', args.rollout) if args.rollout else ('eager', 0)
+    m = self.measure(args.workload, lanes, args.steps, args.warmup, mode, chunk, args.observation_mode, args.logging)
+    also = {}
+    headline = (args.workload == 'deep_sea' and mode == 'eager' and args.observation_mode == 'dense'
+                and not args.logging and not args.no_also)
+    if headline:
+      K, W = args.steps, args.warmup
+      K16, W16 = max(16, K // 16 * 16), max(16, (W + 15) // 16 * 16)
+
+      def sub(workload, n_lanes, md='eager', ch=0, k=K, w=W):
+        return self.guarded(workload, lambda: self.sub_record(self.measure(workload, n_lanes, k, w, md, ch)))
+
+      also['catch/0'] = sub('catch', lanes)                      # the other half of BASELINE.json's metric
+      if world == 1:
+        for w_ in ('cartpole', 'mountain_car'):                  # BASELINE configs[3]
+          bid = WORKLOADS[w_][0]
+          also[bid] = sub(w_, lanes)
+          if 'error' not in also[bid]:
+            also[bid]['graph16'] = sub(w_, lanes, 'graph', 16, K16, W16)
+            also[bid]['rollout16'] = sub(w_, lanes, 'rollout', 16, K16, W16)
+      else:
+        if args.lanes % world == 0 and not args.strong:          # strong scaling: 2^20 lanes over all ranks
+          also['strong'] = {
+              'scaling': 'strong', 'global_lanes': args.lanes,
+              'deep_sea/10': sub('deep_sea', args.lanes // world),
+              'catch/0': sub('catch', args.lanes // world)}
+      # BASELINE configs[4]: the heterogeneous sweep, sharded over the ranks by whole segments
+      also['sweep'] = self.guarded('sweep', lambda: self.measure_sweep(args.lanes, max(20, K // 2), max(5, W // 2)))
+
+    if self.rank == 0:
+      B = lanes
+      line = {
+          'metric': 'env-steps/sec', 'value': m['value'], 'unit': 'env-steps/s',
+          'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+          'ms_per_step': m['wall'] / args.steps * 1e3, 'higher_is_better': True,
+          'scaling': 'strong' if args.strong else 'weak',
+          'vs_baseline': None, 'dtype': 'f32' if m['family'] in ('cartpole', 'mountain_car') else 'int32',
+          'data': 'synthetic',
+          'config': {'workload': f"{m['bsuite_id']} ({m['family']} {m['okw']}) random-action rollout, "
+                                 + ('dense TimeStep' if args.observation_mode == 'dense' else
+                                    'DELTA observation mode (persistent buffers patched in place; not the dense contract)'),
+                     'observation_mode': args.observation_mode, 'logging_wrapper': bool(args.logging),
+                     'lanes_per_gpu': B, 'global_lanes': B * world, 'sharding': f'lanes x{world}',
+                     'bytes_per_env_step': m['bytes_per_step'],
+                     'episode_phases': 'lock-step' if args.no_stagger else 'staggered (steady-state FIRST/MID/LAST mix)'},
+          'roofline': self.roofline(m),
+          'launch': (f'hipGraph x{args.graph}' if args.graph else
+                     f'rollout x{args.rollout} per call' if args.rollout else 'eager'),
+          'episodes_finished': m['episodes_finished'], 'bsuite_info_sums': m['info_sums'],
+          'timed_mix': m['timed_mix'],
+      }
+      if also:
+        line['also'] = also
+      if world == 1 and not args.no_cpu_baseline:
+        line['cpu_baseline'] = cpu_baseline(m['bsuite_id'], m['family'], m['okw'], m['num_actions'])
+      print(json.dumps(line), flush=True)
+
+  def close(self):
+    if self.world > 1:
+      self.dist.destroy_process_group()
 
 
 def main():
@@ -202,11 +584,13 @@ def main():
   ap.add_argument('--steps', type=int, default=200)
   ap.add_argument('--warmup', type=int, default=20)
   ap.add_argument('--workload', default='deep_sea', choices=sorted(WORKLOADS) + ['sweep'])
-  ap.add_argument('--lanes', type=int, default=1 << 20, help='lanes per GPU')
+  ap.add_argument('--lanes', type=int, default=1 << 20, help='lanes per GPU (sweep: global lanes)')
   ap.add_argument('--strong', action='store_true',
                   help='strong scaling (SURVEY §8d): --lanes is the GLOBAL lane count, split evenly over the ranks '
                        '(default: weak scaling, --lanes per GPU)')
   ap.add_argument('--no-cpu-baseline', action='store_true')
+  ap.add_argument('--no-also', action='store_true', help='only the main workload (no catch / cartpole / sweep sub-records)')
+  ap.add_argument('--no-stagger', action='store_true', help='start all lanes in lock-step (fresh lanes, first call = reset)')
   ap.add_argument('--logging', action='store_true',
                   help='wrap the environment in the batched Logging wrapper (bookkeeping fused into the kernels)')
   ap.add_argument('--observation-mode', default='dense', choices=['dense', 'delta'],
@@ -220,188 +604,14 @@ def main():
                        '(for the tiny families whose per-step kernel is shorter than a host launch)')
   args = ap.parse_args()
 
-  import torch
-  import torch.distributed as dist
-  import bsuite_amd
+  if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+    sys.exit(self_launch(args))
 
-  world = int(os.environ.get('WORLD_SIZE', '1'))
-  if args.strong and args.workload != 'sweep':
-    if args.lanes % world:
-      raise SystemExit('--strong needs --lanes divisible by the number of ranks')
-    args.lanes //= world
-  rank = int(os.environ.get('RANK', '0'))
-  local_rank = int(os.environ.get('LOCAL_RANK', '0'))
-  # Test hooks (single-GPU boxes): BSX_BENCH_BACKEND=gloo + BSX_BENCH_SINGLE_DEVICE=1 run all ranks
-  # on cuda:0 so the multi-rank control flow can be exercised without a multi-GPU node.
-  backend = os.environ.get('BSX_BENCH_BACKEND', 'nccl')
-  if os.environ.get('BSX_BENCH_SINGLE_DEVICE'):
-    local_rank = 0
-  if world > 1:
-    os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-    dist.init_process_group(backend)
-  assert args.gpus == world, f'--gpus {args.gpus} but WORLD_SIZE={world}'
-  torch.cuda.set_device(local_rank)
-  dev = torch.device('cuda', local_rank)
-
-  if args.workload == 'sweep':
-    return bench_sweep(args, torch, dist, dev, rank, world)
-
-  def sync_all():
-    torch.cuda.synchronize(dev)
-    if world > 1:
-      dist.barrier()
-      torch.cuda.synchronize(dev)
-
-  def measure(workload):
-    """Times exactly args.steps step() calls of `workload` after args.warmup untimed ones."""
-    bsuite_id, family, okw, obs_numel, state_bytes = WORKLOADS[workload]
-    B = args.lanes
-    delta = args.observation_mode == 'delta'
-    if delta and family not in ('deep_sea', 'catch'):
-      raise SystemExit('--observation-mode delta exists for deep_sea and catch only')
-    extra = {}
-    if family == 'mnist':
-      extra['images'], extra['labels'] = _synthetic_mnist()
-    env = bsuite_amd.load_from_id(bsuite_id, batch=B, device=dev, seed=42, lane_offset=rank * B,
-                                  num_buffers=2, device_step_counter=bool(args.graph),
-                                  observation_mode=args.observation_mode, **extra)
-    if args.logging:
-      # SURVEY §8 f-1: the Logging wrapper's per-lane bookkeeping + log-spaced snapshot rows, fused
-      # into the same kernels (no logger object: rows stay in the device buffer)
-      from bsuite_amd.utils import wrappers as _wrappers
-      env = _wrappers.Logging(env, None)
-    num_actions = env.action_spec().num_values
-    gen = torch.Generator(device=dev)
-    gen.manual_seed(1234 + rank)
-    n_act = max(32, args.graph, args.rollout)
-    actions = torch.randint(num_actions, (n_act, B), generator=gen, device=dev, dtype=torch.int32)
-
-    if args.graph:
-      assert args.steps % args.graph == 0 and args.warmup % args.graph == 0, '--steps/--warmup must be multiples of --graph'
-      env.step(actions[0])                       # allocate outside capture
-      side = torch.cuda.Stream(device=dev)
-      side.wait_stream(torch.cuda.current_stream(dev))
-      graph = torch.cuda.CUDAGraph()
-      with torch.cuda.stream(side):
-        with torch.cuda.graph(graph, stream=side):
-          for t in range(args.graph):
-            env.step(actions[t])
-      torch.cuda.current_stream(dev).wait_stream(side)
-
-      def run(n_steps):
-        for _ in range(n_steps // args.graph):
-          graph.replay()
-    elif args.rollout:
-      assert args.steps % args.rollout == 0 and args.warmup % args.rollout == 0, '--steps/--warmup must be multiples of --rollout'
-
-      def run(n_steps):
-        for _ in range(n_steps // args.rollout):
-          env.rollout(actions[:args.rollout])
-    else:
-      def run(n_steps):
-        for t in range(n_steps):
-          env.step(actions[t % n_act])
-
-    run(args.warmup)
-    sync_all()
-    ev0 = torch.cuda.Event(enable_timing=True)
-    ev1 = torch.cuda.Event(enable_timing=True)
-    t0 = time.perf_counter()
-    ev0.record()
-    run(args.steps)
-    ev1.record()
-    torch.cuda.synchronize(dev)
-    wall = time.perf_counter() - t0
-    sync_all()
-    kernel_ms = ev0.elapsed_time(ev1) / args.steps   # HIP events on the launch stream
-
-    # end-of-rollout summary: the only collective on the path (RCCL all-gather over xGMI)
-    from bsuite_amd import distributed as bdist
-    vec, names = bdist.local_summary(env)
-    summary = bdist.reduce_summary(bdist.all_gather_summary(vec), names)
-    if world > 1:
-      t_wall = torch.tensor([wall, kernel_ms], dtype=torch.float64,
-                            device=dev if dist.get_backend() == 'nccl' else 'cpu')
-      dist.all_reduce(t_wall, op=dist.ReduceOp.MAX)
-      wall, kernel_ms = float(t_wall[0].item()), float(t_wall[1].item())
-    # SURVEY §8(d): state in/out counts once per T fused steps; only the small-observation families
-    # fuse a rollout into one launch (their state then stays in L2 between the T steps)
-    fused_T = args.rollout if (args.rollout and family not in ('deep_sea', 'catch', 'mnist')) else 1
-    bytes_per_step = algorithmic_bytes_per_step(obs_numel, state_bytes / fused_T)
-    if delta:
-      # ACTUAL bytes of the delta mode (SURVEY §8d: reported separately, never against the dense
-      # contract): scalars + state in/out + paint column in/out + the 4-byte cell stores
-      # (deep_sea: clear 1 + set 1; catch: up to 2 + 2).
-      bytes_per_step = 13 + state_bytes + 8 + 4 * (2 if family == 'deep_sea' else 4)
-    achieved = bytes_per_step * B / (kernel_ms * 1e-3) / 1e9
-    traffic, traffic_src = pmc_traffic(workload + ('_delta' if delta else ''), B)
-    del env, actions
-    torch.cuda.empty_cache()
-    return dict(bsuite_id=bsuite_id, family=family, okw=okw, num_actions=num_actions, wall=wall,
-                kernel_ms=kernel_ms, value=B * world * args.steps / wall, bytes_per_step=bytes_per_step,
-                achieved=achieved, traffic=traffic, traffic_src=traffic_src,
-                episodes_finished=summary['episodes_finished'])
-
-  m = measure(args.workload)
-  also = None
-  if args.workload == 'deep_sea' and not (args.graph or args.rollout) and args.observation_mode == 'dense':
-    also = measure('catch')        # the other half of BASELINE.json's metric, same K/W, same box
-
-  # Pure-store ceiling of THIS box (one 16-B store per thread over 2 GiB, no other work): context for
-  # the roofline fraction of the store-bound families.  Not part of the timed region.
-  from bsuite_amd import _native
-  scratch = torch.empty(1 << 31, dtype=torch.uint8, device=dev)   # 2 GiB: far beyond L2 + Infinity Cache
-  nbytes = scratch.numel()
-  stream_h = torch.cuda.current_stream(dev).cuda_stream
-  for _ in range(3):
-    _native.lib.bsx_calib_fill(scratch.data_ptr(), nbytes, 0, stream_h)
-  c0 = torch.cuda.Event(enable_timing=True)
-  c1 = torch.cuda.Event(enable_timing=True)
-  c0.record()
-  for _ in range(10):
-    _native.lib.bsx_calib_fill(scratch.data_ptr(), nbytes, 0, stream_h)
-  c1.record()
-  torch.cuda.synchronize(dev)
-  store_ceiling_gbps = nbytes * 10 / (c0.elapsed_time(c1) * 1e-3) / 1e9
-
-  def roofline(r):
-    return {'bound': 'hbm', 'achieved': r['achieved'], 'peak': HBM_PEAK_GBPS, 'unit': 'GB/s',
-            'frac': r['achieved'] / HBM_PEAK_GBPS, 'traffic': r['traffic'],
-            'traffic_source': r['traffic_src'],
-            'algorithmic_bytes_per_launch': r['bytes_per_step'] * args.lanes,
-            'kernel_ms': r['kernel_ms'], 'box_store_ceiling_GBps': store_ceiling_gbps,
-            'frac_of_box_store_ceiling': r['achieved'] / store_ceiling_gbps}
-
-  if rank == 0:
-    B = args.lanes
-    line = {
-        'metric': 'env-steps/sec', 'value': m['value'], 'unit': 'env-steps/s',
-        'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
-        'ms_per_step': m['wall'] / args.steps * 1e3, 'higher_is_better': True, 'scaling': 'strong' if args.strong else 'weak',
-        'vs_baseline': None, 'dtype': 'f32' if m['family'] in ('cartpole', 'mountain_car') else 'int32',
-        'data': 'synthetic',
-        'config': {'workload': f"{m['bsuite_id']} ({m['family']} {m['okw']}) random-action rollout, "
-                               + ('dense TimeStep' if args.observation_mode == 'dense' else
-                                  'DELTA observation mode (persistent buffers patched in place; not the dense contract)'),
-                   'observation_mode': args.observation_mode, 'logging_wrapper': bool(args.logging),
-                   'lanes_per_gpu': B, 'global_lanes': B * world, 'sharding': f'lanes x{world}',
-                   'bytes_per_env_step': m['bytes_per_step']},
-        'roofline': roofline(m),
-        'launch': (f'hipGraph x{args.graph}' if args.graph else
-                   f'rollout x{args.rollout} per call' if args.rollout else 'eager'),
-        'episodes_finished': m['episodes_finished'],
-    }
-    if also is not None:
-      line['also'] = {also['bsuite_id']: {
-          'value': also['value'], 'unit': 'env-steps/s', 'ms_per_step': also['wall'] / args.steps * 1e3,
-          'workload': f"{also['bsuite_id']} ({also['family']} 10x5) random-action rollout, dense TimeStep, "
-                      f'{B} lanes per GPU', 'bytes_per_env_step': also['bytes_per_step'],
-          'roofline': roofline(also)}}
-    if world == 1 and not args.no_cpu_baseline:
-      line['cpu_baseline'] = cpu_baseline(m['family'], m['okw'], m['num_actions'])
-    print(json.dumps(line), flush=True)
-  if world > 1:
-    dist.destroy_process_group()
+  r = Rank(args)
+  try:
+    r.run()
+  finally:
+    r.close()
 
 
 if __name__ == '__main__':

@@ -41,6 +41,14 @@ def _load():
       raise NativeLibraryError(
           f'{SO_PATH} is missing and could not be built with hipcc ({e}). bsuite_amd has no CPU '
           'fallback: run `python -m bsuite_amd.build`.') from e
+    # a rebuild was needed (a source is newer than the library) and failed: running the old kernels
+    # silently would be worse than stopping.  BSX_ALLOW_STALE_LIB=1 overrides (e.g. read-only trees).
+    if os.environ.get('BSX_ALLOW_STALE_LIB') != '1':
+      raise NativeLibraryError(
+          f'{SO_PATH} is older than its sources and rebuilding it failed ({e}); fix the build or set '
+          'BSX_ALLOW_STALE_LIB=1 to load the stale library anyway.') from e
+    import warnings  # pylint: disable=import-outside-toplevel
+    warnings.warn(f'loading a STALE {SO_PATH}: rebuild failed ({e})')
   try:
     return ctypes.CDLL(SO_PATH)
   except OSError as e:
@@ -78,7 +86,7 @@ class Call(ctypes.Structure):
   _fields_ = [('n_lanes', ctypes.c_int64), ('force_reset', ctypes.c_int32), ('n_steps', ctypes.c_int32),
               ('stream', Stream), ('wrap', RewardWrap), ('counters', ctypes.c_void_p),
               ('hip_stream', ctypes.c_void_p), ('logging', ctypes.POINTER(Logging)),
-              ('obs_paint', ctypes.c_void_p)]
+              ('obs_paint', ctypes.c_void_p), ('reward_f64', ctypes.c_void_p)]
 
 
 class DeepSeaCfg(ctypes.Structure):
@@ -193,7 +201,7 @@ for _name, (_args, _res) in _SIGS.items():
   _fn.restype = _res
 if MISSING:
   raise NativeLibraryError(f'{SO_PATH} does not export {MISSING}; rebuild with `python -m bsuite_amd.build --force`')
-ABI_VERSION = 7
+ABI_VERSION = 8
 if lib.bsx_abi_version() != ABI_VERSION:
   raise NativeLibraryError('ABI version mismatch between bsuite_amd/_native.py and libbsuite_amd.so')
 

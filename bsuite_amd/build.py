@@ -6,6 +6,8 @@ hipcc cross-compiles for gfx950 without a GPU.  The .so is built in-tree so that
 the repository snapshot to the GPU box (it is git-ignored, not gpurun-ignored).
 """
 import concurrent.futures
+import contextlib
+import fcntl
 import os
 import subprocess
 import sys
@@ -40,26 +42,89 @@ def _stale(target, deps):
 
 
 def _compile(src, obj):
-  subprocess.check_call(['hipcc'] + FLAGS + ['-c', src, '-o', obj])
+  tmp = f'{obj}.{os.getpid()}.tmp'
+  subprocess.check_call(['hipcc'] + FLAGS + ['-c', src, '-o', tmp])
+  os.replace(tmp, obj)                      # atomic: a concurrent reader never sees a half-written file
   return obj
 
 
-def build(force=False, verbose=False):
+@contextlib.contextmanager
+def _locked():
+  """One builder at a time: several ranks / helper processes import the package concurrently."""
   os.makedirs(LIB_DIR, exist_ok=True)
-  srcs, hdrs = sources(), _deps()
+  with open(os.path.join(LIB_DIR, '.build.lock'), 'w') as f:
+    fcntl.flock(f, fcntl.LOCK_EX)
+    try:
+      yield
+    finally:
+      fcntl.flock(f, fcntl.LOCK_UN)
+
+
+HASH_PATH = os.path.join(LIB_DIR, '.build_hash')
+
+
+def _digest(paths):
+  import hashlib  # pylint: disable=import-outside-toplevel
+  h = hashlib.sha256(' '.join(FLAGS).encode())
+  for p in sorted(paths):
+    h.update(os.path.basename(p).encode())
+    with open(p, 'rb') as f:
+      h.update(f.read())
+  return h.hexdigest()
+
+
+def source_hashes():
+  """{object file name: sha256 over the flags, its source and every header}."""
+  hdrs = _deps()
+  return {os.path.basename(s)[:-4] + '.o': _digest([s] + hdrs) for s in sources()}
+
+
+def _recorded():
+  import json  # pylint: disable=import-outside-toplevel
+  try:
+    with open(HASH_PATH) as f:
+      return json.load(f)
+  except (OSError, ValueError):
+    return {}
+
+
+def needs_build():
+  """True when the library does not match the sources.  Decided by CONTENT (hashes recorded next to
+  the library at build time), not by mtimes: a snapshot copied to another machine may carry any
+  timestamps, and must neither rebuild needlessly nor run stale kernels."""
+  return not os.path.exists(SO_PATH) or _recorded() != source_hashes()
+
+
+def build(force=False, verbose=False):
+  if not force and not needs_build():        # the common import: nothing to do, no lock traffic
+    return SO_PATH
+  with _locked():
+    return _build_locked(force, verbose)
+
+
+def _build_locked(force, verbose):
+  import json  # pylint: disable=import-outside-toplevel
+  want, have = source_hashes(), _recorded()
+  if not force and os.path.exists(SO_PATH) and want == have:
+    return SO_PATH                           # another process built it while we waited for the lock
   objs, jobs = [], []
-  for s in srcs:
-    o = os.path.join(LIB_DIR, os.path.basename(s)[:-4] + '.o')
+  for s in sources():
+    name = os.path.basename(s)[:-4] + '.o'
+    o = os.path.join(LIB_DIR, name)
     objs.append(o)
-    if force or _stale(o, [s] + hdrs):
+    if force or not os.path.exists(o) or have.get(name) != want[name]:
       jobs.append((s, o))
   if jobs:
     if verbose:
       print('hipcc:', ' '.join(os.path.basename(s) for s, _ in jobs), flush=True)
     with concurrent.futures.ThreadPoolExecutor(max_workers=min(8, len(jobs))) as ex:
       list(ex.map(lambda so: _compile(*so), jobs))
-  if jobs or force or _stale(SO_PATH, objs):
-    subprocess.check_call(['hipcc', '--offload-arch=gfx950', '-shared', '-fPIC', '-o', SO_PATH] + objs)
+  tmp = f'{SO_PATH}.{os.getpid()}.tmp'
+  subprocess.check_call(['hipcc', '--offload-arch=gfx950', '-shared', '-fPIC', '-o', tmp] + objs)
+  os.replace(tmp, SO_PATH)
+  with open(HASH_PATH + '.tmp', 'w') as f:
+    json.dump(want, f)
+  os.replace(HASH_PATH + '.tmp', HASH_PATH)
   return SO_PATH
 
 

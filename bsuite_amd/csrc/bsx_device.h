@@ -31,6 +31,7 @@ struct bsx_ctl {
   int32_t force_reset;
   uint32_t* mt_state;       // MT19937-exact mode: [624, n_lanes] generator states, else nullptr
   int32_t* mt_pos;          // [n_lanes]
+  double* reward_f64;       // optional f64 copy of the reward column (scalar dm_env view), else nullptr
   bsx_logging_t log;        // log.steps == nullptr: logging off
 };
 
@@ -41,17 +42,20 @@ __device__ __forceinline__ uint64_t bsx_step_of(const bsx_ctl& c) {
 // Opens lane i's environment draw stream for this call: the counter-based stream, or — in
 // MT19937-exact mode — the lane's own RandomState carried in HBM.  bsx_draws_end writes the
 // generator position back (the state words are updated in place by the twist).
+// MT: -1 decide at run time (c.mt_state != nullptr), 0 the MT19937 mode is compiled out.
+template <int MT = -1>
 __device__ __forceinline__ void bsx_draws_begin(bsx_draws* d, const bsx_ctl& c, int64_t i, uint64_t lane,
                                                 uint64_t step) {
   bsx_draws_init(d, c.seed, lane, step, BSX_STREAM_ENV);
-  if (c.mt_state != nullptr) {
+  if (MT != 0 && c.mt_state != nullptr) {
     d->mt = c.mt_state + i;
     d->mt_stride = c.n_lanes;
     d->mt_pos = c.mt_pos[i];
   }
 }
+template <int MT = -1>
 __device__ __forceinline__ void bsx_draws_end(const bsx_draws* d, const bsx_ctl& c, int64_t i) {
-  if (c.mt_state != nullptr) c.mt_pos[i] = d->mt_pos;
+  if (MT != 0 && c.mt_state != nullptr) c.mt_pos[i] = d->mt_pos;
 }
 
 // Reward epilogue of utils/wrappers.py:275-283 (RewardNoise) and :338-346 (RewardScale): non-FIRST
@@ -114,8 +118,9 @@ __device__ __forceinline__ void bsx_track(const bsx_ctl& c, int64_t i, int type,
 
 // The scalar TimeStep fields of one lane: wrapper epilogue + Logging bookkeeping, values only.
 // LOG: -1 decide at run time (c.log.steps != nullptr), 0 logging compiled out, 1 always track.
+// `oi` is the output element (== i for step(); t*B + i inside a fused rollout).
 template <int LOG = -1, int NOISE = -1>
-__device__ __forceinline__ void bsx_emit_values(const bsx_ctl& c, int64_t i, uint64_t lane, uint64_t step,
+__device__ __forceinline__ void bsx_emit_values(const bsx_ctl& c, int64_t i, int64_t oi, uint64_t lane, uint64_t step,
                                                 int type, double reward, float& r, float& d) {
   r = 0.0f; d = 1.0f;         // FIRST: dm_env.restart has reward/discount None -> 0 / 1 in a batch
   double wrapped = 0.0;
@@ -124,6 +129,7 @@ __device__ __forceinline__ void bsx_emit_values(const bsx_ctl& c, int64_t i, uin
     r = (float)wrapped;
     d = (type == BSX_LAST) ? 0.0f : 1.0f;
   }
+  if (c.reward_f64 != nullptr) c.reward_f64[oi] = wrapped;
   if (LOG == 1 || (LOG == -1 && c.log.steps != nullptr)) bsx_track(c, i, type, wrapped);
 }
 
@@ -133,7 +139,7 @@ template <int LOG = -1, int NOISE = -1>
 __device__ __forceinline__ void bsx_emit_at(const bsx_ctl& c, const bsx_timestep_t& out, int64_t i, int64_t oi,
                                             uint64_t lane, uint64_t step, int type, double reward) {
   float r, d;
-  bsx_emit_values<LOG, NOISE>(c, i, lane, step, type, reward, r, d);
+  bsx_emit_values<LOG, NOISE>(c, i, oi, lane, step, type, reward, r, d);
   out.reward[oi] = r;
   out.discount[oi] = d;
   out.step_type[oi] = (int8_t)type;

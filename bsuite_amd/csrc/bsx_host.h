@@ -50,6 +50,7 @@ static inline bsx_ctl bsx_make_ctl(const bsx_call_t* call) {
   c.force_reset = call->force_reset;
   c.mt_state = call->stream.mt_state;
   c.mt_pos = call->stream.mt_pos;
+  c.reward_f64 = call->reward_f64;
   if (call->logging != nullptr) c.log = *call->logging;
   else c.log = bsx_logging_t{};
   return c;
@@ -92,7 +93,9 @@ static inline int bsx_launch_hot_stream(float* obs, const int32_t* state, int64_
   static const int k_env = bsx_env_int("BSX_STREAM_K", 0);
   const int k = k_env > 0 ? k_env : default_k;
   const uint64_t total = (uint64_t)n_lanes * cells;
-  if (cells < 4u) {
+  // 4-byte stores for degenerate boards and for an observation slice that does not start on a 16-byte
+  // boundary (rollout slice t of an odd B x cells: t*B*cells*4 bytes into the [T,B,cells] array)
+  if (cells < 4u || (reinterpret_cast<uintptr_t>(obs) & 15u) != 0) {
     const uint64_t blocks = (total + BSX_BLOCK - 1) / BSX_BLOCK;
     if (blocks > 0x7FFFFFFFull) return BSX_EINVAL;
     bsx_hot_stream_tiny_kernel<HotFn><<<dim3((unsigned)blocks), dim3(BSX_BLOCK), 0, st>>>(obs, state, n_lanes, cells, fn);

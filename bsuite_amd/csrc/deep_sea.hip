@@ -135,6 +135,7 @@ extern "C" int bsx_deep_sea_step(const bsx_deep_sea_t* cfg, const bsx_call_t* ca
   for (int t = 0; t < n_steps; ++t) {       // rollout: the kernel pair once per step, outputs [T,B,...]
     const int64_t off = (int64_t)t * call->n_lanes;
     a.ctl.step_index = call->stream.step_index + (uint64_t)t;
+    a.ctl.reward_f64 = call->reward_f64 ? call->reward_f64 + off : nullptr;
     a.action = action ? action + off : action;
     a.out.reward = out.reward + off; a.out.discount = out.discount + off; a.out.step_type = out.step_type + off;
     a.out.observation = out.observation + off * (int64_t)cells;

@@ -199,6 +199,7 @@ extern "C" int bsx_mnist_step(const bsx_mnist_t* cfg, const bsx_call_t* call, co
   for (int t = 0; t < n_steps; ++t) {       // rollout: the kernel pair once per step
     const int64_t off = (int64_t)t * call->n_lanes;
     a.ctl.step_index = call->stream.step_index + (uint64_t)t;
+    a.ctl.reward_f64 = call->reward_f64 ? call->reward_f64 + off : nullptr;
     a.action = action ? action + off : action;
     a.out.reward = out.reward + off; a.out.discount = out.discount + off; a.out.step_type = out.step_type + off;
     mnist_advance_kernel<<<dim3((unsigned)blocks_a), dim3(BSX_BLOCK), 0, st>>>(a);

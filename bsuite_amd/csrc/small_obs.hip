@@ -15,12 +15,16 @@
 // holds Python floats); rewards and the time-fraction observation are formed in f64 exactly as the
 // reference forms them and cast once.
 #include "bsx_host.h"
+#include "bsx_math.h"
 
 // n_steps == 1 is env.step()/reset(); n_steps = T > 1 is the fused rollout: the same thread advances
 // its lane T times inside one launch (actions [T,B], outputs [T,B,...]); per-lane state columns are
 // re-read from L2 by the thread that wrote them, so HBM sees only the action/TimeStep streams —
 // the tiny families are otherwise bound by one ~8 us launch per step.
-template <class Env, int LPB, bool ROLLOUT, int LOG, int NOISE>
+// LOG / NOISE / MT: -1 = decide at run time, 0 = compiled out, 1 = always on.  The common call (no
+// Logging wrapper, no RewardNoise, counter-based draws) runs the <0,0,0> instantiation: without the
+// MT19937 twist, the f64 normal transform and the row snapshots the kernel is a fifth of the size.
+template <class Env, int LPB, bool ROLLOUT, int LOG, int NOISE, int MT>
 __device__ __forceinline__ void small_obs_body(const typename Env::args& a, const int n_steps_arg,
                                                const uint32_t block_id, float* s_obs, unsigned int* s_cnt) {
   const int n_steps = ROLLOUT ? n_steps_arg : 1;   // the single-step instantiation has no loop: keeping
@@ -43,7 +47,7 @@ __device__ __forceinline__ void small_obs_body(const typename Env::args& a, cons
         const uint64_t lane = a.ctl.lane_offset + (uint64_t)i;
         const int64_t oi = (int64_t)t * B + i;
         double reward = 0.0;
-        type = Env::step(a, i, oi, lane, step0 + (uint64_t)t, s_obs + (int)threadIdx.x * numel, reward);
+        type = Env::template step<LOG, MT>(a, i, oi, lane, step0 + (uint64_t)t, s_obs + (int)threadIdx.x * numel, reward);
         bsx_emit_at<LOG, NOISE>(a.ctl, a.out, i, oi, lane, step0 + (uint64_t)t, type, reward);
       }
       bsx_count_types(a.ctl, type, s_cnt);
@@ -65,11 +69,11 @@ __device__ __forceinline__ void small_obs_body(const typename Env::args& a, cons
   bsx_flush_counts(a.ctl, s_cnt, block_id);
 }
 
-template <class Env, int LPB, bool ROLLOUT, int LOG, int NOISE>
+template <class Env, int LPB, bool ROLLOUT, int LOG, int NOISE, int MT>
 __global__ void __launch_bounds__(BSX_BLOCK) small_obs_kernel(const typename Env::args a, const int n_steps) {
   extern __shared__ __attribute__((aligned(16))) float s_obs[];
   __shared__ unsigned int s_cnt[2];
-  small_obs_body<Env, LPB, ROLLOUT, LOG, NOISE>(a, n_steps, blockIdx.x, s_obs, s_cnt);
+  small_obs_body<Env, LPB, ROLLOUT, LOG, NOISE, MT>(a, n_steps, blockIdx.x, s_obs, s_cnt);
 }
 
 // Grouped launch: every workgroup looks up its segment and runs the single-step body on that
@@ -80,7 +84,7 @@ __global__ void __launch_bounds__(BSX_BLOCK) small_obs_group_kernel(const typena
   extern __shared__ __attribute__((aligned(16))) float s_obs[];
   __shared__ unsigned int s_cnt[2];
   const bsx_group_slot w = bsx_group_find(gi, (int)blockIdx.x);
-  small_obs_body<Env, LPB, false, -1, -1>(table[w.seg], 1, w.block, s_obs, s_cnt);
+  small_obs_body<Env, LPB, false, -1, -1, -1>(table[w.seg], 1, w.block, s_obs, s_cnt);
 }
 
 template <class Env>
@@ -125,31 +129,27 @@ template <class Env>
 static int launch_small_obs(const typename Env::args& a, int numel, int n_steps, void* hip_stream) {
   hipStream_t st = (hipStream_t)hip_stream;
   if (n_steps < 1) return BSX_EINVAL;
+  const bool logging = a.ctl.log.steps != nullptr, noise = a.ctl.wrap_kind == BSX_WRAP_NOISE;
+  const bool lean = !logging && !noise && a.ctl.mt_state == nullptr;
+#define SMALL_OBS_LAUNCH(LPB)                                                                              \
+  {                                                                                                        \
+    const int64_t blocks = (a.ctl.n_lanes + (LPB) - 1) / (LPB);                                            \
+    if (blocks > 0x7FFFFFFF) return BSX_EINVAL;                                                            \
+    const size_t lds = (size_t)(LPB) * numel * 4;                                                          \
+    const dim3 g((unsigned)blocks), b(BSX_BLOCK);                                                          \
+    if (n_steps == 1 && lean) small_obs_kernel<Env, LPB, false, 0, 0, 0><<<g, b, lds, st>>>(a, 1);         \
+    else if (n_steps == 1) small_obs_kernel<Env, LPB, false, -1, -1, -1><<<g, b, lds, st>>>(a, 1);         \
+    else if (logging && noise) small_obs_kernel<Env, LPB, true, 1, 1, -1><<<g, b, lds, st>>>(a, n_steps);  \
+    else if (logging) small_obs_kernel<Env, LPB, true, 1, 0, -1><<<g, b, lds, st>>>(a, n_steps);           \
+    else if (noise) small_obs_kernel<Env, LPB, true, 0, 1, -1><<<g, b, lds, st>>>(a, n_steps);             \
+    else if (lean) small_obs_kernel<Env, LPB, true, 0, 0, 0><<<g, b, lds, st>>>(a, n_steps);               \
+    else small_obs_kernel<Env, LPB, true, 0, 0, -1><<<g, b, lds, st>>>(a, n_steps);                        \
+  }
   // Full 256-lane tiles while the LDS tile stays <= 32 KiB (8 resident blocks/CU); 64-lane tiles
   // for the wide umbrella/memory rows.
-  if (numel <= 32) {
-    const int64_t blocks = (a.ctl.n_lanes + 255) / 256;
-    if (blocks > 0x7FFFFFFF) return BSX_EINVAL;
-    const size_t lds = (size_t)256 * numel * 4;
-    const dim3 g((unsigned)blocks), b(BSX_BLOCK);
-    const bool logging = a.ctl.log.steps != nullptr, noise = a.ctl.wrap_kind == BSX_WRAP_NOISE;
-    if (n_steps == 1) small_obs_kernel<Env, 256, false, -1, -1><<<g, b, lds, st>>>(a, 1);
-    else if (logging && noise) small_obs_kernel<Env, 256, true, 1, 1><<<g, b, lds, st>>>(a, n_steps);
-    else if (logging) small_obs_kernel<Env, 256, true, 1, 0><<<g, b, lds, st>>>(a, n_steps);
-    else if (noise) small_obs_kernel<Env, 256, true, 0, 1><<<g, b, lds, st>>>(a, n_steps);
-    else small_obs_kernel<Env, 256, true, 0, 0><<<g, b, lds, st>>>(a, n_steps);
-  } else {
-    const int64_t blocks = (a.ctl.n_lanes + 63) / 64;
-    if (blocks > 0x7FFFFFFF) return BSX_EINVAL;
-    const size_t lds = (size_t)64 * numel * 4;
-    const dim3 g((unsigned)blocks), b(BSX_BLOCK);
-    const bool logging = a.ctl.log.steps != nullptr, noise = a.ctl.wrap_kind == BSX_WRAP_NOISE;
-    if (n_steps == 1) small_obs_kernel<Env, 64, false, -1, -1><<<g, b, lds, st>>>(a, 1);
-    else if (logging && noise) small_obs_kernel<Env, 64, true, 1, 1><<<g, b, lds, st>>>(a, n_steps);
-    else if (logging) small_obs_kernel<Env, 64, true, 1, 0><<<g, b, lds, st>>>(a, n_steps);
-    else if (noise) small_obs_kernel<Env, 64, true, 0, 1><<<g, b, lds, st>>>(a, n_steps);
-    else small_obs_kernel<Env, 64, true, 0, 0><<<g, b, lds, st>>>(a, n_steps);
-  }
+  if (numel <= 32) SMALL_OBS_LAUNCH(256)
+  else SMALL_OBS_LAUNCH(64)
+#undef SMALL_OBS_LAUNCH
   return bsx_launch_status();
 }
 
@@ -159,6 +159,7 @@ struct bandit_env {
     bsx_ctl ctl; const int32_t* action; int32_t* state; bsx_timestep_t out; double* info;
     int32_t obs_numel; int32_t num_actions; double rewards[BSX_BANDIT_MAX_ACTIONS];
   };
+  template <int LOG, int MT>
   __device__ static int step(const args& a, int64_t i, int64_t oi, uint64_t, uint64_t, float* o, double& reward) {
     BSX_NO_CONTRACT
     o[0] = 1.0f;                                                // bandit.py:54 (ones)
@@ -218,18 +219,19 @@ struct memory_chain_env {
     for (int b = 0; b < a.nb; ++b)                              // :69-70
       o[2 + b] = (t == 0) ? (float)(2 * (int)((ctx >> b) & 1ull) - 1) : 0.0f;
   }
+  template <int LOG, int MT>
   __device__ static int step(const args& a, int64_t i, int64_t oi, uint64_t lane, uint64_t step, float* o, double& reward) {
     int32_t st = a.state[i];
     int t = st & 0xFFFFF, query = (st >> 20) & 0xFF;
     uint64_t ctx = a.context[i];
     if (a.ctl.force_reset || (st & MC_RESET_BIT)) {             // :91-97
       bsx_draws d;
-      bsx_draws_begin(&d, a.ctl, i, lane, step);
+      bsx_draws_begin<MT>(&d, a.ctl, i, lane, step);
       ctx = 0;
       uint32_t w = 0;
       for (int b = 0; b < a.nb; ++b) ctx |= (uint64_t)bsx_bern_vec_bit(&d, b, &w) << b;   // BernVec(nb)
       query = (int)bsx_randint(&d, (uint32_t)a.nb);
-      bsx_draws_end(&d, a.ctl, i);
+      bsx_draws_end<MT>(&d, a.ctl, i);
       t = 0;
       a.context[i] = ctx;
       a.state[i] = t | (query << 20);
@@ -290,18 +292,19 @@ struct umbrella_chain_env {
     uint32_t w = 0;
     for (int b = 0; b < a.nd; ++b) o[3 + b] = (float)bsx_bern_vec_bit(d, b, &w);   // :65 BernVec(nd)
   }
+  template <int LOG, int MT>
   __device__ static int step(const args& a, int64_t i, int64_t oi, uint64_t lane, uint64_t step, float* o, double& reward) {
     BSX_NO_CONTRACT
     int32_t st = a.state[i];
     int t = st & 0xFFFFF, need = (st >> 20) & 1, has = (st >> 21) & 1;
     bsx_draws d;
-    bsx_draws_begin(&d, a.ctl, i, lane, step);
+    bsx_draws_begin<MT>(&d, a.ctl, i, lane, step);
     if (a.ctl.force_reset || (st & UC_RESET_BIT)) {             // :87-92
       t = 0;
       need = (int)bsx_bern(&d);
       has = (int)bsx_bern(&d);
       observe(a, o, t, need, has, &d);
-      bsx_draws_end(&d, a.ctl, i);
+      bsx_draws_end<MT>(&d, a.ctl, i);
       a.state[i] = t | (need << 20) | (has << 21);
       return BSX_FIRST;
     }
@@ -318,7 +321,7 @@ struct umbrella_chain_env {
       observe(a, o, t, need, has, &d);
       type = BSX_MID;
     }
-    bsx_draws_end(&d, a.ctl, i);
+    bsx_draws_end<MT>(&d, a.ctl, i);
     a.state[i] = t | (need << 20) | (has << 21) | (type == BSX_LAST ? UC_RESET_BIT : 0);
     return type;
   }
@@ -360,6 +363,7 @@ struct discounting_chain_env {
     bsx_ctl ctl; const int32_t* action; int32_t* state; bsx_timestep_t out;
     int32_t obs_numel; int32_t bonus;
   };
+  template <int LOG, int MT>
   __device__ static int step(const args& a, int64_t i, int64_t oi, uint64_t, uint64_t, float* o, double& reward) {
     BSX_NO_CONTRACT
     int32_t st = a.state[i];
@@ -418,82 +422,112 @@ extern "C" int bsx_group_set_discounting_chain(bsx_group_t* g, int32_t index, co
 
 // ------------------------------------------------------------------------------ cartpole / swingup
 #define CP_RESET_BIT (1 << 30)
+// Info columns (f64 [4,B]): 0 raw_return, 1 best_episode, 2 episode_return, 3 total_upright.
+// Classic cartpole pays r in {0, 1}: an episode of k steps returns (k-1) + [last step rewarded], so
+// raw_return / best_episode / episode_return are EXACT integer-valued functions of the step counter and
+// are folded into the f64 columns only when the episode ends (column 0 then holds finished episodes;
+// the host adds the running episode's k, environments/cartpole.py).  That removes two f64
+// read-modify-writes (32 B) per lane per step — a third of the step's HBM traffic.  Swing-up's
+// rewards (-0.1*|a-1| + 1) do not sum exactly out of order and the fused Logging rows snapshot the
+// columns mid-episode, so swing-up and logging runs keep the reference's per-step accumulation.
 struct cartpole_env {
   struct args {
     bsx_ctl ctl; const int32_t* action; float* state; int32_t* steps; bsx_timestep_t out;
     double* info; int32_t obs_numel; bsx_cartpole_t cfg;
+    // derived on the host in f64, rounded once (cartpole_make)
+    float inv_m_total, pole_ml, pole_ml_over_mt, den_a, den_b, inv_x_threshold;
   };
+  template <int LOG, int MT>
   __device__ static int step(const args& a, int64_t i, int64_t oi, uint64_t lane, uint64_t step, float* o, double& reward) {
     BSX_NO_CONTRACT
     const int64_t B = a.ctl.n_lanes;
     const bsx_cartpole_t& g = a.cfg;
     const int32_t sk = a.steps[i];
+    const bool per_step_info = g.swingup || LOG == 1 || (LOG == -1 && a.ctl.log.steps != nullptr);
     int k = sk & 0x3FFFFFFF;
-    float x, xd, th, thd;
+    float x, xd, th, thd, si, co;
     int type;
     if (a.ctl.force_reset || (sk & CP_RESET_BIT)) {             // cartpole.py:118-128 / swingup:81-91
       bsx_draws d;
-      bsx_draws_begin(&d, a.ctl, i, lane, step);
+      bsx_draws_begin<MT>(&d, a.ctl, i, lane, step);
       const double lo = -g.init_range, hi = g.init_range;
       x = (float)(lo + (hi - lo) * bsx_uniform(&d));
       xd = (float)(lo + (hi - lo) * bsx_uniform(&d));
       th = (float)(g.theta_offset + (lo + (hi - lo) * bsx_uniform(&d)));
       thd = (float)(lo + (hi - lo) * bsx_uniform(&d));
-      bsx_draws_end(&d, a.ctl, i);
+      bsx_draws_end<MT>(&d, a.ctl, i);
       k = 0;
-      a.info[2 * B + i] = 0.0;                                  // _episode_return = 0
+      if (per_step_info) a.info[2 * B + i] = 0.0;               // _episode_return = 0
+      bsx_sincosf(th, &si, &co);                               // |theta_offset| + init_range <= 32 (cartpole_make)
       type = BSX_FIRST;
     } else {
       x = a.state[i]; xd = a.state[B + i]; th = a.state[2 * B + i]; thd = a.state[3 * B + i];
       const int act = a.action[oi];
-      // step_cartpole, cartpole.py:37-65, in f32
+      // step_cartpole, cartpole.py:37-65, in f32.  One sine/cosine pair per step: that of the OLD
+      // angle; the new angle's pair follows from it by the angle-addition formulas below.
+      float s0, c0;
+      bsx_sincosf(th, &s0, &c0);                                // th is in [0, 2*pi) or a reset value
       const float force = (float)(act - 1) * g.force_mag;
-      const float co = cosf(th), si = sinf(th);
-      const float pl = g.mass_pole * g.length;
-      const float m_total = g.mass_cart + g.mass_pole;
-      const float temp = (force + pl * (thd * thd) * si) / m_total;
-      const float theta_acc = (g.gravity * si - co * temp) / (g.length * (4.0f / 3.0f - g.mass_pole * (co * co) / m_total));
-      const float x_acc = temp - pl * theta_acc * co / m_total;
-      const float nx = x + g.timescale * xd;
-      const float nxd = xd + g.timescale * x_acc;
-      // np.remainder(theta + dt*theta_dot, 2*pi): range-reduce in f64 so the period is not the f32 2*pi
-      double ang = fmod((double)th + (double)g.timescale * (double)thd, 6.283185307179586);
-      if (ang < 0.0) ang += 6.283185307179586;
-      const float nthd = thd + g.timescale * theta_acc;
-      x = nx; xd = nxd; th = (float)ang; thd = nthd;
+      const float temp = (force + a.pole_ml * (thd * thd) * s0) * a.inv_m_total;
+      // theta_acc = (g sin - cos*temp) / (l (4/3 - m_p cos^2 / m_t)); v_rcp_f32 is 1 ulp and the
+      // accelerations enter the state scaled by dt = 0.01
+      const float theta_acc = (g.gravity * s0 - c0 * temp) * __builtin_amdgcn_rcpf(a.den_a - a.den_b * (c0 * c0));
+      const float x_acc = temp - a.pole_ml_over_mt * theta_acc * c0;
+      const float dth = g.timescale * thd;
+      x = __builtin_fmaf(g.timescale, xd, x);
+      xd = __builtin_fmaf(g.timescale, x_acc, xd);
+      // np.remainder(theta + dt*theta_dot, 2*pi) in f64 (the period is not the f32 2*pi): one
+      // conditional +-2*pi is exact (Sterbenz) whenever the sum is within one period of [0, 2*pi)
+      double ang = (double)th + (double)g.timescale * (double)thd;
+      if (ang >= 6.283185307179586) ang -= 6.283185307179586;
+      else if (ang < 0.0) ang += 6.283185307179586;
+      if (!(ang >= 0.0 && ang < 6.283185307179586)) {           // |dt*theta_dot| > 2*pi (theta_dot > 600 rad/s:
+        ang = (double)th + (double)g.timescale * (double)thd;   // only reachable from a loaded state)
+        ang -= 6.283185307179586 * floor(ang / 6.283185307179586);
+        if (!(ang >= 0.0 && ang < 6.283185307179586)) ang = 0.0;
+      }
+      th = (float)ang;
+      thd = __builtin_fmaf(g.timescale, theta_acc, thd);
+      if (fabsf(dth) <= 0.5f) bsx_sincos_advance(s0, c0, dth, &si, &co);
+      else bsx_sincosf(th, &si, &co);                           // th is in [0, 2*pi) here
       k += 1;                                                   // time_elapsed += timescale (:63)
       const bool timeout = k >= g.last_step;                    // time_elapsed > max_time
       bool end;
       double r;
       if (!g.swingup) {                                         // cartpole.py:142-153
-        const bool ok = (cosf(th) > g.height_threshold) && (fabsf(x) < g.x_threshold);
+        const bool ok = (co > g.height_threshold) && (fabsf(x) < g.x_threshold);
         r = ok ? 1.0 : 0.0;
         end = timeout || !ok;
       } else {                                                  // swingup:104-123
-        const bool up = (cosf(th) > g.height_threshold) && (fabsf(thd) < g.theta_dot_threshold) &&
+        const bool up = (co > g.height_threshold) && (fabsf(thd) < g.theta_dot_threshold) &&
                         (fabsf(x) < g.x_reward_threshold);
         r = -1.0 * fabs((double)(act - 1)) * g.move_cost;
         if (up) { r += 1.0; a.info[3 * B + i] += 1.0; }
         end = timeout || (fabsf(x) > g.x_threshold);
       }
       reward = r;
-      a.info[i] += r;                                           // _raw_return
-      const double ep = a.info[2 * B + i] + r;                  // _episode_return
-      a.info[2 * B + i] = ep;
-      if (end) {
+      type = end ? BSX_LAST : BSX_MID;
+      if (per_step_info) {
+        a.info[i] += r;                                         // _raw_return
+        const double ep = a.info[2 * B + i] + r;                // _episode_return
+        a.info[2 * B + i] = ep;
+        if (end) {
+          const double best = a.info[B + i];
+          a.info[B + i] = ep > best ? ep : best;                // max(episode_return, best_episode)
+        }
+      } else if (end) {
+        const double ep = (double)(k - 1) + r;                  // sum of the episode's rewards, exact
+        a.info[i] += ep;
         const double best = a.info[B + i];
-        a.info[B + i] = ep > best ? ep : best;                  // max(episode_return, best_episode)
-        type = BSX_LAST;
-      } else {
-        type = BSX_MID;
+        a.info[B + i] = ep > best ? ep : best;
       }
     }
     a.state[i] = x; a.state[B + i] = xd; a.state[2 * B + i] = th; a.state[3 * B + i] = thd;
     a.steps[i] = k | (type == BSX_LAST ? CP_RESET_BIT : 0);
-    o[0] = x / g.x_threshold;                                   // cartpole.py:171-176
-    o[1] = xd / g.x_threshold;
-    o[2] = sinf(th);
-    o[3] = cosf(th);
+    o[0] = x * a.inv_x_threshold;                               // cartpole.py:171-176
+    o[1] = xd * a.inv_x_threshold;
+    o[2] = si;
+    o[3] = co;
     o[4] = thd;
     o[5] = g.time_frac[k < g.last_step ? k : g.last_step];
     if (g.swingup) {                                            // swingup:147-149
@@ -513,6 +547,18 @@ static int cartpole_make(const bsx_cartpole_t* cfg, const bsx_call_t* call, cons
     return BSX_ENULL;
   a->ctl = bsx_make_ctl(call); a->action = action; a->state = state; a->steps = steps; a->out = out;
   a->info = info; a->obs_numel = cfg->swingup ? 8 : 6; a->cfg = *cfg;
+  const double m_total = (double)cfg->mass_cart + (double)cfg->mass_pole;
+  const double pole_ml = (double)cfg->mass_pole * (double)cfg->length;
+  if (!(m_total > 0.0) || !(cfg->x_threshold > 0.0f) || !(cfg->length > 0.0f)) return BSX_ERANGE;
+  // the kernel's sine/cosine is specified for |angle| <= BSX_SINCOS_MAX_ARG; angles live in [0, 2*pi) after
+  // the first step, so only the reset value theta_offset + U(-init_range, init_range) needs the bound
+  if (!(fabs(cfg->theta_offset) + fabs(cfg->init_range) <= 32.0)) return BSX_ERANGE;
+  a->inv_m_total = (float)(1.0 / m_total);
+  a->pole_ml = (float)pole_ml;
+  a->pole_ml_over_mt = (float)(pole_ml / m_total);
+  a->den_a = (float)((double)cfg->length * 4.0 / 3.0);                       // l * 4/3
+  a->den_b = (float)((double)cfg->length * (double)cfg->mass_pole / m_total);  // l * m_p / m_t
+  a->inv_x_threshold = (float)(1.0 / (double)cfg->x_threshold);
   return 0;
 }
 
@@ -534,11 +580,15 @@ extern "C" int bsx_group_set_cartpole(bsx_group_t* g, int32_t index, const bsx_c
 }
 
 // ------------------------------------------------------------------------------ mountain_car
+// Info column 0 = raw_return = -(steps taken): every step pays -1 (mountain_car.py:75-76), so the
+// column is folded at episode ends (+= -t, exact) and the host subtracts the running episode's t;
+// under the fused Logging wrapper (rows snapshot the column mid-episode) it is kept per step.
 struct mountain_car_env {
   struct args {
     bsx_ctl ctl; const int32_t* action; float* state; int32_t* steps; bsx_timestep_t out;
     double* info; int32_t obs_numel; int32_t max_steps;
   };
+  template <int LOG, int MT>
   __device__ static int step(const args& a, int64_t i, int64_t oi, uint64_t lane, uint64_t step, float* o, double& reward) {
     BSX_NO_CONTRACT
     const int64_t B = a.ctl.n_lanes;
@@ -548,29 +598,32 @@ struct mountain_car_env {
     int type;
     if (a.ctl.force_reset || (sk & CP_RESET_BIT)) {             // mountain_car.py:66-71
       bsx_draws d;
-      bsx_draws_begin(&d, a.ctl, i, lane, step);
+      bsx_draws_begin<MT>(&d, a.ctl, i, lane, step);
       t = 0;
       pos = (float)(-0.6 + (-0.4 - -0.6) * bsx_uniform(&d));
-      bsx_draws_end(&d, a.ctl, i);
+      bsx_draws_end<MT>(&d, a.ctl, i);
       vel = 0.0f;
       type = BSX_FIRST;
     } else {
       pos = a.state[i]; vel = a.state[B + i];
       t += 1;                                                   // :74
       reward = -1.0;
-      a.info[i] += reward;                                      // :76
-      vel += (float)(a.action[oi] - 1) * 0.001f + cosf(3.0f * pos) * -0.0025f;   // :79-80
+      float sn, cs;
+      bsx_sincosf(3.0f * pos, &sn, &cs);                        // position is clipped to [-1.2, 0.6]
+      vel += (float)(a.action[oi] - 1) * 0.001f + cs * -0.0025f;   // :79-80
       vel = fminf(fmaxf(vel, -0.07f), 0.07f);                   // :81
       pos += vel;                                               // :82
       pos = fminf(fmaxf(pos, -1.2f), 0.6f);                     // :83
       if (pos == -1.2f) vel = fminf(fmaxf(vel, 0.0f), 0.07f);   // :84-85
       type = (pos >= 0.5f || t >= a.max_steps) ? BSX_LAST : BSX_MID;   // :88-90
+      if (LOG == 1 || (LOG == -1 && a.ctl.log.steps != nullptr)) a.info[i] += reward;   // :76, per step under Logging
+      else if (type == BSX_LAST) a.info[i] -= (double)t;        // the episode's t rewards of -1, exact
     }
     a.state[i] = pos; a.state[B + i] = vel;
     a.steps[i] = t | (type == BSX_LAST ? CP_RESET_BIT : 0);
     o[0] = pos;                                                 // :62-64
     o[1] = vel;
-    o[2] = (float)((double)t / (double)a.max_steps);
+    o[2] = (float)t / (float)a.max_steps;                       // both exact in f32; correctly rounded quotient
     return type;
   }
 };
@@ -615,7 +668,7 @@ __global__ void __launch_bounds__(BSX_BLOCK) small_obs_mixed_group_kernel(const 
   const uint32_t blk = w.block;
   const uint8_t* slot = table + (size_t)seg * SMALL_MIXED_STRIDE;
 #define SMALL_MIXED_CASE(FAM, ENV) \
-  case FAM: small_obs_body<ENV, LPB, false, -1, -1>(*reinterpret_cast<const ENV::args*>(slot), 1, blk, s_obs, s_cnt); break;
+  case FAM: small_obs_body<ENV, LPB, false, -1, -1, -1>(*reinterpret_cast<const ENV::args*>(slot), 1, blk, s_obs, s_cnt); break;
   switch (family[seg]) {                           // uniform per workgroup
     SMALL_MIXED_CASE(BSX_FAM_BANDIT, bandit_env)
     SMALL_MIXED_CASE(BSX_FAM_MEMORY_CHAIN, memory_chain_env)

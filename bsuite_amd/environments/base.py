@@ -102,6 +102,7 @@ class Environment(dm_env.EnvironmentBase):
         if len(self._mt_seeds) != self._batch:
           raise ValueError('need one seed per lane')
     self._wrap = (_native.WRAP_NONE, 0.0, 0)
+    self._logging = None
     self._step_index = 0
     self._buf = 0
     self._allocated = False
@@ -154,6 +155,10 @@ class Environment(dm_env.EnvironmentBase):
     static arguments — `action` is read in place every group step, outputs go to buffer 0, the call
     index comes from the (shared) device step counter."""
     self._ensure_allocated()
+    if (not torch.is_tensor(action) or action.dtype != torch.int32 or action.device != self._device
+        or tuple(action.shape) != (self._batch,) or not action.is_contiguous()):
+      raise ValueError(f'grouped launches read the action tensor in place every step: need a contiguous int32 '
+                       f'tensor of shape ({self._batch},) on {self._device}')
     if not self._device_step_counter:
       raise ValueError('grouped launches need device_step_counter / shared_step_counter')
     if self._delta:
@@ -209,6 +214,8 @@ class Environment(dm_env.EnvironmentBase):
       self._paint = ([torch.full((B,), -1, dtype=torch.int32, device=dev) for _ in range(self._num_buffers)]
                      if self._delta else None)
       self._scalar_action = torch.zeros(1, dtype=torch.int32, **place)
+      # scalar view: the reward as the f64 the reference returns (not its f32 rounding)
+      self._reward_f64 = torch.zeros(1, dtype=torch.float64, **place) if self._scalar else None
       self._out_np = [{k: v.numpy() for k, v in o.items()} for o in self._out] if self._host_out else None
     mt_state_ptr = mt_pos_ptr = None
     if self._rng_mode == 'mt19937':
@@ -231,6 +238,8 @@ class Environment(dm_env.EnvironmentBase):
                               mt_state_ptr, mt_pos_ptr),
         wrap=_native.RewardWrap(_native.WRAP_NONE, 0, 0.0, 0),
         counters=self._counters.data_ptr(), hip_stream=None)
+    if self._reward_f64 is not None:
+      self._call_desc.reward_f64 = self._reward_f64.data_ptr()
     self._allocated = True
 
   # ----------------------------------------------------------------------------------------
@@ -270,16 +279,31 @@ class Environment(dm_env.EnvironmentBase):
                      max_rows: Optional[int] = None, max_count: Optional[int] = None):
     """Turns on per-lane steps/episode/return tracking and log-spaced snapshot rows.
 
-    max_count: largest episode (or step) count to tabulate log points for (default: 100 x
-    bsuite_num_episodes, at least 10^6).  max_rows: snapshot rows kept per lane (default: number of
-    log points up to max_count, or 4096 with log_every)."""
+    max_count: largest episode (or step) count to tabulate log points for (default 10^18: every
+    count a 63-bit counter can reach — 14 points per decade, a few hundred entries).
+    max_rows: snapshot rows kept per lane.  Default: every row a run of any length can produce at
+    log points — len(points) + 2, twice that with log_by_step (a log-point LAST and the FIRST after
+    it share one step count and both log, wrappers.py:96-102) — or 4096 with log_every in the
+    batched view; the scalar view hands each row to its logger right after the step and reuses the
+    buffer, so it never fills.  Rows past max_rows are counted, not stored: `Logging.rows()` raises."""
     from bsuite_amd.utils import wrappers as _w  # pylint: disable=import-outside-toplevel
     self._ensure_allocated()
+    if self._logging is None:
+      # Families that fold an info column only at episode ends (cartpole, mountain_car) switch to the
+      # reference's per-step accumulation under Logging, whose rows snapshot the columns mid-episode:
+      # bring the columns up to date with the running episodes first.
+      for j, pending in self._pending_info().items():
+        self._info[j] += pending
     if max_count is None:
-      max_count = max(10 ** 6, 100 * int(getattr(self, 'bsuite_num_episodes', 0) or 0))
+      max_count = 10 ** 18
     points = _w.logarithmic_logging_points(max_count)
     if max_rows is None:
-      max_rows = 4096 if log_every else len(points) + 2
+      if self._scalar:
+        max_rows = 8
+      elif log_every:
+        max_rows = 4096
+      else:
+        max_rows = (2 if log_by_step else 1) * len(points) + 2
     B, dev = self._batch, self._device
     n_info = len(self._info_keys)
     # scalar view: the one lane's counters and rows sit in mapped host memory like its TimeStep, so
@@ -339,12 +363,12 @@ class Environment(dm_env.EnvironmentBase):
     if self._host_out:
       torch.cuda.current_stream(self._device).synchronize()     # the TimeStep is now in host memory
       o = next(n for n, t in zip(self._out_np, self._out) if t is out)
-      st, reward, discount = int(o['step_type'][0]), float(o['reward'][0]), float(o['discount'][0])
+      st, reward, discount = int(o['step_type'][0]), float(self._reward_f64.numpy()[0]), float(o['discount'][0])
       obs = o['observation'][0].copy()                          # fresh array per step, like the reference
     else:
       st = int(out['step_type'].item())
       obs = out['observation'][0].cpu().numpy()
-      reward, discount = float(out['reward'].item()), float(out['discount'].item())
+      reward, discount = float(self._reward_f64.item()), float(out['discount'].item())
     if st == _native.FIRST:
       return dm_env.restart(obs)
     if st == _native.LAST:
@@ -435,18 +459,36 @@ class Environment(dm_env.EnvironmentBase):
   def action_spec(self):
     return specs.DiscreteArray(self._num_actions, name='action')
 
+  def _pending_info(self) -> Dict[int, torch.Tensor]:
+    """Subclass hook: {info column index: f64 [B] tensor} — what the RUNNING episodes have earned
+    so far in columns that the kernel folds into `_info` only at episode ends (an exact function of
+    the lane's step counter; see cartpole / mountain_car).  Empty for every other family."""
+    return {}
+
+  def _info_columns(self) -> torch.Tensor:
+    """The f64 [K, B] bsuite_info accumulators as the reference would report them right now."""
+    pending = {} if self._logging is not None else self._pending_info()
+    if not pending:
+      return self._info
+    cols = self._info.clone()
+    for j, p in pending.items():
+      cols[j] += p
+    return cols
+
   def bsuite_info(self) -> Dict[str, Any]:
     """Logging metadata (base.py:75-77).  Scalar view: Python numbers as in the reference.
-    Batched view: one f64 device tensor [B] per key (views of the engine's accumulators)."""
+    Batched view: one f64 device tensor [B] per key (the engine's accumulators; for cartpole and
+    mountain_car `raw_return` is a fresh tensor that includes the running episodes)."""
     self._ensure_allocated()
+    info = self._info_columns()
     if self._scalar:
-      vals = self._info[:, 0].cpu().numpy()
+      vals = info[:, 0].cpu().numpy()
       out = {}
       for j, k in enumerate(self._info_keys):
         if not k.startswith('_'):      # '_x' columns are engine-internal accumulators
           out[k] = int(vals[j]) if k in self._info_int_keys else float(vals[j])
       return out
-    return {k: self._info[j] for j, k in enumerate(self._info_keys) if not k.startswith('_')}
+    return {k: info[j] for j, k in enumerate(self._info_keys) if not k.startswith('_')}
 
   def episode_counters(self) -> torch.Tensor:
     """int64 [2] device tensor: lanes that emitted LAST, lanes that emitted FIRST (all calls so
@@ -472,6 +514,10 @@ class Environment(dm_env.EnvironmentBase):
     d['__seed'] = self._seed
     if self._rng_mode == 'mt19937':
       d['__mt_state'], d['__mt_pos'] = self._mt_state.clone(), self._mt_pos.clone()
+    d['__wrap'] = tuple(self._wrap)                       # fused RewardNoise / RewardScale epilogue
+    if self._logging is not None:                         # fused Logging bookkeeping (counters + rows)
+      for k in ('steps', 'episode', 'total_return', 'episode_len', 'episode_return', 'rows', 'n_rows'):
+        d['__logging_' + k] = self._logging[k].clone()
     return d
 
   def load_state_dict(self, d: Dict[str, Any]):
@@ -488,3 +534,15 @@ class Environment(dm_env.EnvironmentBase):
     if self._rng_mode == 'mt19937':
       self._mt_state.copy_(d['__mt_state'])
       self._mt_pos.copy_(d['__mt_pos'])
+    if '__wrap' in d:
+      self._wrap = tuple(d['__wrap'])
+    has_log = '__logging_steps' in d
+    if has_log != (self._logging is not None):
+      raise ValueError('state_dict was taken %s the Logging wrapper but this environment runs %s it: '
+                       'wrap (or unwrap) the environment before load_state_dict'
+                       % (('with', 'without') if has_log else ('without', 'with')))
+    if has_log:
+      if d['__logging_rows'].shape != self._logging['rows'].shape:
+        raise ValueError('Logging row buffers differ in shape (max_rows): construct Logging with the same max_rows')
+      for k in ('steps', 'episode', 'total_return', 'episode_len', 'episode_return', 'rows', 'n_rows'):
+        self._logging[k].copy_(d['__logging_' + k])

@@ -84,6 +84,15 @@ class Cartpole(_CartpoleBase):
 
   _info_keys = ('raw_return', 'best_episode', '_episode_return', '_total_upright')
 
+  def _pending_info(self):
+    # Rewards are 1 on every step that does not end the episode (cartpole.py:142-149), so a running
+    # episode of k steps has earned exactly k; the kernel folds (k-1) + last reward into raw_return /
+    # best_episode when the episode ends (csrc/small_obs.hip, cartpole_env).
+    steps = self._state['steps']
+    running = (steps & (1 << 30)) == 0
+    k = torch.where(running, steps & 0x3FFFFFFF, torch.zeros_like(steps)).to(torch.float64)
+    return {0: k, 2: k}
+
   def __init__(self,
                height_threshold: float = 0.8,
                x_threshold: float = 3.,

@@ -29,5 +29,12 @@ class MountainCar(base.Environment):
 
   _abi_name = 'mountain_car'
 
+  def _pending_info(self):
+    # every step pays -1 (mountain_car.py:75-76): a running episode of t steps has earned -t; the
+    # kernel folds it into raw_return when the episode ends (csrc/small_obs.hip, mountain_car_env)
+    steps = self._state['steps']
+    running = (steps & (1 << 30)) == 0
+    return {0: -torch.where(running, steps & 0x3FFFFFFF, torch.zeros_like(steps)).to(torch.float64)}
+
   def _native_args(self, call, action_ptr, out):
     return (ctypes.byref(self._cfg), ctypes.byref(call), action_ptr, self._state['state'].data_ptr(), self._state['steps'].data_ptr(), out, self._info.data_ptr())

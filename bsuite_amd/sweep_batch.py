@@ -102,12 +102,16 @@ class SweepBatch:
 
   # ---------------------------------------------------------------------------------------
   def random_actions(self, seed: int = 0) -> List[torch.Tensor]:
-    """One int32 action tensor per local segment (uniform over each action_spec)."""
+    """One int32 action tensor per local segment (uniform over each action_spec).  The generator is
+    re-seeded per segment from (seed, global segment index), so a segment gets the same actions
+    whichever rank it was packed onto."""
     g = torch.Generator(device=self.device)
-    g.manual_seed(seed)
-    return [torch.randint(env.action_spec().num_values, (lanes,), generator=g, device=self.device,
-                          dtype=torch.int32)
-            for env, (_, _, lanes) in zip(self.envs, self.segments)]
+    out = []
+    for k, (env, (_, _, lanes)) in zip(self.local, zip(self.envs, self.segments)):
+      g.manual_seed(int(seed) * 1000003 + k)
+      out.append(torch.randint(env.action_spec().num_values, (lanes,), generator=g, device=self.device,
+                               dtype=torch.int32))
+    return out
 
   def _bump(self):
     from bsuite_amd import _native  # pylint: disable=import-outside-toplevel

@@ -144,7 +144,6 @@ class Logging(_RewardWrapper):
     self._log_every = log_every
     self._lg = raw.enable_logging(log_by_step=log_by_step, log_every=log_every, max_rows=max_rows)
     self._columns = raw.logging_columns()
-    self._written = 0
 
   def flush(self):
     if hasattr(self._logger, 'flush'):
@@ -153,12 +152,16 @@ class Logging(_RewardWrapper):
   def _forward_new_rows(self):
     if self._logger is None or not self._raw._scalar:  # pylint: disable=protected-access
       return
+    # Rows are consumed right after the step that produced them (at most two per call), then the
+    # lane's row buffer is rewound: a run of any length never fills it.
     n = int(self._lg['n_rows'][0].item())
-    if n > self._written:
-      rows = self._lg['rows'][0, self._written:n].cpu().numpy()
+    if n:
+      if n > self._lg['rows'].shape[1]:
+        raise RuntimeError(f'{n} log rows in one call exceed the row buffer ({self._lg["rows"].shape[1]})')
+      rows = self._lg['rows'][0, :n].cpu().numpy()
       for r in rows:
         self._logger.write(self._row_dict(r))
-      self._written = n
+      self._lg['n_rows'].zero_()
     if int(self._lg['episode'][0].item()) == self._raw.bsuite_num_episodes:
       self.flush()
 
@@ -192,9 +195,28 @@ class Logging(_RewardWrapper):
     """int32 [B] device tensor: rows each lane has logged so far."""
     return self._lg['n_rows']
 
+  def overflowed(self):
+    """bool [B] device tensor: lanes that logged more rows than the buffer holds (rows past
+    `max_rows` are counted but not stored; size `max_rows` for the run, see enable_logging)."""
+    return self._lg['n_rows'] > self._lg['rows'].shape[1]
+
   def rows(self, lane: int = 0) -> List[Dict[str, Any]]:
-    n = min(int(self._lg['n_rows'][lane].item()), self._lg['rows'].shape[1])
+    n = int(self._lg['n_rows'][lane].item())
+    cap = self._lg['rows'].shape[1]
+    if n > cap:
+      raise RuntimeError(f'lane {lane} logged {n} rows but the buffer holds {cap}: rows were dropped; '
+                         'construct Logging(..., max_rows=...) for the length of the run')
     return [self._row_dict(r) for r in self._lg['rows'][lane, :n].cpu().numpy()]
+
+  def all_rows(self) -> List[List[Dict[str, Any]]]:
+    """rows(lane) for every lane, with one device-to-host copy; raises if any lane overflowed."""
+    n_rows = self._lg['n_rows'].cpu().numpy()
+    cap = self._lg['rows'].shape[1]
+    if (n_rows > cap).any():
+      bad = int((n_rows > cap).sum())
+      raise RuntimeError(f'{bad} lane(s) logged more rows than the buffer holds ({cap}): rows were dropped')
+    rows = self._lg['rows'].cpu().numpy()
+    return [[self._row_dict(r) for r in rows[l, :n_rows[l]]] for l in range(len(n_rows))]
 
   def dataframe(self, lane: int = 0):
     import pandas as pd  # pylint: disable=import-outside-toplevel

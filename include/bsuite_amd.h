@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define BSX_ABI_VERSION 7
+#define BSX_ABI_VERSION 8
 
 #define BSX_FIRST 0
 #define BSX_MID 1
@@ -143,6 +143,10 @@ typedef struct {
                                array contents after the call are identical to the dense mode's.
                                One obs_paint column per observation buffer.  Not available with
                                n_steps > 1, in groups, or for the other families (BSX_EMODE).   */
+  double* reward_f64;       /* device [B] ([T,B] in a rollout) or NULL (ABI v8): the reward BEFORE the
+                               cast to f32 — the f64 value the reference's step() returns (e.g.
+                               deep_sea's -0.01/N move cost, RewardScale's 0.001*r); 0.0 on FIRST.
+                               The scalar dm_env view reads its TimeStep.reward from here.       */
 } bsx_call_t;
 
 /* ---- deep_sea : bsuite/environments/deep_sea.py:51-155 ------------------------------------ */
@@ -236,7 +240,13 @@ typedef struct {
 } bsx_cartpole_t;
 /* state: float [4,B] = x, x_dot, theta, theta_dot ; steps: int32 [B] = k | reset_next<<30
  * (initialise to 1<<30); info double [4,B] = raw_return, best_episode, episode_return,
- * total_upright (cartpole.py:179-181, swingup:152-155); obs float [B,1,6] or [B,1,8] */
+ * total_upright (cartpole.py:179-181, swingup:152-155); obs float [B,1,6] or [B,1,8].
+ * |theta_offset| + init_range must be <= 32 (BSX_ERANGE otherwise).
+ * Accounting of the info columns (ABI v8): swing-up, and any call with call->logging set, accumulate
+ * them per step like the reference.  Classic cartpole without logging (rewards are 0/1, so an episode
+ * of k steps returns exactly (k-1) + its last reward) folds raw_return and best_episode into the
+ * columns when an episode ENDS and leaves episode_return untouched: mid-episode the reference's
+ * raw_return is  info[0][i] + (steps[i] >> 30 ? 0 : steps[i] & 0x3FFFFFFF). */
 int bsx_cartpole_step(const bsx_cartpole_t* cfg, const bsx_call_t* call, const int32_t* action,
                       float* state, int32_t* steps, bsx_timestep_t out, double* info);
 
@@ -246,7 +256,10 @@ typedef struct {
   int32_t _pad;
 } bsx_mountain_car_t;
 /* state: float [2,B] = position, velocity ; steps: int32 [B] = timestep | reset_next<<30
- * info double [1,B] = raw_return; obs float [B,1,3] */
+ * info double [1,B] = raw_return; obs float [B,1,3].
+ * Every step pays -1: without call->logging raw_return is folded into the column when an episode
+ * ENDS (ABI v8); mid-episode the reference's value is
+ * info[0][i] - (steps[i] >> 30 ? 0 : steps[i] & 0x3FFFFFFF).  With call->logging it is per step. */
 int bsx_mountain_car_step(const bsx_mountain_car_t* cfg, const bsx_call_t* call,
                           const int32_t* action, float* state, int32_t* steps,
                           bsx_timestep_t out, double* info);

@@ -19,7 +19,9 @@ if _ROOT not in sys.path:
 
 from oracle import replay  # noqa: E402
 
-OUT_DIR = os.path.join(_ROOT, 'tests', 'golden')
+# BSX_GOLDEN_OUT: write somewhere else (tests/test_golden_regen.py regenerates into a scratch directory
+# and diffs against the committed files)
+OUT_DIR = os.environ.get('BSX_GOLDEN_OUT') or os.path.join(_ROOT, 'tests', 'golden')
 
 BIG_LANE = (1 << 33) + 5        # exercises counter word 1
 BIG_STEP = (1 << 34) + 77       # exercises the step[47:32] counter bits
@@ -96,6 +98,10 @@ def _policy_action(family, raw, policy, rnd, num_actions):
   if family == 'memory_chain':
     return int(raw._context[raw._query])  # pylint: disable=protected-access
   if family == 'umbrella_chain':
+    if raw._reset_next_step:  # pylint: disable=protected-access
+      # the call resets and ignores its action; `_need_umbrella` still holds the constructor's
+      # draw, made before the replay stream is attached (unseeded) — do not record it
+      return 0
     return int(raw._need_umbrella)  # pylint: disable=protected-access
   return int(rnd.integers(num_actions))
 

@@ -42,3 +42,109 @@ def to_np(ts):
 
 def f32_bits(x):
   return np.ascontiguousarray(x, np.float32).view(np.uint32)
+
+
+# ---------------------------------------------------------------------------------------------------
+# Physics families (cartpole, swing-up, mountain_car): the contract is per step, teacher-forced from
+# the reference state, |a - b| <= 1e-6 * max(1, |b|) (BASELINE north_star / SURVEY §8c).
+PHYS_TOL = 1e-6
+
+
+def within_tol(got, want):
+  """Elementwise |a-b| <= 1e-6*max(1,|b|) and the error in units of that bound's scale."""
+  got, want = np.asarray(got, np.float64), np.asarray(want, np.float64)
+  scale = np.maximum(1.0, np.abs(want))
+  err = np.abs(got - want) / scale
+  return err <= PHYS_TOL, err
+
+
+def assert_within_tol(got, want, err_msg=''):
+  ok, err = within_tol(got, want)
+  assert ok.all(), f'{err_msg}: max |a-b|/max(1,|b|) = {err.max():.3e} > {PHYS_TOL:g} at {np.argwhere(~ok)[:5].tolist()}'
+  return float(err.max()) if err.size else 0.0
+
+
+def physics_ties(family, cfg, x=None, theta=None, theta_dot=None, position=None):
+  """Per lane: does a quantity that decides step_type / reward / sign flags sit within the tolerance
+  of its threshold (reference f64 state AFTER the call)?  Only then may the f32 engine land on the
+  other side: cos(theta) vs height_threshold, |x| vs x_threshold (cartpole.py:143-146), swing-up's
+  |theta_dot| vs theta_dot_threshold and |x| vs x_reward_threshold (cartpole_swingup.py:104-123,
+  147-149), mountain_car's position vs the 0.5 goal (mountain_car.py:88)."""
+  def near(q, thr):
+    q = np.asarray(q, np.float64)
+    return np.abs(q - thr) <= PHYS_TOL * np.maximum(1.0, np.abs(q))
+  if family == 'mountain_car':
+    return near(position, 0.5)
+  tie = near(np.cos(theta), cfg['height_threshold']) | near(np.abs(x), cfg['x_threshold'])
+  if family == 'cartpole_swingup':
+    tie |= near(np.abs(theta_dot), cfg['theta_dot_threshold']) | near(np.abs(x), cfg['x_reward_threshold'])
+  return tie
+
+
+def cartpole_cfg(family, kwargs):
+  sw = family == 'cartpole_swingup'
+  return dict(height_threshold=kwargs.get('height_threshold', 0.5 if sw else 0.8),
+              x_threshold=kwargs.get('x_threshold', 3.), theta_dot_threshold=kwargs.get('theta_dot_threshold', 1.),
+              x_reward_threshold=kwargs.get('x_reward_threshold', 1.))
+
+
+class PhysicsChecker:
+  """Compares engine TimeSteps with reference ones call by call.  A lane may disagree on step_type,
+  reward or a sign-flag observation ONLY on a call where `physics_ties` holds for it — a genuine
+  threshold tie inside the tolerance; everything else must be within 1e-6*max(1,|b|).  Lanes that
+  ever tied are `tainted`: their bsuite_info accumulators legitimately differ from then on."""
+
+  def __init__(self, family, kwargs, batch):
+    self.family, self.cfg = family, cartpole_cfg(family, kwargs)
+    self.tainted = np.zeros(batch, bool)
+    self.max_err = dict(observation=0.0, reward=0.0)
+    self.calls = 0
+    self.ties = 0
+
+  def check(self, got, want, state, msg=''):
+    """got / want: (step_type, reward, discount, obs) numpy; state: dict of the reference's f64
+    post-call state (x, theta, theta_dot | position)."""
+    gst, gr, gd, go = got
+    st, r, d, o = want
+    tie = physics_ties(self.family, self.cfg, **state)
+    ok_obs, err_obs = within_tol(go, o)
+    live = st != 0
+    ok_r, err_r = within_tol(gr, r)
+    ok_r |= ~live                              # FIRST: reward is None in the reference
+    ok_d = (gd == np.where(live, d, 1.0).astype(np.float32)) | (gst != st)
+    lane_ok = ok_obs.reshape(len(st), -1).all(axis=1) & ok_r & (gst == st) & ok_d
+    bad = ~lane_ok & ~tie
+    assert not bad.any(), (f'{msg}: lanes {np.flatnonzero(bad)[:5].tolist()} differ beyond 1e-6 without a threshold tie; '
+                           f'step_type {gst[bad][:5]} vs {st[bad][:5]}, reward {gr[bad][:5]} vs {r[bad][:5]}, '
+                           f'max obs err {err_obs.reshape(len(st), -1)[bad].max():.3e}')
+    self.ties += int((~lane_ok).sum())
+    self.tainted |= ~lane_ok
+    good = lane_ok
+    if good.any():
+      self.max_err['observation'] = max(self.max_err['observation'], float(err_obs.reshape(len(st), -1)[good].max()))
+      if (good & live).any():
+        self.max_err['reward'] = max(self.max_err['reward'], float(err_r[good & live].max()))
+    self.calls += 1
+
+  def assert_few_ties(self, max_fraction=2e-3):
+    n = self.calls * len(self.tainted)
+    assert self.ties <= max(2, int(max_fraction * n)), f'{self.ties} threshold ties in {n} lane-steps'
+
+
+def oracle_physics_state(orc, family):
+  if family == 'mountain_car':
+    return dict(position=orc.s['position'].copy())
+  s = orc.s['state']
+  return dict(x=s[:, 0].copy(), theta=s[:, 2].copy(), theta_dot=s[:, 3].copy())
+
+
+def teacher_force(raw_env, orc, family):
+  """device f32 state := f32(reference f64 state); step counter and reset flag := the reference's."""
+  if family == 'mountain_car':
+    st32 = np.stack([orc.s['position'], orc.s['velocity']]).astype(np.float32)
+    k = orc.s['timestep'].astype(np.int32)
+  else:
+    st32 = orc.s['state'][:, :4].T.astype(np.float32)
+    k = np.rint(orc.s['state'][:, 4] / orc.cfg.timescale).astype(np.int32)
+  raw_env._state['state'].copy_(torch.from_numpy(np.ascontiguousarray(st32)).cuda())
+  raw_env._state['steps'].copy_(torch.from_numpy(k | (orc.reset_next.astype(np.int32) << 30)).cuda())

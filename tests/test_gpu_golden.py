@@ -54,9 +54,9 @@ def test_engine_matches_reference(name):
       first = gst == 0
       assert (r[first] == 0).all() and (d[first] == 1).all()
       np.testing.assert_array_equal(d[~first], gd[~first].astype(np.float32))
-      if phys:
-        np.testing.assert_allclose(o, go, rtol=TOL, atol=TOL, err_msg=f'{name} obs t={t}')
-        np.testing.assert_allclose(r[~first], gr[~first], rtol=TOL, atol=TOL)
+      if phys:      # |a-b| <= 1e-6*max(1,|b|), the north_star bound (not rtol+atol = 2e-6)
+        eu.assert_within_tol(o, go, err_msg=f'{name} obs t={t}')
+        eu.assert_within_tol(r[~first], gr[~first], err_msg=f'{name} reward t={t}')
       else:
         np.testing.assert_array_equal(eu.f32_bits(r[~first]), eu.f32_bits(gr[~first].astype(np.float32)),
                                       err_msg=f'{name} reward t={t}')

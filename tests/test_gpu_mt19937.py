@@ -47,8 +47,8 @@ def test_engine_reproduces_reference_on_its_own_rng(name):
     np.testing.assert_array_equal(st_, g['step_type'][t], err_msg=f'{name} t={t}')
     live = g['step_type'][t] != 0
     if phys:
-      np.testing.assert_allclose(o, g['obs'][t], rtol=1e-6, atol=1e-6, err_msg=f'{name} obs t={t}')
-      np.testing.assert_allclose(r[live], g['reward'][t][live], rtol=1e-6, atol=1e-6)
+      eu.assert_within_tol(o, g['obs'][t], err_msg=f'{name} obs t={t}')           # |a-b| <= 1e-6*max(1,|b|)
+      eu.assert_within_tol(r[live], g['reward'][t][live], err_msg=f'{name} reward t={t}')
     else:
       np.testing.assert_array_equal(eu.f32_bits(o), eu.f32_bits(g['obs'][t]), err_msg=f'{name} obs t={t}')
       np.testing.assert_array_equal(eu.f32_bits(r[live]), eu.f32_bits(g['reward'][t][live].astype(np.float32)))

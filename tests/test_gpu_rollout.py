@@ -23,12 +23,13 @@ CASES = [
     ('mountain_car', dict(max_steps=15), None, 3),
     ('deep_sea', dict(size=6, deterministic=False, mapping_seed=1), None, 2),
     ('catch', dict(rows=5, columns=3), None, 3),
+    ('catch', dict(), None, 3),        # 50 cells x odd B: slices t*B*50 floats in are not 16-byte aligned
     ('mnist', dict(), None, 10),
 ]
 
 
 @pytest.mark.parametrize('family,kwargs,wrap,na', CASES)
-@pytest.mark.parametrize('batch', [1, 1000])
+@pytest.mark.parametrize('batch', [1, 1000, 333])
 def test_rollout_equals_steps(family, kwargs, wrap, na, batch):
   kw = dict(kwargs)
   if family == 'mnist':

@@ -1,0 +1,64 @@
+"""CPU: the f32 sine/cosine the physics kernels use (bsuite_amd/csrc/bsx_math.h, compiled here by gcc
+from the very same header) against f64 libm on dense samples of the ranges the path produces.
+The per-step contract is 1e-6*max(1,|b|); these routines must leave most of it to the f32 state."""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope='module')
+def shim(tmp_path_factory):
+  so = str(tmp_path_factory.mktemp('pm') / 'physics_math_shim.so')
+  subprocess.check_call(['gcc', '-O2', '-std=gnu99', '-ffp-contract=off', '-shared', '-fPIC',
+                         os.path.join(ROOT, 'tests', 'csrc', 'physics_math_shim.c'), '-o', so, '-lm'])
+  return ctypes.CDLL(so)
+
+
+def _ptr(a):
+  return a.ctypes.data_as(ctypes.c_void_p)
+
+
+def _sincos(shim, x):
+  x = np.ascontiguousarray(x, np.float32)
+  s, c = np.empty_like(x), np.empty_like(x)
+  shim.shim_sincosf(_ptr(x), ctypes.c_int64(x.size), _ptr(s), _ptr(c))
+  return s, c
+
+
+def test_sincos_on_the_state_range(shim):
+  # theta in [0, 2*pi) after np.remainder; resets put it at 0 +- init_range / pi +- init_range;
+  # mountain_car evaluates cos(3*pos) for pos in [-1.2, 0.6]
+  x = np.concatenate([np.linspace(-4.0, 7.0, 2_000_001), np.random.default_rng(0).uniform(-8, 8, 1_000_000)])
+  x = x.astype(np.float32)
+  s, c = _sincos(shim, x)
+  xd = x.astype(np.float64)
+  assert np.max(np.abs(s - np.sin(xd))) < 1.2e-7
+  assert np.max(np.abs(c - np.cos(xd))) < 1.2e-7
+
+
+def test_sincos_quadrants_and_wider_range(shim):
+  k = np.arange(-40, 41)
+  x = np.concatenate([(k * np.pi / 2).astype(np.float32), (k * np.pi / 4).astype(np.float32),
+                      np.random.default_rng(1).uniform(-64, 64, 500_000).astype(np.float32)])
+  s, c = _sincos(shim, x)
+  xd = x.astype(np.float64)
+  assert np.max(np.abs(s - np.sin(xd))) < 1.5e-7
+  assert np.max(np.abs(c - np.cos(xd))) < 1.5e-7
+  s0, c0 = _sincos(shim, np.zeros(1, np.float32))
+  assert (s0[0], c0[0]) == (0.0, 1.0)
+
+
+def test_angle_advance_matches_the_unrounded_angle(shim):
+  rng = np.random.default_rng(2)
+  t = rng.uniform(-0.1, 2 * np.pi, 1_000_000).astype(np.float32)
+  d = np.concatenate([rng.uniform(-0.5, 0.5, 500_000), rng.normal(0, 0.02, 500_000)]).astype(np.float32)
+  s, c = np.empty_like(t), np.empty_like(t)
+  shim.shim_sincos_advance(_ptr(t), _ptr(d), ctypes.c_int64(t.size), _ptr(s), _ptr(c))
+  ang = t.astype(np.float64) + d.astype(np.float64)        # what the f64 reference takes sin/cos of
+  assert np.max(np.abs(s - np.sin(ang))) < 3e-7
+  assert np.max(np.abs(c - np.cos(ang))) < 3e-7
