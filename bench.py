@@ -326,8 +326,9 @@ class Rank:
       graph = torch.cuda.CUDAGraph()
       with torch.cuda.stream(side):
         with torch.cuda.graph(graph, stream=side):
-          for t in range(chunk):
-            env.step(actions[t])
+          with _raw(env).step_counter_deferred():        # one call-counter bump per replay, not per step
+            for t in range(chunk):
+              env.step(actions[t])
       torch.cuda.current_stream(self.dev).wait_stream(side)
 
       def run(n_steps):

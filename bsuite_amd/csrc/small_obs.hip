@@ -456,6 +456,8 @@ struct cartpole_env {
       th = (float)(g.theta_offset + (lo + (hi - lo) * bsx_uniform(&d)));
       thd = (float)(lo + (hi - lo) * bsx_uniform(&d));
       bsx_draws_end<MT>(&d, a.ctl, i);
+      // an explicit reset() in mid-episode abandons it: the k rewards of 1 it has paid stay in raw_return
+      if (!per_step_info && !(sk & CP_RESET_BIT) && k > 0) a.info[i] += (double)k;
       k = 0;
       if (per_step_info) a.info[2 * B + i] = 0.0;               // _episode_return = 0
       bsx_sincosf(th, &si, &co);                               // |theta_offset| + init_range <= 32 (cartpole_make)
@@ -599,6 +601,8 @@ struct mountain_car_env {
     if (a.ctl.force_reset || (sk & CP_RESET_BIT)) {             // mountain_car.py:66-71
       bsx_draws d;
       bsx_draws_begin<MT>(&d, a.ctl, i, lane, step);
+      // an explicit reset() in mid-episode abandons it: its t rewards of -1 stay in raw_return
+      if (!(LOG == 1 || (LOG == -1 && a.ctl.log.steps != nullptr)) && !(sk & CP_RESET_BIT) && t > 0) a.info[i] -= (double)t;
       t = 0;
       pos = (float)(-0.6 + (-0.4 - -0.6) * bsx_uniform(&d));
       bsx_draws_end<MT>(&d, a.ctl, i);

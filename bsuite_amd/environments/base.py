@@ -22,6 +22,7 @@ for the reference's run loop, which holds `timestep` and `new_timestep`
 
 There is no CPU fallback: without a HIP device the first reset()/step() raises.
 """
+import contextlib
 import os
 import secrets
 from typing import Any, Dict, Optional
@@ -103,6 +104,7 @@ class Environment(dm_env.EnvironmentBase):
           raise ValueError('need one seed per lane')
     self._wrap = (_native.WRAP_NONE, 0.0, 0)
     self._logging = None
+    self._deferred_steps = None
     self._step_index = 0
     self._buf = 0
     self._allocated = False
@@ -135,6 +137,26 @@ class Environment(dm_env.EnvironmentBase):
   def device_step_index(self) -> int:
     self._ensure_allocated()
     return int(self._step_base.item()) if self._device_step_counter else self._step_index
+
+  @contextlib.contextmanager
+  def step_counter_deferred(self):
+    """For HIP-graph capture of K consecutive step() calls (needs device_step_counter=True): inside
+    the block the calls take their call index as `device counter + position`, and the counter is
+    bumped ONCE, by K, when the block ends — one small kernel per K steps instead of one per step
+    (a captured graph otherwise carries 2K nodes for K steps)."""
+    if not self._device_step_counter or self._shared_step_counter is not None:
+      raise ValueError('step_counter_deferred() needs an environment built with device_step_counter=True')
+    self._ensure_allocated()
+    self._deferred_steps = 0
+    try:
+      yield self
+    finally:
+      n, self._deferred_steps = self._deferred_steps, None
+      if n:
+        with torch.cuda.device(self._device):
+          _native.check(_native.lib.bsx_counter_add(self._step_base.data_ptr(), n,
+                                                    torch.cuda.current_stream(self._device).cuda_stream),
+                        'step counter bump')
 
   def _state_tensors(self) -> Dict[str, torch.Tensor]:
     """Subclass hook: allocate the family's SoA state columns with their initial values."""
@@ -261,7 +283,13 @@ class Environment(dm_env.EnvironmentBase):
     call.wrap.kind, call.wrap.param, call.wrap.seed = kind, param, wseed
     hip_stream = torch.cuda.current_stream(self._device).cuda_stream
     call.hip_stream = hip_stream
-    if self._device_step_counter:
+    if self._device_step_counter and self._deferred_steps is not None:
+      # inside `step_counter_deferred()`: call index = device counter + position in the block
+      call.stream.step_index = self._deferred_steps
+      rc = self._launch(call, action_ptr, out_ptrs)
+      call.stream.step_index = 0
+      self._deferred_steps += 1
+    elif self._device_step_counter:
       rc = self._launch(call, action_ptr, out_ptrs)
       if rc == 0 and self._shared_step_counter is None:
         rc = _native.lib.bsx_counter_add(self._step_base.data_ptr(), 1, hip_stream)

@@ -46,7 +46,11 @@ def test_state_dict_round_trip_resumes_bit_exactly():
     torch.testing.assert_close(v, info_want[k], rtol=0, atol=0)
 
 
-def test_hip_graph_replay_equals_eager():
+@pytest.mark.parametrize('deferred', [False, True])
+def test_hip_graph_replay_equals_eager(deferred):
+  """deferred=True: the captured steps take their call index as counter + position and the device
+  call counter is bumped once per replay (Environment.step_counter_deferred)."""
+  import contextlib
   B, T, reps, seed = 4096, 8, 5, 11
   a = _acts(T, B, na=2)
   eager = deep_sea.DeepSea(12, deterministic=False, mapping_seed=42, seed=seed, batch=B, num_buffers=1)
@@ -59,8 +63,9 @@ def test_hip_graph_replay_equals_eager():
   g = torch.cuda.CUDAGraph()
   with torch.cuda.stream(side):
     with torch.cuda.graph(g, stream=side):
-      for t in range(T):
-        last = graphed.step(a[t])
+      with (graphed.step_counter_deferred() if deferred else contextlib.nullcontext()):
+        for t in range(T):
+          last = graphed.step(a[t])
   torch.cuda.current_stream().wait_stream(side)
   for _ in range(reps):
     g.replay()
