@@ -440,7 +440,8 @@ class Rank:
     if grouped:
       batch.prepare_groups(acts, mix_small=os.environ.get('BSX_SWEEP_MIX_SMALL', '1') != '0')
       if mode == 'grouped_graph':              # group launches as concurrent branches of one HIP graph
-        batch.capture_grouped(int(os.environ.get('BSX_SWEEP_STREAMS', '2')))
+        batch.capture_grouped(int(os.environ.get('BSX_SWEEP_STREAMS', '2')),
+                              phased=os.environ.get('BSX_SWEEP_PHASED', '1') != '0')
         replay = batch.replay_grouped
       else:
         replay = batch.step_grouped

@@ -58,12 +58,14 @@ def _load():
 class Stream(ctypes.Structure):
   _fields_ = [('seed', ctypes.c_uint64), ('lane_offset', ctypes.c_uint64),
               ('step_index', ctypes.c_uint64), ('step_base', ctypes.c_void_p),
-              ('mt_state', ctypes.c_void_p), ('mt_pos', ctypes.c_void_p)]
+              ('mt_state', ctypes.c_void_p), ('mt_pos', ctypes.c_void_p),
+              ('mt_gauss', ctypes.c_void_p), ('mt_has_gauss', ctypes.c_void_p)]
 
 
 class RewardWrap(ctypes.Structure):
   _fields_ = [('kind', ctypes.c_int32), ('_pad', ctypes.c_int32), ('param', ctypes.c_double),
-              ('seed', ctypes.c_uint64)]
+              ('seed', ctypes.c_uint64), ('mt_state', ctypes.c_void_p), ('mt_pos', ctypes.c_void_p),
+              ('mt_gauss', ctypes.c_void_p), ('mt_has_gauss', ctypes.c_void_p)]
 
 
 class TimeStepPtrs(ctypes.Structure):
@@ -139,11 +141,15 @@ class MountainCarCfg(ctypes.Structure):
 
 
 IMAGE_SMALL, IMAGE_BILINEAR = 0, 1
+IMAGE_MAX_RADIUS = 64
 
 
 class ImageCfg(ctypes.Structure):
   _fields_ = [('mode', ctypes.c_int32), ('in_rows', ctypes.c_int32), ('in_cols', ctypes.c_int32),
-              ('out_rows', ctypes.c_int32), ('out_cols', ctypes.c_int32), ('tail', ctypes.c_int32)]
+              ('out_rows', ctypes.c_int32), ('out_cols', ctypes.c_int32), ('tail', ctypes.c_int32),
+              ('radius_y', ctypes.c_int32), ('radius_x', ctypes.c_int32),
+              ('gauss_y', ctypes.c_double * (IMAGE_MAX_RADIUS + 1)),
+              ('gauss_x', ctypes.c_double * (IMAGE_MAX_RADIUS + 1))]
 
 
 lib = _load()
@@ -181,6 +187,8 @@ _SIGS.update({
     'bsx_group_create': ([ctypes.c_int32, ctypes.c_int32, ctypes.POINTER(_G)], ctypes.c_int),
     'bsx_group_commit': ([_G], ctypes.c_int),
     'bsx_group_step': ([_G, _P], ctypes.c_int),
+    'bsx_group_phases': ([_G], ctypes.c_int),
+    'bsx_group_step_phase': ([_G, ctypes.c_int32, _P], ctypes.c_int),
     'bsx_group_destroy': ([_G], ctypes.c_int),
 })
 for _fam in ('deep_sea', 'catch', 'bandit', 'memory_chain', 'umbrella_chain', 'discounting_chain',

@@ -31,6 +31,12 @@ struct bsx_ctl {
   int32_t force_reset;
   uint32_t* mt_state;       // MT19937-exact mode: [624, n_lanes] generator states, else nullptr
   int32_t* mt_pos;          // [n_lanes]
+  double* mt_gauss;         // [n_lanes] cached second normal of the env generator (nullable)
+  int32_t* mt_has_gauss;
+  uint32_t* wrap_mt_state;  // RewardNoise's own generator in MT19937-exact mode (all four or none)
+  int32_t* wrap_mt_pos;
+  double* wrap_mt_gauss;
+  int32_t* wrap_mt_has_gauss;
   double* reward_f64;       // optional f64 copy of the reward column (scalar dm_env view), else nullptr
   bsx_logging_t log;        // log.steps == nullptr: logging off
 };
@@ -51,11 +57,15 @@ __device__ __forceinline__ void bsx_draws_begin(bsx_draws* d, const bsx_ctl& c, 
     d->mt = c.mt_state + i;
     d->mt_stride = c.n_lanes;
     d->mt_pos = c.mt_pos[i];
+    if (c.mt_gauss != nullptr) { d->mt_has_gauss = c.mt_has_gauss[i]; d->mt_gauss = c.mt_gauss[i]; }
   }
 }
 template <int MT = -1>
 __device__ __forceinline__ void bsx_draws_end(const bsx_draws* d, const bsx_ctl& c, int64_t i) {
-  if (MT != 0 && c.mt_state != nullptr) c.mt_pos[i] = d->mt_pos;
+  if (MT != 0 && c.mt_state != nullptr) {
+    c.mt_pos[i] = d->mt_pos;
+    if (c.mt_gauss != nullptr) { c.mt_has_gauss[i] = d->mt_has_gauss; c.mt_gauss[i] = d->mt_gauss; }
+  }
 }
 
 // Reward epilogue of utils/wrappers.py:275-283 (RewardNoise) and :338-346 (RewardScale): non-FIRST
@@ -63,13 +73,25 @@ __device__ __forceinline__ void bsx_draws_end(const bsx_draws* d, const bsx_ctl&
 // NOISE = 0 compiles the RewardNoise branch out: its ~100 f64 polynomial constants are otherwise
 // hoisted into VGPRs ahead of the T-step rollout loop and cost two thirds of the occupancy.
 template <int NOISE = -1>
-__device__ __forceinline__ double bsx_wrap_reward(const bsx_ctl& c, uint64_t lane, uint64_t step,
+__device__ __forceinline__ double bsx_wrap_reward(const bsx_ctl& c, int64_t i, uint64_t lane, uint64_t step,
                                                   double reward) {
   BSX_NO_CONTRACT
   if (c.wrap_kind == BSX_WRAP_SCALE) return reward * c.wrap_param;
   if (NOISE != 0 && c.wrap_kind == BSX_WRAP_NOISE) {
     bsx_draws w;
     bsx_draws_init(&w, c.wrap_seed, lane, step, BSX_STREAM_WRAP);
+    if (c.wrap_mt_state != nullptr) {       // MT19937-exact mode: the wrapper's own RandomState (wrappers.py:267)
+      w.mt = c.wrap_mt_state + i;
+      w.mt_stride = c.n_lanes;
+      w.mt_pos = c.wrap_mt_pos[i];
+      w.mt_has_gauss = c.wrap_mt_has_gauss[i];
+      w.mt_gauss = c.wrap_mt_gauss[i];
+      const double z = bsx_normal(&w);
+      c.wrap_mt_pos[i] = w.mt_pos;
+      c.wrap_mt_has_gauss[i] = w.mt_has_gauss;
+      c.wrap_mt_gauss[i] = w.mt_gauss;
+      return reward + c.wrap_param * z;
+    }
     return reward + c.wrap_param * bsx_normal(&w);
   }
   return reward;
@@ -125,7 +147,7 @@ __device__ __forceinline__ void bsx_emit_values(const bsx_ctl& c, int64_t i, int
   r = 0.0f; d = 1.0f;         // FIRST: dm_env.restart has reward/discount None -> 0 / 1 in a batch
   double wrapped = 0.0;
   if (type != BSX_FIRST) {
-    wrapped = bsx_wrap_reward<NOISE>(c, lane, step, reward);
+    wrapped = bsx_wrap_reward<NOISE>(c, i, lane, step, reward);
     r = (float)wrapped;
     d = (type == BSX_LAST) ? 0.0f : 1.0f;
   }

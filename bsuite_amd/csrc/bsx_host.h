@@ -23,7 +23,11 @@ static inline int bsx_check_call(const bsx_call_t* call, const void* action, con
   if (call->wrap.kind < BSX_WRAP_NONE || call->wrap.kind > BSX_WRAP_NOISE) return BSX_EINVAL;
   if (call->n_steps < 0 || (call->n_steps > 1 && call->force_reset)) return BSX_EINVAL;
   if ((call->stream.mt_state == nullptr) != (call->stream.mt_pos == nullptr)) return BSX_ENULL;
-  if (call->stream.mt_state != nullptr && call->wrap.kind == BSX_WRAP_NOISE) return BSX_EMODE;
+  if ((call->stream.mt_gauss == nullptr) != (call->stream.mt_has_gauss == nullptr)) return BSX_ENULL;
+  if (call->stream.mt_state != nullptr && call->wrap.kind == BSX_WRAP_NOISE &&
+      (call->wrap.mt_state == nullptr || call->wrap.mt_pos == nullptr || call->wrap.mt_gauss == nullptr ||
+       call->wrap.mt_has_gauss == nullptr))
+    return BSX_ENULL;                      // MT19937-exact RewardNoise needs the wrapper's own generator
   if (call->logging != nullptr) {
     const bsx_logging_t* g = call->logging;
     if (g->steps == nullptr || g->episode == nullptr || g->total_return == nullptr || g->episode_len == nullptr ||
@@ -50,6 +54,13 @@ static inline bsx_ctl bsx_make_ctl(const bsx_call_t* call) {
   c.force_reset = call->force_reset;
   c.mt_state = call->stream.mt_state;
   c.mt_pos = call->stream.mt_pos;
+  c.mt_gauss = call->stream.mt_gauss;
+  c.mt_has_gauss = call->stream.mt_has_gauss;
+  const bool wrap_mt = call->stream.mt_state != nullptr && call->wrap.kind == BSX_WRAP_NOISE;
+  c.wrap_mt_state = wrap_mt ? call->wrap.mt_state : nullptr;
+  c.wrap_mt_pos = wrap_mt ? call->wrap.mt_pos : nullptr;
+  c.wrap_mt_gauss = wrap_mt ? call->wrap.mt_gauss : nullptr;
+  c.wrap_mt_has_gauss = wrap_mt ? call->wrap.mt_has_gauss : nullptr;
   c.reward_f64 = call->reward_f64;
   if (call->logging != nullptr) c.log = *call->logging;
   else c.log = bsx_logging_t{};
@@ -146,7 +157,11 @@ struct bsx_group {
   bsx_group_index index2() const { bsx_group_index gi; gi.start = d_start2; gi.map = d_map2; gi.n = n; return gi; }
   int64_t total_blocks = 0, total_blocks2 = 0;
   bool committed = false;
-  int (*launch)(bsx_group*, hipStream_t) = nullptr;
+  // launch(g, phase, stream): phase 0 = the first kernel (the lane advance of a two-kernel family, or the
+  // whole step of a small-observation group), phase 1 = the observation stream kernel of a two-kernel
+  // family (depends on phase 0 of the same group only), phase < 0 = both in order.
+  int (*launch)(bsx_group*, int, hipStream_t) = nullptr;
+  int n_phases = 1;
 };
 
 static inline uint64_t bsx_flat_blocks(uint64_t total_floats, int k) {
@@ -173,11 +188,13 @@ static inline int bsx_group_put_pair(bsx_group* g, int32_t index, const typename
 }
 
 template <class Fam, class HotFn, int K>
-static int bsx_group_launch_pair(bsx_group* g, hipStream_t st) {
-  bsx_advance_group_kernel<Fam><<<dim3((unsigned)g->total_blocks), dim3(BSX_BLOCK), 0, st>>>(
-      (const typename Fam::args*)g->d_args, g->index1());
-  bsx_hot_stream_group_kernel<HotFn, K><<<dim3((unsigned)g->total_blocks2), dim3(BSX_BLOCK), 0, st>>>(
-      (const bsx_stream_seg<HotFn>*)g->d_args2, g->index2());
+static int bsx_group_launch_pair(bsx_group* g, int phase, hipStream_t st) {
+  if (phase != 1)
+    bsx_advance_group_kernel<Fam><<<dim3((unsigned)g->total_blocks), dim3(BSX_BLOCK), 0, st>>>(
+        (const typename Fam::args*)g->d_args, g->index1());
+  if (phase != 0)
+    bsx_hot_stream_group_kernel<HotFn, K><<<dim3((unsigned)g->total_blocks2), dim3(BSX_BLOCK), 0, st>>>(
+        (const bsx_stream_seg<HotFn>*)g->d_args2, g->index2());
   return (int)hipGetLastError();
 }
 

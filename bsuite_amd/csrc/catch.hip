@@ -119,6 +119,7 @@ extern "C" int bsx_group_set_catch(bsx_group_t* g, int32_t index, const bsx_catc
   rc = catch_make(cfg, call, action, state, out, info, &a);
   if (rc != 0) return rc;
   g->launch = bsx_group_launch_pair<catch_fam, catch_hot, 2>;
+  g->n_phases = 2;
   return bsx_group_put_pair<catch_fam, catch_hot>(g, index, a, out.observation, state,
                                                   (uint32_t)(cfg->rows * cfg->columns),
                                                   catch_hot{cfg->rows, cfg->columns}, 2);

@@ -110,7 +110,8 @@ static int deep_sea_make(const bsx_deep_sea_t* cfg, const bsx_call_t* call, cons
   int rc = bsx_check_call(call, action, out, /*delta_ok=*/true);
   if (rc != 0) return rc;
   if (cfg->size < 1 || cfg->size > BSX_DEEP_SEA_MAX_SIZE) return BSX_ERANGE;
-  if (call->stream.mt_state != nullptr && !cfg->deterministic) return BSX_EMODE;   // needs randn
+  if (call->stream.mt_state != nullptr && !cfg->deterministic && call->stream.mt_gauss == nullptr)
+    return BSX_ENULL;                      // the stochastic variant draws randn: needs the gauss cache columns
   if (call->n_lanes > 0 && (state == nullptr || info == nullptr)) return BSX_ENULL;
   a->ctl = bsx_make_ctl(call);
   a->action = action; a->state = state; a->out = out; a->info = info;
@@ -162,6 +163,7 @@ extern "C" int bsx_group_set_deep_sea(bsx_group_t* g, int32_t index, const bsx_d
   rc = deep_sea_make(cfg, call, action, state, out, info, &a);
   if (rc != 0) return rc;
   g->launch = bsx_group_launch_pair<deep_sea_fam, deep_sea_hot, 4>;
+  g->n_phases = 2;
   return bsx_group_put_pair<deep_sea_fam, deep_sea_hot>(g, index, a, out.observation, state,
                                                         (uint32_t)(cfg->size * cfg->size), deep_sea_hot{cfg->size}, 4);
 }

@@ -9,14 +9,17 @@
 // lane-interleaved 16-byte stores.
 //
 // Arithmetic of the bilinear rule restates scipy.ndimage.zoom(order=1, mode='mirror',
-// grid_mode=True) — what skimage.transform.resize(order=1, mode='reflect') calls when no
-// anti-aliasing filter applies (output >= input) — operation for operation in f64 without FMA:
+// grid_mode=True) — what skimage.transform.resize(order=1, mode='reflect') calls, after its
+// anti-aliasing Gaussian along the axes that shrink (img_gauss_pass) — operation for operation in
+// f64 without FMA:
 //   zoom = in / out;  cc = ((k + 0.5) * zoom) - 0.5;  cc = mirror(cc);  f = floor(cc);
 //   weights (1 - (cc - f), cc - f) on source indices mirror(f), mirror(f + 1);
 //   t = 0 + (v00*wy0)*wx0 + (v01*wy0)*wx1 + (v10*wy1)*wx0 + (v11*wy1)*wx1;  out = (float)t
 // (pinned bit for bit against scipy in tests/test_image_oracle.py and tests/test_gpu_image.py).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+
+#include <mutex>
 
 #include "../../include/bsuite_amd.h"
 #include "bsx_device.h"
@@ -25,6 +28,8 @@
 struct image_args {
   const float* obs; float* image; int64_t n_lanes;
   int32_t mode, in_rows, in_cols, out_rows, out_cols, tail;
+  int32_t radius_y, radius_x;                     // anti-aliasing Gaussian (down-scaling), 0 = none
+  const double* gauss;                            // device: [2][BSX_IMAGE_MAX_RADIUS+1] half kernels (y, x), or null
   uint32_t numel;                                 // out_rows*out_cols*tail (< 2^20)
   uint32_t tail_magic, cols_magic;                // bsx_div_magic(tail), bsx_div_magic(out_cols)
   uint32_t blocks_per_lane;
@@ -110,6 +115,28 @@ __device__ __forceinline__ float img_pixel(const image_args& a, const img_tables
   return (float)t;
 }
 
+// skimage's anti-aliasing pre-filter = scipy.ndimage.gaussian_filter(mode='mirror') on the f32
+// observation staged in LDS: one pass per filtered axis (rows, then columns), each element
+//   t = in[0]*w[0];  for j = radius..1: t += (in[-j] + in[+j]) * w[j]        (f64, NI_Correlate1D's
+// symmetric branch), rounded to f32 like scipy's float32 output array.  src -> dst, both [rows x cols].
+__device__ __forceinline__ void img_gauss_pass(const float* src, float* dst, int rows, int cols, int axis,
+                                               int radius, const double* __restrict__ w) {
+  BSX_NO_CONTRACT
+  const int n = rows * cols, len = axis == 0 ? rows : cols, stride = axis == 0 ? cols : 1;
+  for (int e = threadIdx.x; e < n; e += BSX_BLOCK) {
+    const int y = e / cols, x = e - y * cols;
+    const int pos = axis == 0 ? y : x;
+    const int base = e - pos * stride;               // element 0 of this line
+    double t = (double)src[e] * w[0];
+    for (int j = radius; j >= 1; --j) {
+      const double lo = (double)src[base + img_mirror_index(pos - j, len) * stride];
+      const double hi = (double)src[base + img_mirror_index(pos + j, len) * stride];
+      t = t + (lo + hi) * w[j];
+    }
+    dst[e] = (float)t;
+  }
+}
+
 template <int IMG_K>
 __global__ void __launch_bounds__(BSX_BLOCK) bsx_image_kernel(const image_args a) {
   constexpr uint32_t IMG_RUN = IMG_K * BSX_BLOCK * 4;
@@ -120,6 +147,7 @@ __global__ void __launch_bounds__(BSX_BLOCK) bsx_image_kernel(const image_args a
   int* s_yi = reinterpret_cast<int*>(s_xw + 2 * a.out_cols);
   int* s_xi = s_yi + a.out_rows;
   float* s_obs = reinterpret_cast<float*>(s_xi + a.out_cols);
+  float* s_tmp = s_obs + a.in_rows * a.in_cols;    // second plane: only allocated when a filter runs
 
   const uint32_t lane = blockIdx.x / a.blocks_per_lane;
   const uint32_t run = blockIdx.x - lane * a.blocks_per_lane;
@@ -140,6 +168,16 @@ __global__ void __launch_bounds__(BSX_BLOCK) bsx_image_kernel(const image_args a
     }
   }
   __syncthreads();
+  if (a.radius_y > 0) {                            // uniform branches: the barriers are safe
+    img_gauss_pass(s_obs, s_tmp, a.in_rows, a.in_cols, 0, a.radius_y, a.gauss);
+    __syncthreads();
+    float* t = s_obs; s_obs = s_tmp; s_tmp = t;
+  }
+  if (a.radius_x > 0) {
+    img_gauss_pass(s_obs, s_tmp, a.in_rows, a.in_cols, 1, a.radius_x, a.gauss + (BSX_IMAGE_MAX_RADIUS + 1));
+    __syncthreads();
+    float* t = s_obs; s_obs = s_tmp; s_tmp = t;
+  }
   img_tables tb; tb.s_obs = s_obs; tb.s_yi = s_yi; tb.s_xi = s_xi; tb.s_yw = s_yw; tb.s_xw = s_xw;
 
   float* __restrict__ dst = a.image + (int64_t)lane * a.numel;
@@ -179,6 +217,26 @@ __global__ void __launch_bounds__(BSX_BLOCK) bsx_image_kernel(const image_args a
   }
 }
 
+// Device copy of the two half kernels of a configuration.  Configurations are few (one per wrapped
+// environment): a small cache keyed by the weights themselves; entries live until the process ends.
+struct img_gauss_entry { double w[2 * (BSX_IMAGE_MAX_RADIUS + 1)]; double* dev; };
+static const double* img_gauss_upload(const bsx_image_t* cfg, hipStream_t st) {
+  static std::vector<img_gauss_entry> cache;
+  static std::mutex mu;
+  img_gauss_entry e;
+  memset(e.w, 0, sizeof(e.w));
+  for (int j = 0; j <= cfg->radius_y; ++j) e.w[j] = cfg->gauss_y[j];
+  for (int j = 0; j <= cfg->radius_x; ++j) e.w[BSX_IMAGE_MAX_RADIUS + 1 + j] = cfg->gauss_x[j];
+  std::lock_guard<std::mutex> lock(mu);
+  for (const img_gauss_entry& c : cache)
+    if (memcmp(c.w, e.w, sizeof(e.w)) == 0) return c.dev;
+  if (hipMalloc((void**)&e.dev, sizeof(e.w)) != hipSuccess) return nullptr;
+  if (hipMemcpy(e.dev, e.w, sizeof(e.w), hipMemcpyHostToDevice) != hipSuccess) { (void)hipFree(e.dev); return nullptr; }
+  (void)st;
+  try { cache.push_back(e); } catch (...) { (void)hipFree(e.dev); return nullptr; }
+  return e.dev;
+}
+
 extern "C" int bsx_image_observation(const bsx_image_t* cfg, int64_t n_lanes, const float* obs, float* image,
                                      void* hip_stream) {
   if (cfg == nullptr) return BSX_ENULL;
@@ -191,8 +249,9 @@ extern "C" int bsx_image_observation(const bsx_image_t* cfg, int64_t n_lanes, co
   if (in_numel > 4096 || cfg->out_rows > 1024 || cfg->out_cols > 1024 || cfg->tail > 4096 || numel >= (1 << 20))
     return BSX_ERANGE;
   if (cfg->mode == BSX_IMAGE_SMALL && in_numel > 4) return BSX_ERANGE;        // wrappers.py:200-201
-  if (cfg->mode == BSX_IMAGE_BILINEAR && (cfg->out_rows < cfg->in_rows || cfg->out_cols < cfg->in_cols))
-    return BSX_ERANGE;                             // down-scaling needs skimage's anti-aliasing filter
+  if (cfg->radius_y < 0 || cfg->radius_x < 0 || cfg->radius_y > BSX_IMAGE_MAX_RADIUS || cfg->radius_x > BSX_IMAGE_MAX_RADIUS)
+    return BSX_ERANGE;
+  const bool filtered = cfg->mode == BSX_IMAGE_BILINEAR && (cfg->radius_y > 0 || cfg->radius_x > 0);
   if (n_lanes == 0) return 0;
   if (obs == nullptr || image == nullptr) return BSX_ENULL;
   if (((uintptr_t)image & 15u) != 0 || ((uintptr_t)obs & 3u) != 0) return BSX_EALIGN;
@@ -200,6 +259,8 @@ extern "C" int bsx_image_observation(const bsx_image_t* cfg, int64_t n_lanes, co
   a.obs = obs; a.image = image; a.n_lanes = n_lanes;
   a.mode = cfg->mode; a.in_rows = cfg->in_rows; a.in_cols = cfg->in_cols;
   a.out_rows = cfg->out_rows; a.out_cols = cfg->out_cols; a.tail = cfg->tail;
+  a.radius_y = filtered ? cfg->radius_y : 0; a.radius_x = filtered ? cfg->radius_x : 0;
+  a.gauss = nullptr;
   a.numel = (uint32_t)numel;
   a.tail_magic = bsx_div_magic((uint32_t)cfg->tail);
   a.cols_magic = bsx_div_magic((uint32_t)cfg->out_cols);
@@ -214,9 +275,16 @@ extern "C" int bsx_image_observation(const bsx_image_t* cfg, int64_t n_lanes, co
   a.blocks_per_lane = (uint32_t)((numel + run - 1) / run);
   const int64_t blocks = n_lanes * (int64_t)a.blocks_per_lane;
   if (blocks > 0x7FFFFFFF) return BSX_EINVAL;
-  const size_t lds = (size_t)(cfg->out_rows + cfg->out_cols) * (16 + 4) + (size_t)in_numel * 4;
+  const size_t lds = (size_t)(cfg->out_rows + cfg->out_cols) * (16 + 4) + (size_t)in_numel * 4 * (filtered ? 2 : 1);
   const dim3 grid((unsigned)blocks), block(BSX_BLOCK);
   hipStream_t st = (hipStream_t)hip_stream;
+  if (filtered) {
+    // The half kernels live in a small device buffer owned by the library, uploaded (synchronously) the
+    // first time a configuration is seen and reused afterwards: later calls are asynchronous and
+    // capturable like every other entry point.  Down-scaling is the rare path of this adapter.
+    a.gauss = img_gauss_upload(cfg, st);
+    if (a.gauss == nullptr) return BSX_ENOMEM;
+  }
   switch (k) {
     case 2: bsx_image_kernel<2><<<grid, block, lds, st>>>(a); break;
     case 8: bsx_image_kernel<8><<<grid, block, lds, st>>>(a); break;

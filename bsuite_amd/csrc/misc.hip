@@ -159,7 +159,15 @@ static int group_commit(bsx_group* g) {
 extern "C" int bsx_group_step(bsx_group_t* g, void* hip_stream) {
   if (g == nullptr) return BSX_ENULL;
   if (!g->committed) return BSX_EINVAL;
-  return g->launch(g, (hipStream_t)hip_stream);
+  return g->launch(g, -1, (hipStream_t)hip_stream);
+}
+
+extern "C" int bsx_group_phases(const bsx_group_t* g) { return g == nullptr ? BSX_ENULL : g->n_phases; }
+
+extern "C" int bsx_group_step_phase(bsx_group_t* g, int32_t phase, void* hip_stream) {
+  if (g == nullptr) return BSX_ENULL;
+  if (!g->committed || phase < 0 || phase >= g->n_phases) return BSX_EINVAL;
+  return g->launch(g, phase, (hipStream_t)hip_stream);
 }
 
 extern "C" int bsx_group_destroy(bsx_group_t* g) {

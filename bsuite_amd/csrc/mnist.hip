@@ -215,9 +215,11 @@ extern "C" int bsx_mnist_step(const bsx_mnist_t* cfg, const bsx_call_t* call, co
   return bsx_launch_status();
 }
 
-static int mnist_group_launch(bsx_group* g, hipStream_t st) {
-  mnist_advance_group_kernel<<<dim3((unsigned)g->total_blocks), dim3(BSX_BLOCK), 0, st>>>(
-      (const mnist_args*)g->d_args, g->index1());
+static int mnist_group_launch(bsx_group* g, int phase, hipStream_t st) {
+  if (phase != 1)
+    mnist_advance_group_kernel<<<dim3((unsigned)g->total_blocks), dim3(BSX_BLOCK), 0, st>>>(
+        (const mnist_args*)g->d_args, g->index1());
+  if (phase == 0) return (int)hipGetLastError();
   const dim3 go((unsigned)g->total_blocks2), bo(BSX_BLOCK);
   const mnist_observe_args* tb = (const mnist_observe_args*)g->d_args2;
   const int k = mnist_group_k(), var = mnist_variant();
@@ -245,5 +247,6 @@ extern "C" int bsx_group_set_mnist(bsx_group_t* g, int32_t index, const bsx_mnis
   g->blocks[index] = (int32_t)b1; g->blocks2[index] = (int32_t)b2;
   g->is_set[index] = 1;
   g->launch = mnist_group_launch;
+  g->n_phases = 2;
   return 0;
 }

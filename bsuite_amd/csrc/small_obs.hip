@@ -88,7 +88,8 @@ __global__ void __launch_bounds__(BSX_BLOCK) small_obs_group_kernel(const typena
 }
 
 template <class Env>
-static int small_obs_group_launch(bsx_group* g, hipStream_t st) {
+static int small_obs_group_launch(bsx_group* g, int phase, hipStream_t st) {
+  if (phase == 1) return 0;                 // one kernel per step: everything happens in phase 0
   const dim3 grid((unsigned)g->total_blocks), block(BSX_BLOCK);
   const typename Env::args* table = (const typename Env::args*)g->d_args;
   if (g->klass == 256) small_obs_group_kernel<Env, 256><<<grid, block, g->lds_bytes, st>>>(table, g->index1());
@@ -101,7 +102,7 @@ static int small_obs_group_launch(bsx_group* g, hipStream_t st) {
 // advances them all (the kernel switches on the tag per workgroup).  Six ~8 us launches of a
 // heterogeneous sweep become one.
 #define SMALL_MIXED_STRIDE 1024
-static int small_obs_mixed_launch(bsx_group* g, hipStream_t st);
+static int small_obs_mixed_launch(bsx_group* g, int phase, hipStream_t st);
 
 // Records one segment of a small-observation family in a group (of its own family, or mixed).
 template <class Env>
@@ -685,7 +686,8 @@ __global__ void __launch_bounds__(BSX_BLOCK) small_obs_mixed_group_kernel(const 
 #undef SMALL_MIXED_CASE
 }
 
-static int small_obs_mixed_launch(bsx_group* g, hipStream_t st) {
+static int small_obs_mixed_launch(bsx_group* g, int phase, hipStream_t st) {
+  if (phase == 1) return 0;
   const dim3 grid((unsigned)g->total_blocks), block(BSX_BLOCK);
   const uint8_t* table = (const uint8_t*)g->d_args;
   const int32_t* family = (const int32_t*)g->d_args2;

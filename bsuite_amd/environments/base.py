@@ -103,6 +103,8 @@ class Environment(dm_env.EnvironmentBase):
         if len(self._mt_seeds) != self._batch:
           raise ValueError('need one seed per lane')
     self._wrap = (_native.WRAP_NONE, 0.0, 0)
+    self._wrap_mt_seeds = None         # rng='mt19937' + RewardNoise: the wrapper's own RandomState seeds
+    self._wrap_mt = None
     self._logging = None
     self._deferred_steps = None
     self._step_index = 0
@@ -194,6 +196,37 @@ class Environment(dm_env.EnvironmentBase):
     return getattr(_native.lib, f'bsx_group_set_{self._abi_name}')(
         group, index, *self._native_args(call, action.data_ptr(), self._out_ptrs[0]))
 
+  def _set_wrap_mt_seeds(self, seeds):
+    """rng='mt19937': RewardNoise's own np.random.RandomState(seed) per lane (wrappers.py:267)."""
+    self._wrap_mt_seeds = [int(s) & 0xFFFFFFFF for s in seeds]
+    if self._allocated:
+      self._upload_wrap_mt()
+
+  @staticmethod
+  def _mt_columns(seeds, device, prepare=None):
+    """[624,B] key words, [B] pos, [B] gauss, [B] has_gauss of np.random.RandomState(seed) per lane."""
+    B = len(seeds)
+    keys = np.empty((B, 624), np.uint32)
+    pos = np.empty(B, np.int32)
+    gauss = np.zeros(B, np.float64)
+    has = np.zeros(B, np.int32)
+    for i, s_i in enumerate(seeds):
+      rs = np.random.RandomState(s_i)
+      if prepare is not None:
+        prepare(rs)
+      _, key, p, hg, cg = rs.get_state()
+      keys[i], pos[i], has[i], gauss[i] = key, p, hg, cg
+    return dict(state=torch.from_numpy(np.ascontiguousarray(keys.T).view(np.int32)).to(device),
+                pos=torch.from_numpy(pos).to(device), gauss=torch.from_numpy(gauss).to(device),
+                has_gauss=torch.from_numpy(has).to(device))
+
+  def _upload_wrap_mt(self):
+    with torch.cuda.device(self._device):
+      self._wrap_mt = self._mt_columns(self._wrap_mt_seeds, self._device)
+    w = self._call_desc.wrap
+    w.mt_state, w.mt_pos = self._wrap_mt['state'].data_ptr(), self._wrap_mt['pos'].data_ptr()
+    w.mt_gauss, w.mt_has_gauss = self._wrap_mt['gauss'].data_ptr(), self._wrap_mt['has_gauss'].data_ptr()
+
   def _mt_constructor_draws(self, rs: np.random.RandomState):
     """Subclass hook (rng='mt19937'): consume from `rs` exactly what the reference constructor
     draws from `self._rng` before the first reset (most families: nothing)."""
@@ -239,29 +272,27 @@ class Environment(dm_env.EnvironmentBase):
       # scalar view: the reward as the f64 the reference returns (not its f32 rounding)
       self._reward_f64 = torch.zeros(1, dtype=torch.float64, **place) if self._scalar else None
       self._out_np = [{k: v.numpy() for k, v in o.items()} for o in self._out] if self._host_out else None
-    mt_state_ptr = mt_pos_ptr = None
+    mt_state_ptr = mt_pos_ptr = mt_gauss_ptr = mt_has_ptr = None
     if self._rng_mode == 'mt19937':
-      keys = np.empty((B, 624), np.uint32)
-      pos = np.empty(B, np.int32)
-      for i, s_i in enumerate(self._mt_seeds):
-        rs = np.random.RandomState(s_i)
-        self._mt_constructor_draws(rs)           # the draws the reference constructor makes
-        _, key, p, _, _ = rs.get_state()
-        keys[i], pos[i] = key, p
       with torch.cuda.device(dev):
-        self._mt_state = torch.from_numpy(np.ascontiguousarray(keys.T).view(np.int32)).to(dev)   # [624, B]
-        self._mt_pos = torch.from_numpy(pos).to(dev)
+        # initial states built by numpy itself, after the draws each reference constructor makes
+        cols = self._mt_columns(self._mt_seeds, dev, prepare=self._mt_constructor_draws)
+      self._mt_state, self._mt_pos = cols['state'], cols['pos']              # [624, B], [B]
+      self._mt_gauss, self._mt_has_gauss = cols['gauss'], cols['has_gauss']
       mt_state_ptr, mt_pos_ptr = self._mt_state.data_ptr(), self._mt_pos.data_ptr()
+      mt_gauss_ptr, mt_has_ptr = self._mt_gauss.data_ptr(), self._mt_has_gauss.data_ptr()
     # One persistent call descriptor: only step_index / force_reset / stream change per call.
     self._call_desc = _native.Call(
         n_lanes=B, force_reset=0,
         stream=_native.Stream(self._seed, self._lane_offset, 0,
                               self._step_base.data_ptr() if self._device_step_counter else None,
-                              mt_state_ptr, mt_pos_ptr),
-        wrap=_native.RewardWrap(_native.WRAP_NONE, 0, 0.0, 0),
+                              mt_state_ptr, mt_pos_ptr, mt_gauss_ptr, mt_has_ptr),
+        wrap=_native.RewardWrap(_native.WRAP_NONE, 0, 0.0, 0, None, None, None, None),
         counters=self._counters.data_ptr(), hip_stream=None)
     if self._reward_f64 is not None:
       self._call_desc.reward_f64 = self._reward_f64.data_ptr()
+    if self._wrap_mt_seeds is not None:
+      self._upload_wrap_mt()
     self._allocated = True
 
   # ----------------------------------------------------------------------------------------
@@ -542,6 +573,10 @@ class Environment(dm_env.EnvironmentBase):
     d['__seed'] = self._seed
     if self._rng_mode == 'mt19937':
       d['__mt_state'], d['__mt_pos'] = self._mt_state.clone(), self._mt_pos.clone()
+      d['__mt_gauss'], d['__mt_has_gauss'] = self._mt_gauss.clone(), self._mt_has_gauss.clone()
+      if self._wrap_mt is not None:
+        for k, v in self._wrap_mt.items():
+          d['__wrap_mt_' + k] = v.clone()
     d['__wrap'] = tuple(self._wrap)                       # fused RewardNoise / RewardScale epilogue
     if self._logging is not None:                         # fused Logging bookkeeping (counters + rows)
       for k in ('steps', 'episode', 'total_return', 'episode_len', 'episode_return', 'rows', 'n_rows'):
@@ -562,6 +597,11 @@ class Environment(dm_env.EnvironmentBase):
     if self._rng_mode == 'mt19937':
       self._mt_state.copy_(d['__mt_state'])
       self._mt_pos.copy_(d['__mt_pos'])
+      self._mt_gauss.copy_(d['__mt_gauss'])
+      self._mt_has_gauss.copy_(d['__mt_has_gauss'])
+      if self._wrap_mt is not None:
+        for k, v in self._wrap_mt.items():
+          v.copy_(d['__wrap_mt_' + k])
     if '__wrap' in d:
       self._wrap = tuple(d['__wrap'])
     has_log = '__logging_steps' in d

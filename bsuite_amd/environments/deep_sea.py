@@ -35,8 +35,6 @@ class DeepSea(base.Environment):
     if not 1 <= size <= _native.DEEP_SEA_MAX_SIZE:
       raise ValueError(f'size must be in [1, {_native.DEEP_SEA_MAX_SIZE}]')
     super().__init__(obs_shape=(size, size), num_actions=2, seed=seed, **engine_kwargs)
-    if self._rng_mode == 'mt19937' and not deterministic:
-      raise NotImplementedError("stochastic DeepSea needs randn, which rng='mt19937' mode does not provide")
     self._size = size
     self._deterministic = deterministic
     self._unscaled_move_cost = unscaled_move_cost

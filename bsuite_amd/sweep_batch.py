@@ -182,35 +182,56 @@ class SweepBatch:
       raw._step_index += 1  # pylint: disable=protected-access
     return self._group_outs
 
-  def capture_grouped(self, num_streams: int = 2):
-    """Captures one grouped sweep step as a HIP graph whose group launches run as `num_streams`
-    concurrent branches (largest groups first, round-robin): the small families' launches — each
-    near the ~8 us floor of a launch — overlap the store streams of deep_sea / mnist / catch instead
-    of queueing behind them.  Groups are independent (disjoint segments); the shared call counter is
-    bumped after the join.  Call prepare_groups() first; then `replay_grouped()` per sweep step."""
+  def capture_grouped(self, num_streams: int = 2, phased: bool = True):
+    """Captures one grouped sweep step as a HIP graph.
+
+    phased=True (default): the step is split by what bounds each kernel.  One branch runs everything
+    latency-bound back to back — the lane-advance kernels of the two-kernel families (largest store
+    stream first), then the small-observation groups, each near the ~8 us floor of a launch and moving
+    little data; every observation stream kernel (HBM-bound: deep_sea, mnist, catch carry ~850 of the
+    sweep's 886 MB) starts on one of `num_streams` other branches as soon as ITS advance kernel is done
+    (one event per group, bsx_group_step_phase).  The store streams then run from ~6 us into the step
+    to its end with the small kernels hidden beside them.
+    phased=False: whole groups as `num_streams` round-robin branches (the r01 topology).
+    Groups are independent (disjoint segments); the shared call counter is bumped after the join.
+    Call prepare_groups() first; then `replay_grouped()` per sweep step."""
     from bsuite_amd import _native  # pylint: disable=import-outside-toplevel
     if not self._groups:
       raise RuntimeError('capture_grouped() needs prepare_groups() first')
     self.step_grouped()                        # one eager step: first-use work stays out of the capture
     torch.cuda.synchronize(self.device)
     main = torch.cuda.Stream(device=self.device)
-    side = [torch.cuda.Stream(device=self.device) for _ in range(max(1, int(num_streams)) - 1)]
-    lanes = [main] + side
+    n_side = max(1, int(num_streams)) if phased else max(1, int(num_streams)) - 1
+    side = [torch.cuda.Stream(device=self.device) for _ in range(n_side)]
     main.wait_stream(torch.cuda.current_stream(self.device))
     graph = torch.cuda.CUDAGraph()
     with torch.cuda.stream(main):
       with torch.cuda.graph(graph, stream=main):
         for st in side:
           st.wait_stream(main)                 # fork
-        for j, handle in enumerate(self._groups_by_cost):
-          st = lanes[j % len(lanes)]
-          _native.check(_native.lib.bsx_group_step(handle, st.cuda_stream), 'bsx_group_step')
+        if phased:
+          pairs = [h for h in self._groups_by_cost if _native.lib.bsx_group_phases(h) == 2]
+          singles = [h for h in self._groups_by_cost if _native.lib.bsx_group_phases(h) == 1]
+          for j, handle in enumerate(pairs):   # heaviest store stream first
+            _native.check(_native.lib.bsx_group_step_phase(handle, 0, main.cuda_stream), 'bsx_group_step_phase')
+            ev = torch.cuda.Event()
+            ev.record(main)
+            st = side[j % len(side)]
+            st.wait_event(ev)
+            _native.check(_native.lib.bsx_group_step_phase(handle, 1, st.cuda_stream), 'bsx_group_step_phase')
+          for handle in singles:
+            _native.check(_native.lib.bsx_group_step_phase(handle, 0, main.cuda_stream), 'bsx_group_step_phase')
+        else:
+          lanes = [main] + side
+          for j, handle in enumerate(self._groups_by_cost):
+            st = lanes[j % len(lanes)]
+            _native.check(_native.lib.bsx_group_step(handle, st.cuda_stream), 'bsx_group_step')
         for st in side:
           main.wait_stream(st)                 # join
         self._bump()
     torch.cuda.current_stream(self.device).wait_stream(main)
     self._grouped_graph = graph
-    self._grouped_streams = lanes
+    self._grouped_streams = [main] + side
     return self._group_outs
 
   def replay_grouped(self):

@@ -78,13 +78,24 @@ class RewardNoise(_RewardWrapper):
 
   def __init__(self, env: base.Environment, noise_scale: float, seed: Optional[int] = None):
     super().__init__(env)
-    if getattr(env, '_rng_mode', 'philox') == 'mt19937':
-      raise NotImplementedError("RewardNoise needs randn, which rng='mt19937' mode does not provide "
-                                '(numpy polar Box-Muller depends on libm log bit for bit)')
     self._noise_scale = noise_scale
     # The reference wrapper owns a RandomState(seed) separate from the env's (wrappers.py:267);
-    # here that is stream_id 1 of the draw stream, keyed by this seed.
-    wrap_seed = env.seed if seed is None else int(seed)
+    # here that is stream_id 1 of the draw stream, keyed by this seed.  In the MT19937-exact mode it
+    # IS a second np.random.RandomState per lane (lane i: seed + i, or seed[i] for a sequence), whose
+    # legacy randn the kernels reproduce bit for bit (include/bsx_stream.h bsx_mt_gauss).
+    if getattr(env, '_rng_mode', 'philox') == 'mt19937':
+      if seed is None:
+        seeds = list(env._mt_seeds)  # pylint: disable=protected-access
+      elif isinstance(seed, (int, np.integer)):
+        seeds = [(int(seed) + i) & 0xFFFFFFFF for i in range(env.batch_size)]
+      else:
+        seeds = [int(x) for x in seed]
+        if len(seeds) != env.batch_size:
+          raise ValueError('need one wrapper seed per lane')
+      env._set_wrap_mt_seeds(seeds)  # pylint: disable=protected-access
+      wrap_seed = seeds[0]
+    else:
+      wrap_seed = env.seed if seed is None else int(seed)
     env._wrap = (_native.WRAP_NOISE, float(noise_scale), wrap_seed & ((1 << 63) - 1))  # pylint: disable=protected-access
 
 
@@ -241,11 +252,39 @@ def _image_cfg(shape: Sequence[int], obs_shape: Sequence[int]) -> '_native.Image
   if len(obs_shape) > 2:
     raise ValueError('Cannot convert observation shape {} to desired shape {}'.format(obs_shape, shape))
   rows, cols = (1, obs_shape[0]) if len(obs_shape) == 1 else obs_shape   # np.expand_dims(obs, 0) (:212-213)
+  cfg = _native.ImageCfg(_native.IMAGE_BILINEAR, rows, cols, shape[0], shape[1], tail)
   if shape[0] < rows or shape[1] < cols:
-    raise NotImplementedError(
-        f'to_image: down-scaling {obs_shape} -> {shape[:2]} needs skimage\'s anti-aliasing filter, '
-        'which the device kernel does not restate')
-  return _native.ImageCfg(_native.IMAGE_BILINEAR, rows, cols, shape[0], shape[1], tail)
+    # skimage.transform.resize(anti_aliasing=None): some output dimension is smaller than the input's
+    # -> Gaussian pre-filter with sigma = max(0, (in/out - 1)/2) per axis (skimage/transform/_warps.py),
+    # applied by scipy.ndimage.gaussian_filter; the kernel takes the half kernels built as scipy builds
+    # them (scipy/ndimage/_filters.py _gaussian_kernel1d, truncate = 4)
+    for axis, (n_in, n_out) in (('y', (rows, shape[0])), ('x', (cols, shape[1]))):
+      half = _gaussian_half_kernel(n_in, n_out)
+      if half is None:
+        continue
+      if len(half) - 1 > _native.IMAGE_MAX_RADIUS:
+        raise ValueError(f'to_image: shrinking {n_in} -> {n_out} needs an anti-aliasing kernel of radius '
+                         f'{len(half) - 1} > {_native.IMAGE_MAX_RADIUS}')
+      setattr(cfg, 'radius_' + axis, len(half) - 1)
+      arr = getattr(cfg, 'gauss_' + axis)
+      for j, v in enumerate(half):
+        arr[j] = float(v)
+  return cfg
+
+
+def _gaussian_half_kernel(n_in: int, n_out: int):
+  """Weights at distance 0..radius of the anti-aliasing Gaussian along one axis, or None when the axis
+  is not filtered (it does not shrink, or the kernel has a single tap)."""
+  sigma = max(0.0, (np.float64(n_in) / np.float64(n_out) - 1) / 2)
+  if not sigma > 1e-15:                               # scipy's gaussian_filter skips such axes
+    return None
+  radius = int(4.0 * float(sigma) + 0.5)
+  if radius == 0:
+    return None                                     # weights [1.0]: exact identity
+  x = np.arange(-radius, radius + 1)
+  phi = np.exp(-0.5 / (sigma * sigma) * x ** 2)
+  phi = phi / phi.sum()
+  return phi[radius:]
 
 
 def to_image(shape: Sequence[int], observation, out: Optional[torch.Tensor] = None, batched=None):
@@ -254,7 +293,8 @@ def to_image(shape: Sequence[int], observation, out: Optional[torch.Tensor] = No
   observation: a device tensor `[B, *obs_shape]` (batched; returns a device tensor `[B, *shape]`)
   or a single numpy observation (returns numpy, like the reference; one H2D + D2H — compatibility
   path).  Values are tiled (size <= 4) or bilinearly interpolated (skimage >= 0.19 `resize` =
-  scipy.ndimage.zoom(order=1, mode='mirror', grid_mode=True)) and broadcast over trailing dims."""
+  scipy.ndimage.zoom(order=1, mode='mirror', grid_mode=True), after skimage's anti-aliasing Gaussian
+  along every axis that shrinks) and broadcast over trailing dims."""
   shape = tuple(int(s) for s in shape)
   if batched is None:
     batched = torch.is_tensor(observation)

@@ -37,7 +37,7 @@ extern "C" {
 #define BSX_ENULL (-2)      /* a required pointer is NULL                          */
 #define BSX_EALIGN (-3)     /* observation pointer not 16-byte aligned             */
 #define BSX_ERANGE (-4)     /* parameter outside the supported range of the family */
-#define BSX_EMODE (-5)      /* combination not available (randn in MT19937-exact mode, obs_paint with a rollout / group / other family) */
+#define BSX_EMODE (-5)      /* combination not available (obs_paint with a rollout / group / other family) */
 #define BSX_ENOMEM (-6)     /* host allocation failed (group bookkeeping)          */
 
 /* Random stream coordinates of one call (include/bsx_stream.h).  The reference gives every env its
@@ -53,10 +53,15 @@ typedef struct {
   /* MT19937-exact mode (include/bsx_stream.h "mode B"); both NULL = counter-based
    * stream.  mt_state: device uint32 [624, B] (word k of lane i at [k*B + i]), each lane holding
    * np.random.RandomState's key; mt_pos: device int32 [B], its `pos`.  The kernels then draw with
-   * numpy's legacy samplers from that generator and write the advanced state back.  Not available
-   * with RewardNoise or the stochastic deep_sea (both need randn).                              */
+   * numpy's legacy samplers from that generator and write the advanced state back.
+   * mt_gauss / mt_has_gauss (ABI v8): device double [B] / int32 [B], RandomState's cached second
+   * value of the polar Box-Muller pair (`gauss`, `has_gauss`); required (with mt_state) by the
+   * stochastic deep_sea, whose `randn` then is numpy's own, log included (include/bsx_libm_log.h);
+   * may be NULL for every other family.                                                         */
   uint32_t* mt_state;
   int32_t* mt_pos;
+  double* mt_gauss;
+  int32_t* mt_has_gauss;
 } bsx_stream_t;
 
 /* Fused reward epilogue = bsuite/utils/wrappers.py RewardNoise (:275-283) / RewardScale (:338-346):
@@ -69,6 +74,13 @@ typedef struct {
   int32_t _pad;
   double param;        /* reward_scale or noise_scale (sigma)                                   */
   uint64_t seed;       /* key of the wrapper's own stream (RewardNoise has its own RNG, :267)   */
+  /* MT19937-exact mode (ABI v8): RewardNoise owns a second np.random.RandomState(seed) per lane
+   * (wrappers.py:267) that only ever draws randn; same layout as the bsx_stream_t members.  All four
+   * non-NULL when kind == BSX_WRAP_NOISE and stream.mt_state != NULL, else ignored.             */
+  uint32_t* mt_state;
+  int32_t* mt_pos;
+  double* mt_gauss;
+  int32_t* mt_has_gauss;
 } bsx_reward_wrap_t;
 
 /* The batched dm_env.TimeStep, written in full on every call (dense contract). */
@@ -329,6 +341,12 @@ int bsx_group_set_mnist(bsx_group_t* g, int32_t index, const bsx_mnist_t* cfg, c
                         const int32_t* action, int32_t* state, bsx_timestep_t out, double* info);
 int bsx_group_commit(bsx_group_t* g);
 int bsx_group_step(bsx_group_t* g, void* hip_stream);
+/* A group step in its phases, for callers that schedule them on several HIP streams (ABI v8): a
+ * two-kernel family (deep_sea, catch, mnist) has 2 — phase 0 the lane advance (latency-bound, little
+ * traffic), phase 1 the observation stream (HBM-bound), which depends on phase 0 of the SAME group only;
+ * the small-observation groups have 1.  bsx_group_step == all phases in order on one stream. */
+int bsx_group_phases(const bsx_group_t* g);
+int bsx_group_step_phase(bsx_group_t* g, int32_t phase, void* hip_stream);
 int bsx_group_destroy(bsx_group_t* g);
 
 /* ---- observation adapter ------------------------------------------------------
@@ -337,18 +355,28 @@ int bsx_group_destroy(bsx_group_t* g);
  * product of the trailing dimensions of `shape`, 1 for a 2-D shape); each plane value is broadcast
  * over the tail.  mode BSX_IMAGE_SMALL is `_small_state_to_image` (:178-204, observation.size
  * <= 4: constant / left-right halves / quadrants, incl. the reference's quadrant order);
- * BSX_IMAGE_BILINEAR is `_interpolate_to_image` (:207-219) for out >= in in both dimensions, i.e.
- * skimage.transform.resize(order=1, mode='reflect', no anti-aliasing) = scipy.ndimage.zoom(order=1,
- * mode='mirror', grid_mode=True): per axis cc = (k+0.5)*(in/out)-0.5 mirrored, weights
- * (1-frac, frac), the 4 terms (v*wy)*wx summed in f64 in scipy's order, cast to f32.
+ * BSX_IMAGE_BILINEAR is `_interpolate_to_image` (:207-219), i.e. skimage.transform.resize(order=1,
+ * mode='reflect') = scipy.ndimage.zoom(order=1, mode='mirror', grid_mode=True): per axis
+ * cc = (k+0.5)*(in/out)-0.5 mirrored, weights (1-frac, frac), the 4 terms (v*wy)*wx summed in f64 in
+ * scipy's order, cast to f32.  An axis that SHRINKS is first passed through skimage's anti-aliasing
+ * Gaussian (ABI v8; scipy.ndimage.gaussian_filter, mode='mirror': per element
+ * t = in[0]*w[0]; for j = radius..1: t += (in[-j] + in[+j])*w[j] in f64, rounded to f32, rows first
+ * then columns): the caller passes the half kernel w[0..radius] it built the way scipy does
+ * (sigma = (in/out - 1)/2, radius = int(4*sigma + 0.5), exp(-0.5/sigma^2 * x^2) normalised);
+ * radius 0 = that axis is not filtered.
  * obs: f32 [n_lanes, in_rows*in_cols]; image: f32 [n_lanes, out_rows*out_cols*tail], 16-B aligned.
- * Limits: in_rows*in_cols <= 4096, out_rows/out_cols <= 1024, out_rows*out_cols*tail < 2^20. */
+ * Limits: in_rows*in_cols <= 4096, out_rows/out_cols <= 1024, out_rows*out_cols*tail < 2^20,
+ * radius <= BSX_IMAGE_MAX_RADIUS. */
 #define BSX_IMAGE_SMALL 0
 #define BSX_IMAGE_BILINEAR 1
+#define BSX_IMAGE_MAX_RADIUS 64
 typedef struct {
   int32_t mode;
   int32_t in_rows, in_cols;
   int32_t out_rows, out_cols, tail;
+  int32_t radius_y, radius_x;                      /* anti-aliasing filter along rows / columns, 0 = none */
+  double gauss_y[BSX_IMAGE_MAX_RADIUS + 1];        /* weights at distance 0..radius_y                     */
+  double gauss_x[BSX_IMAGE_MAX_RADIUS + 1];
 } bsx_image_t;
 int bsx_image_observation(const bsx_image_t* cfg, int64_t n_lanes, const float* obs, float* image,
                           void* hip_stream);

@@ -34,6 +34,8 @@
 
 #include <stdint.h>
 
+#include "bsx_libm_log.h"
+
 #if defined(__HIPCC__)
 #define BSX_HD __host__ __device__ __forceinline__
 #else
@@ -74,6 +76,8 @@ typedef struct {
   uint32_t* mt;       /* element k of this lane's 624-word state lives at mt[k * mt_stride]  */
   int64_t mt_stride;
   int32_t mt_pos;     /* numpy's `pos`: 0..624 */
+  int32_t mt_has_gauss; /* RandomState's cached second value of the polar pair */
+  double mt_gauss;
 } bsx_draws;
 
 BSX_HD void bsx_draws_init(bsx_draws* d, uint64_t seed, uint64_t lane, uint64_t step, uint32_t stream_id) {
@@ -82,7 +86,7 @@ BSX_HD void bsx_draws_init(bsx_draws* d, uint64_t seed, uint64_t lane, uint64_t 
   d->c2 = (uint32_t)step;
   d->c3hi = (((uint32_t)(step >> 32) & 0xFFFFu) << 16) | ((stream_id & 0xFFu) << 8);
   d->next = 0; d->have = -1;
-  d->mt = 0; d->mt_stride = 0; d->mt_pos = 0;
+  d->mt = 0; d->mt_stride = 0; d->mt_pos = 0; d->mt_has_gauss = 0; d->mt_gauss = 0.0;
 }
 
 /* ---- MT19937-exact mode ("mode B") ------------------------------------------------------------
@@ -98,7 +102,9 @@ BSX_HD void bsx_draws_init(bsx_draws* d, uint64_t seed, uint64_t lane, uint64_t 
  *   binomial(1,.5)          one U() per draw: int(U > 0.5)  (inversion algorithm with n=1, p=.5)
  *   binomial(1,.5,size=n)   n sequential draws
  *   randint(n)   n==1: 0 without a draw; else mask = next_pow2(n-1)-1, reject next_u32&mask > n-1
- *   randn        NOT available in this mode (polar Box-Muller needs libm's log bit for bit).    */
+ *   randn        legacy_gauss: polar Box-Muller, x = 2U-1 pairs until 0 < r2 < 1,
+ *                f = sqrt(-2*log(r2)/r2), returns f*x2 and caches f*x1 (`has_gauss`); `log` is the
+ *                host libm's, restated bit for bit in include/bsx_libm_log.h; sqrt and / are IEEE.   */
 BSX_HD void bsx_mt_twist(uint32_t* mt, int64_t st) {
   const uint32_t UPPER = 0x80000000u, LOWER = 0x7fffffffu, MATRIX_A = 0x9908b0dfu;
   int kk;
@@ -277,6 +283,31 @@ BSX_HD double bsx_normal_from_k53(uint64_t k) {
   }
   return q < 0 ? -val : val;
 }
-BSX_HD double bsx_normal(bsx_draws* d) { return bsx_normal_from_k53(bsx_k53(d)); }
+/* np.random.RandomState.randn() / standard_normal(): numpy/random/src/legacy/legacy-distributions.c
+ * legacy_gauss, driven by the lane's MT19937 (used by the reference at utils/wrappers.py:278 and
+ * environments/deep_sea.py:126). */
+BSX_HD double bsx_mt_gauss(bsx_draws* d) {
+  BSX_NO_CONTRACT
+  if (d->mt_has_gauss) {
+    const double t = d->mt_gauss;
+    d->mt_has_gauss = 0;
+    d->mt_gauss = 0.0;
+    return t;
+  }
+  double x1, x2, r2;
+  do {
+    x1 = 2.0 * bsx_uniform(d) - 1.0;
+    x2 = 2.0 * bsx_uniform(d) - 1.0;
+    r2 = x1 * x1 + x2 * x2;
+  } while (r2 >= 1.0 || r2 == 0.0);
+  const double f = BSX_SQRT(-2.0 * bsx_libm_log(r2) / r2);
+  d->mt_gauss = f * x1;
+  d->mt_has_gauss = 1;
+  return f * x2;
+}
+BSX_HD double bsx_normal(bsx_draws* d) {
+  if (d->mt) return bsx_mt_gauss(d);
+  return bsx_normal_from_k53(bsx_k53(d));
+}
 
 #endif /* BSX_STREAM_H_ */

@@ -3,9 +3,10 @@
 
 `_small_state_to_image` (:178-204) is restated literally.  `_interpolate_to_image` (:207-219)
 calls skimage.transform.resize, a third-party dependency that is NOT under /root/reference and not
-installed (setup.py lists `scikit-image` unpinned); for scikit-image >= 0.19 and an output no smaller
-than the input that call is scipy.ndimage.zoom(order=1, mode='mirror', grid_mode=True), whose
-arithmetic `resize_bilinear` restates operation by operation in f64 (ni_interpolation.c
+installed (setup.py lists `scikit-image` unpinned); for scikit-image >= 0.19 that call is
+scipy.ndimage.zoom(order=1, mode='mirror', grid_mode=True) — preceded, when an output dimension is
+smaller than the input's, by the anti-aliasing scipy.ndimage.gaussian_filter(sigma=(in/out-1)/2,
+mode='mirror') — whose arithmetic `resize_bilinear` restates operation by operation in f64 (ni_interpolation.c
 NI_ZoomShift: cc = (k+0.5)*zoom-0.5, map_coordinate mirror, weights (1-f, f), 4-term sum in C
 order).  Pinned: bit for bit against scipy.ndimage.zoom (tests/test_image_oracle.py) and against
 fixtures written by the reference's own to_image running over that scipy call
@@ -67,12 +68,51 @@ def axis_table(n_in, n_out):
   return i0, i1, w0, w1
 
 
+def gaussian_half_kernel(n_in, n_out):
+  """skimage's anti-aliasing Gaussian along one axis as scipy builds it: sigma = max(0, (in/out-1)/2)
+  (skimage/transform/_warps.py resize), radius = int(4*sigma + 0.5) and normalised weights
+  exp(-0.5/sigma^2 * x^2) / sum (scipy.ndimage._filters._gaussian_kernel1d).  Returns the weights at
+  distance 0..radius, or None when the axis is not filtered (sigma <= 1e-15, or a 1-tap kernel)."""
+  sigma = max(0.0, (np.float64(n_in) / np.float64(n_out) - 1) / 2)
+  if not sigma > 1e-15:
+    return None
+  radius = int(4.0 * float(sigma) + 0.5)
+  if radius == 0:
+    return None                                     # weights [1.0]: exact identity
+  sigma2 = sigma * sigma
+  x = np.arange(-radius, radius + 1)
+  phi = np.exp(-0.5 / sigma2 * x ** 2)
+  phi = phi / phi.sum()
+  return phi[radius:]
+
+
+def gaussian_prefilter_axis(a, half, axis):
+  """scipy NI_Correlate1D, symmetric branch, mode 'mirror', on a float32 array: per output element
+  t = in[0]*w[0]; for j = radius .. 1: t += (in[-j] + in[+j]) * w[j]  (f64), rounded to f32."""
+  a = np.moveaxis(np.asarray(a, np.float32), axis, -1)
+  n = a.shape[-1]
+  r = len(half) - 1
+  idx = np.array([[_mirror_index(i + j, n) for i in range(n)] for j in range(-r, r + 1)])   # [2r+1, n]
+  d = a.astype(np.float64)
+  t = d * half[0]
+  for j in range(r, 0, -1):
+    t = t + (d[..., idx[r - j]] + d[..., idx[r + j]]) * half[j]
+  return np.moveaxis(t.astype(np.float32), -1, axis)
+
+
 def resize_bilinear(obs, out_shape):
-  """[..., h, w] -> [..., H, W]; leading dimensions are independent images."""
+  """[..., h, w] -> [..., H, W]; leading dimensions are independent images.  When an axis shrinks,
+  skimage >= 0.19 first applies its anti-aliasing Gaussian (scipy.ndimage.gaussian_filter, axis by
+  axis, each pass rounded to the float32 input dtype), then the same order-1 zoom."""
   obs = np.asarray(obs)
   H, W = out_shape
+  lo = obs.min(axis=(-2, -1), keepdims=True)
+  hi = obs.max(axis=(-2, -1), keepdims=True)
   if H < obs.shape[-2] or W < obs.shape[-1]:
-    raise NotImplementedError('down-scaling needs skimage\'s anti-aliasing filter')
+    for axis, n_out in ((-2, H), (-1, W)):
+      half = gaussian_half_kernel(obs.shape[axis], n_out)
+      if half is not None:
+        obs = gaussian_prefilter_axis(obs, half, axis)
   y0, y1, wy0, wy1 = axis_table(obs.shape[-2], H)
   x0, x1, wx0, wx1 = axis_table(obs.shape[-1], W)
   a = obs.astype(np.float64)
@@ -83,9 +123,8 @@ def resize_bilinear(obs, out_shape):
   t = t + (a[..., y1[:, None], x0[None, :]] * wy1) * wx0
   t = t + (a[..., y1[:, None], x1[None, :]] * wy1) * wx1
   out = t.astype(obs.dtype)
-  lo = obs.min(axis=(-2, -1), keepdims=True)
-  hi = obs.max(axis=(-2, -1), keepdims=True)
-  return np.clip(out, lo, hi)                    # skimage's clip=True; a no-op after the f32 cast
+  return np.clip(out, lo, hi)                    # skimage's clip=True (range of the ORIGINAL image); a no-op:
+                                                 # every stage is a convex combination rounded to nearest
 
 
 def small_state_to_image(shape, obs):

@@ -40,7 +40,7 @@ def synthetic_mnist(n=96, seed=7):
   return images, labels
 
 
-def _make_env(bs, family, kwargs, wrap):
+def _make_env(bs, family, kwargs, wrap, wrap_seed=None):
   from bsuite.environments import (bandit, cartpole, catch, deep_sea, discounting_chain,  # pylint: disable=import-outside-toplevel
                                    memory_chain, mountain_car, umbrella_chain)
   from bsuite.experiments.cartpole_swingup import cartpole_swingup  # pylint: disable=import-outside-toplevel
@@ -59,9 +59,9 @@ def _make_env(bs, family, kwargs, wrap):
   if wrap is not None:
     kind, param = wrap
     if kind == 'noise':
-      env = wrappers.RewardNoise(env=env, noise_scale=param, seed=None)
+      env = wrappers.RewardNoise(env=env, noise_scale=param, seed=wrap_seed)
     else:
-      env = wrappers.RewardScale(env=env, reward_scale=param, seed=None)
+      env = wrappers.RewardScale(env=env, reward_scale=param, seed=wrap_seed)
   return env
 
 
@@ -136,7 +136,10 @@ def run_case(bs, name, family, kwargs, lanes, T, seed=42, step0=0, wrap=None, po
   envs, rngs, collectors = [], [], []
   for lane in lanes:
     if rng == 'mt19937':
-      env = _make_env(bs, family, dict(kwargs, seed=lane), wrap)
+      # as the <exp>_noise loaders do (e.g. experiments/catch_noise/catch_noise.py:23-30): the wrapper's
+      # own RandomState gets the same seed as the environment
+      # (SimpleBandit takes no seed: its only generator is the wrapper's, bandit_noise.py:27-34)
+      env = _make_env(bs, family, dict(kwargs) if family == 'bandit' else dict(kwargs, seed=lane), wrap, wrap_seed=lane)
       rngs.append([])
     else:
       env = _make_env(bs, family, kwargs, wrap)
@@ -320,6 +323,17 @@ def cases():
       wrap=('noise', 10.0))
   add('mountain_car_scale', 'mountain_car', dict(max_steps=50), LANES[:3], 120,
       wrap=('scale', 0.001))
+  # (appended last: a case's scripted-random actions are seeded by its position in this list)
+  # ... and where the reference draws randn (numpy's legacy polar Box-Muller on the generator's own
+  # MT19937, libm log included): RewardNoise's own RandomState, the stochastic deep_sea's end cells
+  add('mt_catch_noise', 'catch', dict(), SEEDS, 90, wrap=('noise', 0.5), policies=['optimal'], **mt)
+  add('mt_bandit_noise', 'bandit', dict(mapping_seed=4), SEEDS[:4], 41, wrap=('noise', 1.0), **mt)
+  add('mt_cartpole_noise', 'cartpole', dict(), SEEDS[:4], 200, wrap=('noise', 0.1), **mt)
+  add('mt_deep_sea_stochastic', 'deep_sea', dict(size=6, deterministic=False, mapping_seed=3), SEEDS, 64,
+      policies=ds_pol, **mt)
+  add('mt_deep_sea_stochastic_noise', 'deep_sea', dict(size=5, deterministic=False, mapping_seed=1), SEEDS[:4], 40,
+      wrap=('noise', 0.3), policies=ds_pol, **mt)
+  add('mt_logging_catch_noise', 'catch', dict(), SEEDS[:4], 120, wrap=('noise', 1.0), log='by_episode', **mt)
   return c
 
 
@@ -400,6 +414,18 @@ def make_adapter_fixtures(bs):
       'vector7_14x21': ((14, 21), rng.standard_normal((3, 7)).astype(np.float32)),
       'random_3x5_to_3x5x2': ((3, 5, 2), rng.standard_normal((2, 3, 5)).astype(np.float32)),
   }
+  # down-scaling: skimage's anti-aliasing Gaussian runs along every axis that shrinks (own generator:
+  # the cases above keep the draws they always had)
+  rng2 = np.random.RandomState(12)
+  cases.update({
+      'down_catch_6x4': ((6, 4), env_obs('catch', dict(seed=2), 5, 3)),                                  # radius (1, 1)
+      'down_catch_8x8x3': ((8, 8, 3), env_obs('catch', dict(seed=3), 4, 3)),                             # rows shrink, columns grow
+      'down_deep_sea30_12x12x4': ((12, 12, 4), env_obs('deep_sea', dict(size=30, mapping_seed=42, seed=0), 4, 2)),   # radius 3
+      'down_umbrella103_84x84x4': ((84, 84, 4), env_obs('umbrella_chain', dict(chain_length=5, n_distractor=100, seed=0), 4, 2)),  # one-tap kernel
+      'down_mnist_7x9': ((7, 9), (imgs[2:4].astype(np.int8).astype(np.float32) / 255).reshape(2, 28, 28)),
+      'down_random_40x40_to_5x84': ((5, 84), rng2.standard_normal((2, 40, 40)).astype(np.float32)),     # radius 14 / none
+      'down_vector200_to_9x20x2': ((9, 20, 2), rng2.standard_normal((3, 200)).astype(np.float32)),       # radius 18
+  })
   out, meta = {}, {}
   for name, (shape, obs) in cases.items():
     image = np.stack([rw.to_image(shape, o) for o in obs])

@@ -41,7 +41,10 @@ def test_kernel_reproduces_reference_to_image(case):
     ((1, 23), (33, 47, 3)), ((28, 28), (84, 84, 1)), ((50, 50), (50, 50)), ((1, 3), (84, 84, 4)),
     ((1, 2), (7, 9, 3)), ((1, 1), (5, 5)), ((2, 2), (6, 10, 2)), ((1, 4), (9, 7)), ((3, 5), (3, 5, 2)),
     ((7,), (14, 21)), ((1, 103), (84, 120, 2)), ((5, 1), (9, 4, 6)), ((10, 5), (61, 17, 5)),
-    ((64, 64), (1024, 1000)), ((2, 3), (100, 100, 100))])
+    ((64, 64), (1024, 1000)), ((2, 3), (100, 100, 100)),
+    # down-scaling: anti-aliasing Gaussian along the shrinking axes (radius 1 .. 30), mixed up / down
+    ((10, 5), (6, 4)), ((10, 5), (8, 8, 3)), ((30, 30), (12, 12, 4)), ((1, 103), (84, 84, 4)), ((28, 28), (7, 9)),
+    ((50, 50), (10, 84)), ((1, 412), (84, 84)), ((64, 64), (4, 3)), ((9, 200), (9, 20, 2)), ((7, 7), (6, 6, 5))])
 @pytest.mark.parametrize('lanes', [1, 3, 130])
 def test_kernel_equals_oracle_on_ragged_batches(obs_shape, shape, lanes):
   if lanes == 130 and int(np.prod(shape)) > 200000:
@@ -61,8 +64,10 @@ def test_to_image_out_buffer_and_errors():
   assert res.data_ptr() == out.data_ptr()
   with pytest.raises(ValueError):
     wrappers.to_image((20, 20, 4), obs, out=torch.empty((4, 20, 20), device='cuda'))
-  with pytest.raises(NotImplementedError):
-    wrappers.to_image((5, 5), obs)                               # down-scaling
+  small = wrappers.to_image((5, 5), obs)                         # down-scaling: anti-aliased like skimage
+  np.testing.assert_array_equal(_bits(small.cpu().numpy()), _bits(io.to_image((5, 5), obs.cpu().numpy(), batched=True)))
+  with pytest.raises(ValueError):
+    wrappers.to_image((1, 1), torch.rand((2, 40, 80), device='cuda'))    # filter radius beyond the kernel's limit
   with pytest.raises(ValueError):
     wrappers.to_image((20, 20), torch.rand((4, 2, 3, 4), device='cuda'))
   with pytest.raises(TypeError):

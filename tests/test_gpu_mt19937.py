@@ -2,7 +2,8 @@
 running on its own np.random.RandomState(seed) — no replay shim anywhere — and the engine, given the
 same integer seeds with rng='mt19937', must reproduce them: bit-exact for the integer / grid
 families, teacher-forced 1e-6 for the f32 physics families (their reset states come from the same
-uniform draws)."""
+uniform draws).  That includes every place the reference draws randn — RewardNoise's own RandomState and the
+stochastic deep_sea's end cells — numpy's legacy polar Box-Muller, libm log and all (include/bsx_libm_log.h)."""
 import numpy as np
 import pytest
 import torch
@@ -30,8 +31,10 @@ def test_engine_reproduces_reference_on_its_own_rng(name):
   with warnings.catch_warnings():
     warnings.simplefilter('ignore')
     env = eu.CTORS[fam](**kwargs, seed=seeds, batch=n, rng='mt19937', num_buffers=1)
-  if meta['wrap']:
-    env = wrappers.RewardScale(env, reward_scale=meta['wrap'][1])
+  if meta['wrap']:       # the <exp>_noise / _scale loaders give the wrapper the environment's seed
+    kind, param = meta['wrap']
+    env = (wrappers.RewardNoise(env, noise_scale=param, seed=seeds) if kind == 'noise'
+           else wrappers.RewardScale(env, reward_scale=param))
   logged = None
   if meta.get('log'):
     env = logged = wrappers.Logging(env, None, max_rows=g['log_rows'].shape[1] + 2)
@@ -77,12 +80,29 @@ def test_known_answer_from_the_survey():
   assert xs == [4, 0, 3, 3, 3, 1, 3, 2]
 
 
-def test_mt_mode_rejects_what_needs_randn():
-  from bsuite_amd.environments import deep_sea
-  with pytest.raises(NotImplementedError):
-    deep_sea.DeepSea(5, deterministic=False, seed=1, rng='mt19937')
-  with pytest.raises(NotImplementedError):
-    wrappers.RewardNoise(catch.Catch(seed=1, rng='mt19937'), noise_scale=0.1)
+def test_mt_noise_wrapper_is_the_references_own_randn():
+  """Scalar view: RewardNoise(Catch(seed=s), sigma, seed=s) in MT19937-exact mode returns, as f64, exactly
+  base reward + sigma * np.random.RandomState(s).randn() per non-FIRST step (wrappers.py:267,278), while the
+  environment's own generator keeps producing the reference's ball columns."""
+  s, sigma = 11, 0.7
+  env = wrappers.RewardNoise(catch.Catch(seed=s, rng='mt19937'), noise_scale=sigma, seed=s)
+  plain = catch.Catch(seed=s, rng='mt19937')
+  noise = np.random.RandomState(s)
+  rs = np.random.RandomState(1)
+  for _ in range(200):
+    a = int(rs.randint(3))
+    ts, tp = env.step(a), plain.step(a)
+    assert ts.step_type == tp.step_type
+    np.testing.assert_array_equal(ts.observation, tp.observation)
+    if not ts.first():
+      assert ts.reward == tp.reward + sigma * noise.randn()        # bit for bit, f64
+  # state_dict carries both generators (cached second normal included)
+  twin = wrappers.RewardNoise(catch.Catch(seed=999, rng='mt19937'), noise_scale=sigma, seed=5)
+  twin.raw_env.load_state_dict(env.raw_env.state_dict())
+  for _ in range(30):
+    a = int(rs.randint(3))
+    t1, t2 = env.step(a), twin.step(a)
+    assert (t1.step_type, t1.reward) == (t2.step_type, t2.reward)
 
 
 def test_mt_state_dict_round_trip_and_rollout():

@@ -73,7 +73,7 @@ def test_sweep_rank_assignment_is_a_partition():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize('mode', ['eager', 'graph', 'per_family'])
+@pytest.mark.parametrize('mode', ['eager', 'graph', 'graph_phased', 'per_family'])
 def test_grouped_sweep_equals_standalone_envs(tmp_path, mode):
   """One grouped launch per family advances every segment exactly like its standalone environment
   (eager on one stream, or as concurrent branches of one captured HIP graph)."""
@@ -93,8 +93,10 @@ def test_grouped_sweep_equals_standalone_envs(tmp_path, mode):
     assert 9 <= len(batch._groups) <= 12         # families (+ wide-row classes), not segments
   else:
     assert len(batch._groups) == 5               # deep_sea, catch, mnist + two mixed tile classes
-  if mode == 'graph':
-    assert batch.capture_grouped(num_streams=4) is outs       # runs sweep step 0 eagerly, captures one step
+  if mode in ('graph', 'graph_phased'):
+    # runs sweep step 0 eagerly, captures one step; phased: advance kernels + small groups on one
+    # branch, every observation stream kernel on another as soon as its advance kernel is done
+    assert batch.capture_grouped(num_streams=4 if mode == 'graph' else 2, phased=(mode == 'graph_phased')) is outs
     for _ in range(reps - 1):
       batch.replay_grouped()
   else:

@@ -28,6 +28,25 @@ def test_bilinear_restatement_equals_scipy_zoom(dims):
     np.testing.assert_array_equal(ref.view(np.uint32), got.view(np.uint32))
 
 
+@pytest.mark.parametrize('dims', [(10, 5, 6, 4), (10, 5, 8, 8), (30, 30, 12, 12), (1, 103, 84, 84), (28, 28, 7, 9),
+                                  (50, 50, 10, 84), (1, 412, 84, 84), (64, 64, 3, 2), (9, 200, 9, 20), (7, 7, 6, 6)])
+def test_downscaling_restatement_equals_scipy_gaussian_then_zoom(dims):
+  """An axis that shrinks is pre-filtered (skimage anti_aliasing=None -> sigma=(in/out-1)/2) before the zoom."""
+  ndi = pytest.importorskip('scipy.ndimage')
+  ih, iw, oh, ow = dims
+  rng = np.random.default_rng(ih * 1000 + iw + oh)
+  for trial in range(3):
+    a = (rng.standard_normal((ih, iw)) if trial else (rng.random((ih, iw)) > 0.7)).astype(np.float32)
+    factors = np.divide((ih, iw), (oh, ow))
+    filtered = ndi.gaussian_filter(a, np.maximum(0, (factors - 1) / 2), cval=0, mode='mirror')
+    assert filtered.dtype == np.float32
+    ref = ndi.zoom(filtered, [1 / f for f in factors], order=1, mode='mirror', cval=0, grid_mode=True)
+    got = io.resize_bilinear(a, (oh, ow))
+    assert ref.shape == got.shape == (oh, ow) and got.dtype == np.float32
+    np.testing.assert_array_equal(ref.view(np.uint32), got.view(np.uint32))
+    assert got.min() >= a.min() and got.max() <= a.max()             # skimage's clip=True never bites
+
+
 @pytest.mark.parametrize('case', gu.image_adapter_cases(), ids=lambda c: c[0])
 def test_oracle_reproduces_reference_to_image(case):
   _, shape, obs, image = case
@@ -61,7 +80,7 @@ def test_entry_point_argument_errors_without_a_device():
   assert _call(ok, 4, 64, 72) == _native.BSX_EALIGN                    # image must be 16-byte aligned
   assert _call(_native.ImageCfg(7, 1, 2, 8, 8, 1), 1) == _native.BSX_EINVAL
   assert _call(_native.ImageCfg(_native.IMAGE_SMALL, 1, 5, 8, 8, 1), 1) == _native.BSX_ERANGE      # size > 4
-  assert _call(_native.ImageCfg(_native.IMAGE_BILINEAR, 10, 5, 8, 8, 1), 1) == _native.BSX_ERANGE  # down-scaling
+  assert _call(_native.ImageCfg(_native.IMAGE_BILINEAR, 10, 5, 8, 8, 1, 65), 1) == _native.BSX_ERANGE  # filter radius
   assert _call(_native.ImageCfg(_native.IMAGE_BILINEAR, 2, 2, 2000, 8, 1), 1) == _native.BSX_ERANGE
   assert _call(_native.ImageCfg(_native.IMAGE_BILINEAR, 2, 2, 1024, 1024, 1), 1) == _native.BSX_ERANGE  # >= 2^20 floats
 
@@ -75,7 +94,11 @@ def test_host_rule_selection_matches_to_image():
   assert (c.in_rows, c.in_cols, c.tail) == (1, 7, 1)
   with pytest.raises(ValueError):
     w._image_cfg((8, 8), (2, 3, 4))
-  with pytest.raises(NotImplementedError):
-    w._image_cfg((8, 8), (10, 5))
+  c = w._image_cfg((6, 4), (10, 5))                  # down-scaling: anti-aliasing Gaussian half-kernels
+  assert (c.radius_y, c.radius_x) == (1, 1)
+  np.testing.assert_array_equal(np.array(c.gauss_y[:2]), io.gaussian_half_kernel(10, 6))
+  np.testing.assert_array_equal(np.array(c.gauss_x[:2]), io.gaussian_half_kernel(5, 4))
+  c = w._image_cfg((84, 84), (1, 103))               # sigma 0.113: a one-tap kernel is the identity
+  assert (c.radius_y, c.radius_x) == (0, 0)
   with pytest.raises(AssertionError):
     w._image_cfg((8,), (1, 2))

@@ -65,3 +65,63 @@ def test_vector_binomial_and_uniform_forms(shim):
   np.testing.assert_allclose(got[:23], want[:23], rtol=0, atol=0)
   np.testing.assert_allclose(got[23:27], want[23:27], rtol=0, atol=1e-15)
   assert got[27] == want[27]
+
+
+def _cpu_has_fma():
+  try:
+    with open('/proc/cpuinfo') as f:
+      flags = next(l for l in f if l.startswith('flags')).split()
+    return 'fma' in flags and 'avx2' in flags
+  except (OSError, StopIteration):
+    return False
+
+
+def _run_gauss(shim, rs, ops, args=None):
+  _, key, pos, has_gauss, gauss = rs.get_state()
+  state = np.ascontiguousarray(key, np.uint32).copy()
+  p, h, g = ctypes.c_int32(int(pos)), ctypes.c_int32(int(has_gauss)), ctypes.c_double(float(gauss))
+  ops = np.ascontiguousarray(ops, np.int32)
+  args = np.ascontiguousarray(np.zeros(len(ops)) if args is None else args, np.uint32)
+  out = np.zeros(len(ops), np.float64)
+  shim.mt_run_gauss(state.ctypes.data_as(ctypes.c_void_p), ctypes.byref(p), ctypes.byref(h), ctypes.byref(g),
+                    len(ops), ops.ctypes.data_as(ctypes.c_void_p), args.ctypes.data_as(ctypes.c_void_p),
+                    out.ctypes.data_as(ctypes.c_void_p))
+  return out, state, p.value, h.value, g.value
+
+
+@pytest.mark.skipif(not _cpu_has_fma(), reason='include/bsx_libm_log.h restates the FMA build of glibc log')
+@pytest.mark.parametrize('seed', [0, 42, 2**32 - 1])
+def test_randn_matches_numpy_randomstate_bit_for_bit(shim, seed):
+  """>= 10^6 draws per seed: numpy's legacy polar Box-Muller (cached second value included) driven by
+  the lane's MT19937, with the restated libm log — utils/wrappers.py:278, deep_sea.py:126."""
+  n = 1_000_001                                      # odd: ends with a value in the cache
+  got, state, pos, has_gauss, gauss = _run_gauss(shim, np.random.RandomState(seed), np.full(n, 4))
+  ref = np.random.RandomState(seed)
+  want = ref.randn(n)                                # vector form == n scalar randn() calls
+  np.testing.assert_array_equal(got.view(np.uint64), want.view(np.uint64))
+  _, key, rpos, rhas, rgauss = ref.get_state()
+  assert (has_gauss, gauss) == (rhas, rgauss) and has_gauss == 1
+  assert (pos % 624, list(state)) == (rpos % 624, list(key)) or (pos, list(state)) == (rpos, list(key))
+
+
+@pytest.mark.skipif(not _cpu_has_fma(), reason='include/bsx_libm_log.h restates the FMA build of glibc log')
+def test_randn_interleaved_with_the_other_samplers(shim):
+  """deep_sea's stochastic step mixes randn() and rand() on one generator (deep_sea.py:126,130): the
+  cached normal survives the interleaved uniform draws exactly as in numpy."""
+  rng = np.random.default_rng(5)
+  n = 200_000
+  ops = rng.choice([0, 1, 2, 4], size=n, p=[0.3, 0.1, 0.1, 0.5])
+  args = rng.choice([1, 2, 5, 30, 60000], size=n)
+  ref = np.random.RandomState(99)
+  got, _, _, _, _ = _run_gauss(shim, np.random.RandomState(99), ops, args)
+  want = np.zeros(n)
+  for i in range(n):
+    if ops[i] == 0:
+      want[i] = ref.rand()
+    elif ops[i] == 1:
+      want[i] = ref.binomial(1, 0.5)
+    elif ops[i] == 2:
+      want[i] = ref.randint(int(args[i]))
+    else:
+      want[i] = ref.randn()
+  np.testing.assert_array_equal(got.view(np.uint64), want.view(np.uint64))
