@@ -349,6 +349,11 @@ E2E_RUNS = (
     ('deep_sea/0', 1, 2, 60),
     ('bandit/4', None, 5, 300),
     ('discounting_chain/1', None, 6, 12),
+    # ids whose reference draws randn (RewardNoise's own RandomState; the stochastic deep_sea)
+    # (their sweep settings leave seed=None; deep_sea_stochastic.load takes no seed at all, so only its
+    # step-level fixtures mt_deep_sea_stochastic* exist)
+    ('catch_noise/7', 21, 4, 150),
+    ('bandit_noise/13', 17, 8, 200),
 )
 
 
