@@ -435,14 +435,17 @@ class Rank:
                           num_streams=int(os.environ.get('BSX_SWEEP_STREAMS', '32')),
                           env_kwargs=dict(mnist=mn, mnist_noise=mn, mnist_scale=mn))
     acts = batch.random_actions(seed=1)          # keyed by segment: independent of the rank assignment
-    mode = os.environ.get('BSX_SWEEP_MODE', 'grouped_graph')
-    grouped = mode in ('grouped', 'grouped_graph')
+    mode = os.environ.get('BSX_SWEEP_MODE', 'grouped_streams')
+    grouped = mode in ('grouped', 'grouped_graph', 'grouped_streams')
     if grouped:
-      batch.prepare_groups(acts, mix_small=os.environ.get('BSX_SWEEP_MIX_SMALL', '1') != '0')
+      batch.prepare_groups(acts, mix_small=os.environ.get('BSX_SWEEP_MIX_SMALL', '1') != '0',
+                           mix_pairs=os.environ.get('BSX_SWEEP_MIX_PAIRS', '1') != '0')
       if mode == 'grouped_graph':              # group launches as concurrent branches of one HIP graph
         batch.capture_grouped(int(os.environ.get('BSX_SWEEP_STREAMS', '2')),
                               phased=os.environ.get('BSX_SWEEP_PHASED', '1') != '0')
         replay = batch.replay_grouped
+      elif mode == 'grouped_streams':          # eager, two HIP streams: pipe (advance -> store stream) + small
+        replay = batch.step_grouped_streams
       else:
         replay = batch.step_grouped
     else:
@@ -452,6 +455,7 @@ class Rank:
     def run(n):
       for _ in range(n):
         replay()
+      batch.join_streams()                     # the timing events sit on the current stream
 
     wall, step_ms = self.timed(run, steps, warmup)
     local_bytes = float(sum(l * sb.bytes_per_step(int(np.prod(e.observation_spec().shape)))
@@ -478,7 +482,9 @@ class Rank:
                      'algorithmic_bytes_per_launch': max_rank_bytes,
                      'algorithmic_bytes_all_ranks': total_bytes},
         'launch': (f'{len(batch._groups)} grouped launches per sweep step ({len(batch.envs)} segments on rank 0)'
-                   + (' as concurrent branches of one HIP graph' if mode == 'grouped_graph' else '') if grouped else
+                   + (' as concurrent branches of one HIP graph' if mode == 'grouped_graph' else
+                      ' on two HIP streams (advance -> store stream | small groups + counter bump)' if mode == 'grouped_streams'
+                      else '') if grouped else
                    f'one hipGraph per sweep step ({len(batch.envs)} segments over {batch.num_streams} streams)')}
     batch.release_groups()
     del batch, acts

@@ -146,6 +146,8 @@ struct bsx_group {
   std::vector<uint8_t> args, args2;     // n * arg_size  /  n * arg2_size (second kernel of a pair)
   std::vector<int32_t> blocks, blocks2; // workgroups of each segment in kernel 1 / kernel 2
   std::vector<uint8_t> is_set;
+  std::vector<int32_t> tags;            // BSX_FAM_PAIR_MIXED: family of each segment (empty otherwise)
+  int32_t* d_tags = nullptr;
   size_t lds_bytes = 0;                 // max dynamic LDS over segments (kernel 1)
   void* d_args = nullptr;
   void* d_args2 = nullptr;

@@ -10,62 +10,8 @@
 //            rows*cols = 50 is not a multiple of 4, so a 16-byte chunk may straddle two lanes'
 //            boards (one division per chunk, spill-over elements patched from lane l+1's state).
 #include "bsx_host.h"
-
-#define CATCH_RESET_BIT (1 << 24)
-
-struct catch_fam {
-  struct args {
-    bsx_ctl ctl;
-    const int32_t* action;
-    int32_t* state;
-    bsx_timestep_t out;
-    double* info;        // [1,B]: total_regret
-    int32_t rows, columns;
-  };
-  struct shared { int unused; };
-  __device__ static __forceinline__ void stage(const args&, shared&) {}
-
-  __device__ static __forceinline__ int advance(const args& a, const shared&, int64_t i, uint64_t lane,
-                                                uint64_t step, int32_t st, int act, int32_t& nst,
-                                                double& reward) {
-    const int rows = a.rows, cols = a.columns;
-    int ball_x = st & 0xFF, ball_y = (st >> 8) & 0xFF, paddle_x = (st >> 16) & 0xFF;
-    int type;
-    reward = 0.0;
-    if (a.ctl.force_reset || (st & CATCH_RESET_BIT)) {         // catch.py:80-81 -> :68-76
-      bsx_draws d;
-      bsx_draws_begin(&d, a.ctl, i, lane, step);
-      ball_x = (int)bsx_randint(&d, (uint32_t)cols);            // :71
-      bsx_draws_end(&d, a.ctl, i);
-      ball_y = 0;
-      paddle_x = cols / 2;
-      type = BSX_FIRST;
-    } else {
-      if (act < 0 || act > 2) bsx_note_invalid_action(a.ctl, i);   // reference: IndexError (catch.py:84)
-      const int dx = act - 1;                                   // _ACTIONS :27
-      paddle_x = paddle_x + dx;                                 // :85 np.clip
-      paddle_x = paddle_x < 0 ? 0 : (paddle_x > cols - 1 ? cols - 1 : paddle_x);
-      ball_y += 1;                                              // :88
-      if (ball_y == rows - 1) {                                 // :91-95
-        reward = (paddle_x == ball_x) ? 1.0 : -1.0;
-        a.info[i] += (1.0 - reward);
-        type = BSX_LAST;
-      } else {
-        type = BSX_MID;                                         // :97
-      }
-    }
-    nst = ball_x | (ball_y << 8) | (paddle_x << 16) | (type == BSX_LAST ? CATCH_RESET_BIT : 0);
-    return type;
-  }
-};
-
-struct catch_hot {
-  int rows, cols;
-  __device__ __forceinline__ void operator()(int32_t st, int& a, int& b) const {
-    a = ((st >> 8) & 0xFF) * cols + (st & 0xFF);          // ball   (catch.py:111)
-    b = (rows - 1) * cols + ((st >> 16) & 0xFF);          // paddle (catch.py:112)
-  }
-};
+#include "catch_fam.h"
+#include "pair_mixed.h"
 
 static int catch_make(const bsx_catch_t* cfg, const bsx_call_t* call, const int32_t* action, int32_t* state,
                       bsx_timestep_t out, double* info, catch_fam::args* a) {
@@ -112,10 +58,24 @@ extern "C" int bsx_catch_step(const bsx_catch_t* cfg, const bsx_call_t* call, co
 
 extern "C" int bsx_group_set_catch(bsx_group_t* g, int32_t index, const bsx_catch_t* cfg, const bsx_call_t* call,
                                    const int32_t* action, int32_t* state, bsx_timestep_t out, double* info) {
-  int rc = bsx_group_check_set(g, BSX_FAM_CATCH, index, call, sizeof(catch_fam::args),
-                               sizeof(bsx_stream_seg<catch_hot>), 0);
-  if (rc != 0) return rc;
+  if (g == nullptr) return BSX_ENULL;
+  int rc;
   catch_fam::args a;
+  if (g->family == BSX_FAM_PAIR_MIXED) {            // one segment of the mixed two-kernel group
+    rc = catch_make(cfg, call, action, state, out, info, &a);
+    if (rc != 0) return rc;
+    const uint32_t cells = (uint32_t)(cfg->rows * cfg->columns);
+    if (cells < 4u) return BSX_ERANGE;
+    bsx_stream_seg<catch_hot> sg;
+    sg.obs = out.observation; sg.state = state; sg.n_lanes = a.ctl.n_lanes; sg.cells = cells;
+    sg.cells_magic = bsx_div_magic(cells); sg.dv = bsx_make_div64(cells); sg.fn = catch_hot{cfg->rows, cfg->columns};
+    return bsx_pair_mixed_put(g, BSX_FAM_CATCH, index, call, &a, sizeof(a), &sg, sizeof(sg),
+                              (uint64_t)(a.ctl.n_lanes + BSX_BLOCK - 1) / BSX_BLOCK,
+                              bsx_flat_blocks((uint64_t)a.ctl.n_lanes * cells, 2));
+  }
+  rc = bsx_group_check_set(g, BSX_FAM_CATCH, index, call, sizeof(catch_fam::args),
+                           sizeof(bsx_stream_seg<catch_hot>), 0);
+  if (rc != 0) return rc;
   rc = catch_make(cfg, call, action, state, out, info, &a);
   if (rc != 0) return rc;
   g->launch = bsx_group_launch_pair<catch_fam, catch_hot, 2>;

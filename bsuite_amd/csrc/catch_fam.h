@@ -1,0 +1,65 @@
+// catch_fam.h — the device side of batched Catch (bsuite/environments/catch.py:68-114): the lane advance
+// (catch_fam) and the two-hot decoder of the observation stream (catch_hot).  Shared by catch.hip and
+// pair_mixed.hip (the sweep's mixed two-kernel group).
+#ifndef BSX_CATCH_FAM_H_
+#define BSX_CATCH_FAM_H_
+
+#include "bsx_device.h"
+
+#define CATCH_RESET_BIT (1 << 24)
+
+struct catch_fam {
+  struct args {
+    bsx_ctl ctl;
+    const int32_t* action;
+    int32_t* state;
+    bsx_timestep_t out;
+    double* info;        // [1,B]: total_regret
+    int32_t rows, columns;
+  };
+  struct shared { int unused; };
+  __device__ static __forceinline__ void stage(const args&, shared&) {}
+
+  __device__ static __forceinline__ int advance(const args& a, const shared&, int64_t i, uint64_t lane,
+                                                uint64_t step, int32_t st, int act, int32_t& nst,
+                                                double& reward) {
+    const int rows = a.rows, cols = a.columns;
+    int ball_x = st & 0xFF, ball_y = (st >> 8) & 0xFF, paddle_x = (st >> 16) & 0xFF;
+    int type;
+    reward = 0.0;
+    if (a.ctl.force_reset || (st & CATCH_RESET_BIT)) {         // catch.py:80-81 -> :68-76
+      bsx_draws d;
+      bsx_draws_begin(&d, a.ctl, i, lane, step);
+      ball_x = (int)bsx_randint(&d, (uint32_t)cols);            // :71
+      bsx_draws_end(&d, a.ctl, i);
+      ball_y = 0;
+      paddle_x = cols / 2;
+      type = BSX_FIRST;
+    } else {
+      if (act < 0 || act > 2) bsx_note_invalid_action(a.ctl, i);   // reference: IndexError (catch.py:84)
+      const int dx = act - 1;                                   // _ACTIONS :27
+      paddle_x = paddle_x + dx;                                 // :85 np.clip
+      paddle_x = paddle_x < 0 ? 0 : (paddle_x > cols - 1 ? cols - 1 : paddle_x);
+      ball_y += 1;                                              // :88
+      if (ball_y == rows - 1) {                                 // :91-95
+        reward = (paddle_x == ball_x) ? 1.0 : -1.0;
+        a.info[i] += (1.0 - reward);
+        type = BSX_LAST;
+      } else {
+        type = BSX_MID;                                         // :97
+      }
+    }
+    nst = ball_x | (ball_y << 8) | (paddle_x << 16) | (type == BSX_LAST ? CATCH_RESET_BIT : 0);
+    return type;
+  }
+};
+
+struct catch_hot {
+  int rows, cols;
+  __device__ __forceinline__ void operator()(int32_t st, int& a, int& b) const {
+    a = ((st >> 8) & 0xFF) * cols + (st & 0xFF);          // ball   (catch.py:111)
+    b = (rows - 1) * cols + ((st >> 16) & 0xFF);          // paddle (catch.py:112)
+  }
+};
+
+#endif  // BSX_CATCH_FAM_H_

@@ -16,92 +16,8 @@
 // lanes, synchronise and then store (per-block 230 KB tiles, or flat 16 KiB runs with ping-pong
 // state) measured 5.1-5.5 TB/s against 6.2-6.4 TB/s for this pair (profiles/r01/ab_*.log).
 #include "bsx_host.h"
-
-#define DS_RESET_BIT (1 << 17)
-#define DS_MAP_WORDS (BSX_DEEP_SEA_MAX_SIZE * BSX_DEEP_SEA_MAX_SIZE / 32)
-
-struct deep_sea_fam {
-  struct args {
-    bsx_ctl ctl;
-    const int32_t* action;
-    int32_t* state;
-    bsx_timestep_t out;
-    double* info;        // [2,B]: total_bad_episodes, denoised_return
-    double move_cost;
-    double inv_size;
-    int32_t size;
-    int32_t deterministic;
-    uint32_t mapping_bits[DS_MAP_WORDS];
-  };
-  struct shared { uint32_t map[DS_MAP_WORDS]; };
-
-  __device__ static __forceinline__ void stage(const args& a, shared& s) {
-    const int map_words = (a.size * a.size + 31) >> 5;
-    for (int w = threadIdx.x; w < map_words; w += BSX_BLOCK) s.map[w] = a.mapping_bits[w];
-  }
-
-  // One lane's reset()/step() (base.py:59-65 -> deep_sea.py:110-144).
-  __device__ static __forceinline__ int advance(const args& a, const shared& s, int64_t i, uint64_t lane,
-                                                uint64_t step, int32_t st, int act, int32_t& nst,
-                                                double& reward) {
-    BSX_NO_CONTRACT
-    const int N = a.size;
-    int row = st & 0xFF, col = (st >> 8) & 0xFF, bad = (st >> 16) & 1;
-    int type;
-    reward = 0.0;
-    if (a.ctl.force_reset || (st & DS_RESET_BIT)) {            // base.py:61-62 -> deep_sea.py:110-114
-      row = 0; col = 0; bad = 0;
-      type = BSX_FIRST;
-    } else {
-      const int cell = row * N + col;
-      const int mapped = (int)((s.map[cell >> 5] >> (cell & 31)) & 1u);
-      const bool right = (act == mapped);                       // deep_sea.py:118
-      bsx_draws d;
-      bsx_draws_begin(&d, a.ctl, i, lane, step);
-      if (col == N - 1 && right) {                              // :121-123
-        reward += 1.0;
-        a.info[a.ctl.n_lanes + i] += 1.0;
-      }
-      if (!a.deterministic && row == N - 1 && (col == 0 || col == N - 1))   // :124-126
-        reward += bsx_normal(&d);
-      if (right) {                                              // :129-132
-        // The reference draws rand() here even when deterministic (the value is then unused).  The
-        // counter-based stream restarts at every call, so an unused draw leaves no trace and is
-        // skipped; the lane's own MT19937 generator (exact mode) must advance, so there it is drawn.
-        bool moves = true;
-        if (!a.deterministic || a.ctl.mt_state != nullptr) {
-          const double u = bsx_uniform(&d);
-          moves = (u > a.inv_size) || a.deterministic;
-        }
-        if (moves) col = col + 1 > N - 1 ? N - 1 : col + 1;
-        reward -= a.move_cost;
-      } else {                                                  // :133-136
-        if (row == col) bad = 1;
-        col = col - 1 < 0 ? 0 : col - 1;
-      }
-      bsx_draws_end(&d, a.ctl, i);
-      row += 1;                                                 // :137
-      if (row == N) {                                           // :140-143
-        if (bad) a.info[i] += 1.0;
-        type = BSX_LAST;
-      } else {
-        type = BSX_MID;
-      }
-    }
-    nst = row | (col << 8) | (bad << 16) | (type == BSX_LAST ? DS_RESET_BIT : 0);
-    return type;
-  }
-};
-
-// hot cell of a lane from its packed state (observation stream kernel)
-struct deep_sea_hot {
-  int N;
-  __device__ __forceinline__ void operator()(int32_t st, int& a, int& b) const {
-    const int row = st & 0xFF, col = (st >> 8) & 0xFF;
-    a = row < N ? row * N + col : -1;     // deep_sea.py:105-107 (terminal observation is all-zero)
-    b = -1;
-  }
-};
+#include "deep_sea_fam.h"
+#include "pair_mixed.h"
 
 // Validates one call's arguments and fills the kernel argument struct (shared by step and group).
 static int deep_sea_make(const bsx_deep_sea_t* cfg, const bsx_call_t* call, const int32_t* action,
@@ -156,10 +72,24 @@ extern "C" int bsx_deep_sea_step(const bsx_deep_sea_t* cfg, const bsx_call_t* ca
 extern "C" int bsx_group_set_deep_sea(bsx_group_t* g, int32_t index, const bsx_deep_sea_t* cfg,
                                       const bsx_call_t* call, const int32_t* action, int32_t* state,
                                       bsx_timestep_t out, double* info) {
-  int rc = bsx_group_check_set(g, BSX_FAM_DEEP_SEA, index, call, sizeof(deep_sea_fam::args),
-                               sizeof(bsx_stream_seg<deep_sea_hot>), 0);
-  if (rc != 0) return rc;
+  if (g == nullptr) return BSX_ENULL;
+  int rc;
   deep_sea_fam::args a;
+  if (g->family == BSX_FAM_PAIR_MIXED) {            // one segment of the mixed two-kernel group
+    rc = deep_sea_make(cfg, call, action, state, out, info, &a);
+    if (rc != 0) return rc;
+    const uint32_t cells = (uint32_t)(cfg->size * cfg->size);
+    if (cells < 4u) return BSX_ERANGE;
+    bsx_stream_seg<deep_sea_hot> sg;
+    sg.obs = out.observation; sg.state = state; sg.n_lanes = a.ctl.n_lanes; sg.cells = cells;
+    sg.cells_magic = bsx_div_magic(cells); sg.dv = bsx_make_div64(cells); sg.fn = deep_sea_hot{cfg->size};
+    return bsx_pair_mixed_put(g, BSX_FAM_DEEP_SEA, index, call, &a, sizeof(a), &sg, sizeof(sg),
+                              (uint64_t)(a.ctl.n_lanes + BSX_BLOCK - 1) / BSX_BLOCK,
+                              bsx_flat_blocks((uint64_t)a.ctl.n_lanes * cells, 4));
+  }
+  rc = bsx_group_check_set(g, BSX_FAM_DEEP_SEA, index, call, sizeof(deep_sea_fam::args),
+                           sizeof(bsx_stream_seg<deep_sea_hot>), 0);
+  if (rc != 0) return rc;
   rc = deep_sea_make(cfg, call, action, state, out, info, &a);
   if (rc != 0) return rc;
   g->launch = bsx_group_launch_pair<deep_sea_fam, deep_sea_hot, 4>;

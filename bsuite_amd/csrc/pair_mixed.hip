@@ -1,0 +1,94 @@
+// pair_mixed.hip — ONE launch pair for all the two-kernel families of a heterogeneous sweep.
+//
+// deep_sea, catch and the mnist bandit each step as advance kernel + observation stream kernel.  In a
+// sweep (BASELINE config 5: 468 bsuite_ids as lane segments) their three grouped pairs are six kernels;
+// the timeline of a captured sweep step (profiles/r02/sweep_graph_timeline_before.txt) shows what that
+// costs: every dependent node of a HIP graph starts 6-14 us after its predecessor ends, the three
+// advance kernels run one after another in front of "their" streams, and two store-bound kernels that
+// overlap slow each other down.  A BSX_FAM_PAIR_MIXED group holds segments of all three families in
+// fixed-stride argument slots next to a family tag (like BSX_FAM_SMALL_MIXED for the small families):
+//   phase 0  pair_mixed_advance_kernel   every lane of every segment advances in one ~8 us launch;
+//   phase 1  pair_mixed_stream_kernel    ONE store stream over all observation arrays (~850 of the
+//                                        sweep's 886 MB), each workgroup running its family's stream
+//                                        body (deep_sea 4 x 4 KiB, catch 2 x 4 KiB, mnist 8 x 4 KiB runs).
+#include "catch_fam.h"
+#include "deep_sea_fam.h"
+#include "mnist_fam.h"
+#include "pair_mixed.h"
+
+#define PAIR_ADV_STRIDE 1024
+#define PAIR_STR_STRIDE 1280
+#define PAIR_MNIST_K 8
+
+static_assert(sizeof(deep_sea_fam::args) <= PAIR_ADV_STRIDE && sizeof(catch_fam::args) <= PAIR_ADV_STRIDE &&
+              sizeof(mnist_args) <= PAIR_ADV_STRIDE, "advance argument struct exceeds the mixed-group slot");
+static_assert(sizeof(bsx_stream_seg<deep_sea_hot>) <= PAIR_STR_STRIDE && sizeof(bsx_stream_seg<catch_hot>) <= PAIR_STR_STRIDE &&
+              sizeof(mnist_observe_args) <= PAIR_STR_STRIDE, "stream argument struct exceeds the mixed-group slot");
+
+__global__ void __launch_bounds__(BSX_BLOCK) pair_mixed_advance_kernel(const uint8_t* __restrict__ table,
+                                                                       const int32_t* __restrict__ family,
+                                                                       const bsx_group_index gi) {
+  __shared__ deep_sea_fam::shared s_ds;
+  __shared__ catch_fam::shared s_ca;
+  __shared__ unsigned int s_cnt[2];
+  const bsx_group_slot w = bsx_group_find(gi, (int)blockIdx.x);
+  const uint8_t* slot = table + (size_t)w.seg * PAIR_ADV_STRIDE;
+  switch (family[w.seg]) {                          // uniform per workgroup
+    case BSX_FAM_DEEP_SEA: bsx_advance_body<deep_sea_fam>(*reinterpret_cast<const deep_sea_fam::args*>(slot), w.block, s_ds, s_cnt); break;
+    case BSX_FAM_CATCH: bsx_advance_body<catch_fam>(*reinterpret_cast<const catch_fam::args*>(slot), w.block, s_ca, s_cnt); break;
+    case BSX_FAM_MNIST: mnist_advance_body(*reinterpret_cast<const mnist_args*>(slot), w.block, s_cnt); break;
+    default: break;
+  }
+}
+
+__global__ void __launch_bounds__(BSX_BLOCK) pair_mixed_stream_kernel(const uint8_t* __restrict__ table,
+                                                                      const int32_t* __restrict__ family,
+                                                                      const bsx_group_index gi) {
+  __shared__ float s_lut[256];
+  const bsx_group_slot w = bsx_group_find(gi, (int)blockIdx.x);
+  const uint8_t* slot = table + (size_t)w.seg * PAIR_STR_STRIDE;
+  switch (family[w.seg]) {
+    case BSX_FAM_DEEP_SEA: {
+      const bsx_stream_seg<deep_sea_hot>& g = *reinterpret_cast<const bsx_stream_seg<deep_sea_hot>*>(slot);
+      bsx_hot_stream_body<deep_sea_hot, 4, BSX_BLOCK>(g.obs, g.state, g.n_lanes, g.cells, g.cells_magic, g.dv, g.fn, w.block);
+      break;
+    }
+    case BSX_FAM_CATCH: {
+      const bsx_stream_seg<catch_hot>& g = *reinterpret_cast<const bsx_stream_seg<catch_hot>*>(slot);
+      bsx_hot_stream_body<catch_hot, 2, BSX_BLOCK>(g.obs, g.state, g.n_lanes, g.cells, g.cells_magic, g.dv, g.fn, w.block);
+      break;
+    }
+    case BSX_FAM_MNIST:
+      mnist_observe_body<PAIR_MNIST_K, 3>(*reinterpret_cast<const mnist_observe_args*>(slot), w.block, s_lut);
+      break;
+    default: break;
+  }
+}
+
+static int pair_mixed_launch(bsx_group* g, int phase, hipStream_t st) {
+  if (phase != 1)
+    pair_mixed_advance_kernel<<<dim3((unsigned)g->total_blocks), dim3(BSX_BLOCK), 0, st>>>(
+        (const uint8_t*)g->d_args, g->d_tags, g->index1());
+  if (phase != 0)
+    pair_mixed_stream_kernel<<<dim3((unsigned)g->total_blocks2), dim3(BSX_BLOCK), 0, st>>>(
+        (const uint8_t*)g->d_args2, g->d_tags, g->index2());
+  return (int)hipGetLastError();
+}
+
+int bsx_pair_mixed_put(bsx_group* g, int32_t family, int32_t index, const bsx_call_t* call,
+                       const void* adv, size_t adv_size, const void* str, size_t str_size,
+                       uint64_t blocks1, uint64_t blocks2) {
+  if (adv_size > PAIR_ADV_STRIDE || str_size > PAIR_STR_STRIDE) return BSX_EINVAL;
+  int rc = bsx_group_check_set(g, BSX_FAM_PAIR_MIXED, index, call, PAIR_ADV_STRIDE, PAIR_STR_STRIDE, 0);
+  if (rc != 0) return rc;
+  if (blocks1 > 0x3FFFFFFFull || blocks2 > 0x3FFFFFFFull) return BSX_EINVAL;
+  memcpy(&g->args[(size_t)index * PAIR_ADV_STRIDE], adv, adv_size);
+  memcpy(&g->args2[(size_t)index * PAIR_STR_STRIDE], str, str_size);
+  if (g->tags.empty()) g->tags.assign((size_t)g->n, -1);
+  g->tags[index] = family;
+  g->blocks[index] = (int32_t)blocks1; g->blocks2[index] = (int32_t)blocks2;
+  g->is_set[index] = 1;
+  g->launch = pair_mixed_launch;
+  g->n_phases = 2;
+  return 0;
+}

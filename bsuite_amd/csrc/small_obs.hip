@@ -104,12 +104,18 @@ static int small_obs_group_launch(bsx_group* g, int phase, hipStream_t st) {
 #define SMALL_MIXED_STRIDE 1024
 static int small_obs_mixed_launch(bsx_group* g, int phase, hipStream_t st);
 
+// Tile class of a segment inside a GROUPED launch (segments of one group must share it): 256-lane tiles
+// while the observation row is at most 32 floats, 64-lane tiles beyond — the rule of launch_small_obs.
+// (Splitting at 8 or 3 floats, so that the 256-lane launch of a sweep needs only 8 KiB of LDS per
+// workgroup, changed nothing: profiles/r02/ab_sweep_small_class.log.)
+extern "C" int bsx_group_small_class(int32_t numel) { return numel <= 32 ? 256 : 64; }
+
 // Records one segment of a small-observation family in a group (of its own family, or mixed).
 template <class Env>
 static int small_obs_group_put(bsx_group* g, int32_t family, int32_t index, const bsx_call_t* call,
                                const typename Env::args& a, int numel) {
   static_assert(sizeof(typename Env::args) <= SMALL_MIXED_STRIDE, "argument struct exceeds the mixed-group slot");
-  const int lpb = numel <= 32 ? 256 : 64;
+  const int lpb = bsx_group_small_class(numel);
   const bool mixed = g != nullptr && g->family == BSX_FAM_SMALL_MIXED;
   int rc = bsx_group_check_set(g, mixed ? BSX_FAM_SMALL_MIXED : family, index, call,
                                mixed ? SMALL_MIXED_STRIDE : sizeof(typename Env::args), mixed ? sizeof(int32_t) : 0, lpb);
@@ -481,9 +487,9 @@ struct cartpole_env {
       xd = __builtin_fmaf(g.timescale, x_acc, xd);
       // np.remainder(theta + dt*theta_dot, 2*pi) in f64 (the period is not the f32 2*pi): one
       // conditional +-2*pi is exact (Sterbenz) whenever the sum is within one period of [0, 2*pi)
-      double ang = (double)th + (double)g.timescale * (double)thd;
-      if (ang >= 6.283185307179586) ang -= 6.283185307179586;
-      else if (ang < 0.0) ang += 6.283185307179586;
+      const double raw_ang = (double)th + (double)g.timescale * (double)thd;
+      double ang = raw_ang >= 6.283185307179586 ? raw_ang - 6.283185307179586       // selects, not branches
+                   : (raw_ang < 0.0 ? raw_ang + 6.283185307179586 : raw_ang);
       if (!(ang >= 0.0 && ang < 6.283185307179586)) {           // |dt*theta_dot| > 2*pi (theta_dot > 600 rad/s:
         ang = (double)th + (double)g.timescale * (double)thd;   // only reachable from a loaded state)
         ang -= 6.283185307179586 * floor(ang / 6.283185307179586);

@@ -99,6 +99,9 @@ class SweepBatch:
     self._groups = []
     self._groups_by_cost = []
     self._grouped_graph = None
+    self._pipe = None                          # step_grouped_streams(): the two HIP streams + their events
+    self._small = None
+    self._pending_steps = 0
 
   # ---------------------------------------------------------------------------------------
   def random_actions(self, seed: int = 0) -> List[torch.Tensor]:
@@ -121,17 +124,20 @@ class SweepBatch:
 
   def step(self, actions: Sequence[torch.Tensor]):
     """Eager sweep step: one launch (pair) per local segment on the current stream."""
+    self.flush_step_indices()
     outs = [env.step(a) for env, a in zip(self.envs, actions)]
     self._bump()
     return outs
 
   # -- grouped launches --------------------------------------------------------------------
-  def prepare_groups(self, actions: Sequence[torch.Tensor], mix_small: bool = True):
-    """Builds the launch groups: one per two-kernel family (deep_sea, catch, mnist) and — with
-    `mix_small` — ONE mixed group per tile class for all small-observation families together
-    (BSX_FAM_SMALL_MIXED), else one per (family, class).  Records every local segment with its
-    static `actions` tensor and uploads the argument tables.  Returns the per-segment output
-    TimeSteps (tensors that every `step_grouped()` overwrites)."""
+  def prepare_groups(self, actions: Sequence[torch.Tensor], mix_small: bool = True, mix_pairs: bool = True):
+    """Builds the launch groups.  With `mix_pairs` (default) ONE mixed group for the two-kernel families
+    deep_sea, catch and mnist together (BSX_FAM_PAIR_MIXED: one advance launch + one observation-stream
+    launch for all their segments), else one group per family; with `mix_small` ONE mixed group per
+    tile class for all small-observation families together (BSX_FAM_SMALL_MIXED), else one per
+    (family, class).  Records every local segment with its static `actions` tensor and uploads the
+    argument tables.  Returns the per-segment output TimeSteps (tensors that every `step_grouped()`
+    overwrites)."""
     import ctypes  # pylint: disable=import-outside-toplevel
     from bsuite_amd import _native  # pylint: disable=import-outside-toplevel
     from bsuite_amd import dm_env_compat as dm_env  # pylint: disable=import-outside-toplevel
@@ -143,8 +149,9 @@ class SweepBatch:
       raw._ensure_allocated()  # pylint: disable=protected-access
       numel = int(np.prod(raw.observation_spec().shape))
       small = raw._abi_name not in ('deep_sea', 'catch', 'mnist')  # pylint: disable=protected-access
-      klass = (256 if numel <= 32 else 64) if small else 0
-      group_family = 'small_mixed' if (small and mix_small) else raw._abi_name  # pylint: disable=protected-access
+      klass = _native.lib.bsx_group_small_class(numel) if small else 0
+      group_family = ('small_mixed' if (small and mix_small) else
+                      'pair_mixed' if (not small and mix_pairs) else raw._abi_name)  # pylint: disable=protected-access
       buckets.setdefault((group_family, klass), []).append(k)
     outs = [None] * len(self.envs)
     costs = []
@@ -177,21 +184,94 @@ class SweepBatch:
       if rc != 0:
         _native.check(rc, 'bsx_group_step')
     self._bump()
-    for env in self.envs:                      # host-side bookkeeping of the call index
-      raw = env.raw_env if hasattr(env, 'raw_env') else env
-      raw._step_index += 1  # pylint: disable=protected-access
+    self._pending_steps += 1                   # host-side call index: settled lazily (flush_step_indices)
     return self._group_outs
+
+  # -- eager two-stream schedule ----------------------------------------------------------
+  def step_grouped_streams(self):
+    """One sweep step, eager, on two HIP streams owned by the batch (no graph): the `pipe` stream runs
+    the advance kernel(s) of the two-kernel families followed by their observation stream kernel(s);
+    the `small` stream runs the small-observation groups beside them and bumps the shared call counter
+    as soon as the advance and small kernels — its only readers — are done.  Consecutive kernels of a
+    stream start within a few microseconds of each other, where dependent nodes of a captured HIP graph
+    start 6-14 us apart and consecutive graph launches ~20 us apart on this stack
+    (profiles/r02/sweep_graph_timeline_*.txt): for a step of ~165 us that is the difference.  Call
+    `join_streams()` before reading the outputs on the current stream."""
+    from bsuite_amd import _native  # pylint: disable=import-outside-toplevel
+    if self._pipe is None:
+      cur = torch.cuda.current_stream(self.device)
+      self._pipe, self._small = torch.cuda.Stream(device=self.device), torch.cuda.Stream(device=self.device)
+      self._ev_adv, self._ev_bump, self._ev_small = torch.cuda.Event(), torch.cuda.Event(), torch.cuda.Event()
+      import os  # pylint: disable=import-outside-toplevel
+      self._small_beside_advance = os.environ.get('BSX_SWEEP_SMALL_BESIDE', 'stream') == 'advance'
+      self._pipe.wait_stream(cur)
+      self._small.wait_stream(cur)
+      self._pairs = [h for h in self._groups_by_cost if _native.lib.bsx_group_phases(h) == 2]
+      self._singles = [h for h in self._groups_by_cost if _native.lib.bsx_group_phases(h) == 1]
+    else:
+      self._pipe.wait_event(self._ev_bump)     # this step's kernels read the counter the last step bumped
+    pipe, small = self._pipe.cuda_stream, self._small.cuda_stream
+    step_phase = _native.lib.bsx_group_step_phase
+    for handle in self._pairs:
+      rc = step_phase(handle, 0, pipe)
+      if rc != 0:
+        _native.check(rc, 'bsx_group_step_phase')
+    self._ev_adv.record(self._pipe)
+    for handle in self._singles:
+      rc = step_phase(handle, 0, small)
+      if rc != 0:
+        _native.check(rc, 'bsx_group_step_phase')
+    if self._small_beside_advance:
+      # A/B knob BSX_SWEEP_SMALL_BESIDE=advance: the store stream starts only when the small groups are
+      # done too (everything latency-bound overlaps, then the HBM-bound stream has the machine to
+      # itself) — measured 3-5 % slower than letting them run beside the stream
+      # (profiles/r02/ab_sweep_pair_mixed.log)
+      self._ev_small.record(self._small)
+      self._pipe.wait_event(self._ev_small)
+    for handle in self._pairs:
+      rc = step_phase(handle, 1, pipe)
+      if rc != 0:
+        _native.check(rc, 'bsx_group_step_phase')
+    self._small.wait_event(self._ev_adv)
+    _native.check(_native.lib.bsx_counter_add(self._step_counter.data_ptr(), 1, small), 'sweep step counter')
+    self._ev_bump.record(self._small)
+    self._pending_steps += 1                   # host-side call index: settled lazily (flush_step_indices)
+    return self._group_outs
+
+  def flush_step_indices(self):
+    """Settles the environments' host-side call index (`env.step_index`) after grouped steps: a grouped
+    step costs the host a handful of launches, not a loop over several hundred environment objects;
+    the authoritative index lives in the shared device counter anyway."""
+    n, self._pending_steps = self._pending_steps, 0
+    if n:
+      for env in self.envs:
+        raw = env.raw_env if hasattr(env, 'raw_env') else env
+        raw._step_index += n  # pylint: disable=protected-access
+
+  def sync(self):
+    """join_streams() + flush_step_indices() + a device synchronisation: call before inspecting the
+    environments after grouped steps."""
+    self.join_streams()
+    self.flush_step_indices()
+    torch.cuda.synchronize(self.device)
+
+  def join_streams(self):
+    """Makes the current stream wait for everything `step_grouped_streams()` has issued."""
+    if self._pipe is not None:
+      cur = torch.cuda.current_stream(self.device)
+      cur.wait_stream(self._pipe)
+      cur.wait_stream(self._small)
 
   def capture_grouped(self, num_streams: int = 2, phased: bool = True):
     """Captures one grouped sweep step as a HIP graph.
 
-    phased=True (default): the step is split by what bounds each kernel.  One branch runs everything
-    latency-bound back to back — the lane-advance kernels of the two-kernel families (largest store
-    stream first), then the small-observation groups, each near the ~8 us floor of a launch and moving
-    little data; every observation stream kernel (HBM-bound: deep_sea, mnist, catch carry ~850 of the
-    sweep's 886 MB) starts on one of `num_streams` other branches as soon as ITS advance kernel is done
-    (one event per group, bsx_group_step_phase).  The store streams then run from ~6 us into the step
-    to its end with the small kernels hidden beside them.
+    phased=True (default): the step is split by what bounds each kernel (bsx_group_step_phase).  The
+    main branch runs the lane-advance kernel(s) of the two-kernel families; every observation stream
+    kernel (HBM-bound: deep_sea, mnist, catch carry ~850 of the sweep's 886 MB) starts on a side branch
+    as soon as ITS advance kernel is done; the small-observation groups (latency-bound, little data) run
+    on another side branch from the start; the shared call counter — read by the advance and small
+    kernels only — is bumped as soon as those are done, beside the store streams.  With the default
+    mixed groups that is: advance -> stream on the critical path and nothing else.
     phased=False: whole groups as `num_streams` round-robin branches (the r01 topology).
     Groups are independent (disjoint segments); the shared call counter is bumped after the join.
     Call prepare_groups() first; then `replay_grouped()` per sweep step."""
@@ -201,7 +281,7 @@ class SweepBatch:
     self.step_grouped()                        # one eager step: first-use work stays out of the capture
     torch.cuda.synchronize(self.device)
     main = torch.cuda.Stream(device=self.device)
-    n_side = max(1, int(num_streams)) if phased else max(1, int(num_streams)) - 1
+    n_side = max(2, int(num_streams)) if phased else max(1, int(num_streams)) - 1
     side = [torch.cuda.Stream(device=self.device) for _ in range(n_side)]
     main.wait_stream(torch.cuda.current_stream(self.device))
     graph = torch.cuda.CUDAGraph()
@@ -209,18 +289,29 @@ class SweepBatch:
       with torch.cuda.graph(graph, stream=main):
         for st in side:
           st.wait_stream(main)                 # fork
+        bumped = False
         if phased:
           pairs = [h for h in self._groups_by_cost if _native.lib.bsx_group_phases(h) == 2]
           singles = [h for h in self._groups_by_cost if _native.lib.bsx_group_phases(h) == 1]
+          # `small` runs the small-observation groups from t = 0; main runs the advance kernels; every
+          # stream kernel goes to a side branch as soon as ITS advance kernel is done.
+          small = side[-1] if (len(side) > 1 and singles) else main
+          streams = side[:-1] if small is not main else side
+          for handle in singles:
+            _native.check(_native.lib.bsx_group_step_phase(handle, 0, small.cuda_stream), 'bsx_group_step_phase')
           for j, handle in enumerate(pairs):   # heaviest store stream first
             _native.check(_native.lib.bsx_group_step_phase(handle, 0, main.cuda_stream), 'bsx_group_step_phase')
             ev = torch.cuda.Event()
             ev.record(main)
-            st = side[j % len(side)]
+            st = streams[j % len(streams)]
             st.wait_event(ev)
             _native.check(_native.lib.bsx_group_step_phase(handle, 1, st.cuda_stream), 'bsx_group_step_phase')
-          for handle in singles:
-            _native.check(_native.lib.bsx_group_step_phase(handle, 0, main.cuda_stream), 'bsx_group_step_phase')
+          # The call counter is read by the advance and small kernels only (stream kernels decode
+          # states): bump it as soon as THOSE are done, beside the store streams, not after them.
+          if small is not main:
+            main.wait_stream(small)
+          self._bump()
+          bumped = True
         else:
           lanes = [main] + side
           for j, handle in enumerate(self._groups_by_cost):
@@ -228,7 +319,8 @@ class SweepBatch:
             _native.check(_native.lib.bsx_group_step(handle, st.cuda_stream), 'bsx_group_step')
         for st in side:
           main.wait_stream(st)                 # join
-        self._bump()
+        if not bumped:
+          self._bump()
     torch.cuda.current_stream(self.device).wait_stream(main)
     self._grouped_graph = graph
     self._grouped_streams = [main] + side
@@ -237,14 +329,18 @@ class SweepBatch:
   def replay_grouped(self):
     """One sweep step from the graph captured by capture_grouped()."""
     self._grouped_graph.replay()
-    for env in self.envs:
-      raw = env.raw_env if hasattr(env, 'raw_env') else env
-      raw._step_index += 1  # pylint: disable=protected-access
+    self._pending_steps += 1
     return self._group_outs
 
   def release_groups(self):
     from bsuite_amd import _native  # pylint: disable=import-outside-toplevel
     self._grouped_graph = None
+    if hasattr(self, '_pending_steps'):
+      self.flush_step_indices()
+    if getattr(self, '_pipe', None) is not None:
+      self.join_streams()
+      torch.cuda.synchronize(self.device)
+      self._pipe = self._small = None
     for handle in self._groups:
       _native.lib.bsx_group_destroy(handle)
     self._groups = []
@@ -291,6 +387,8 @@ class SweepBatch:
   def summary(self) -> Dict[str, Dict[str, float]]:
     """Per local bsuite_id: lanes, episodes finished/started, sum of every bsuite_info column."""
     from bsuite_amd import distributed as bdist  # pylint: disable=import-outside-toplevel
+    self.join_streams()
+    self.flush_step_indices()
     out = {}
     for env, (bid, _, _) in zip(self.envs, self.segments):
       vec, names = bdist.local_summary(env)

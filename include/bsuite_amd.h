@@ -315,6 +315,9 @@ typedef struct bsx_group bsx_group_t;
  * discounting_chain, cartpole and mountain_car segments alike (all of one tile class: observation
  * rows of <= 32 floats, or all wider) and advances them with ONE launch. */
 #define BSX_FAM_SMALL_MIXED 9
+#define BSX_FAM_PAIR_MIXED 10  /* segments of deep_sea, catch and mnist together: ONE advance launch + ONE
+                                  observation-stream launch for all of them (bsx_group_set_deep_sea /
+                                  _catch / _mnist accept such a group); csrc/pair_mixed.hip */
 int bsx_group_create(int32_t family, int32_t n_segments, bsx_group_t** group);
 int bsx_group_set_deep_sea(bsx_group_t* g, int32_t index, const bsx_deep_sea_t* cfg, const bsx_call_t* call,
                            const int32_t* action, int32_t* state, bsx_timestep_t out, double* info);
@@ -339,6 +342,9 @@ int bsx_group_set_mountain_car(bsx_group_t* g, int32_t index, const bsx_mountain
                                bsx_timestep_t out, double* info);
 int bsx_group_set_mnist(bsx_group_t* g, int32_t index, const bsx_mnist_t* cfg, const bsx_call_t* call,
                         const int32_t* action, int32_t* state, bsx_timestep_t out, double* info);
+/* Tile class (lanes per workgroup: 256 or 64) a small-observation segment with `numel` observation
+ * floats gets inside a group; segments of one group must share it (BSX_EINVAL otherwise). */
+int bsx_group_small_class(int32_t numel);
 int bsx_group_commit(bsx_group_t* g);
 int bsx_group_step(bsx_group_t* g, void* hip_stream);
 /* A group step in its phases, for callers that schedule them on several HIP streams (ABI v8): a

@@ -73,7 +73,7 @@ def test_sweep_rank_assignment_is_a_partition():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize('mode', ['eager', 'graph', 'graph_phased', 'per_family'])
+@pytest.mark.parametrize('mode', ['eager', 'streams', 'graph', 'graph_phased', 'per_family', 'pairs_per_family'])
 def test_grouped_sweep_equals_standalone_envs(tmp_path, mode):
   """One grouped launch per family advances every segment exactly like its standalone environment
   (eager on one stream, or as concurrent branches of one captured HIP graph)."""
@@ -88,21 +88,27 @@ def test_grouped_sweep_equals_standalone_envs(tmp_path, mode):
   total, seed, reps = len(ids) * 257 + 3, 77, 23
   batch = sb.SweepBatch(ids, total, seed=seed, env_kwargs=kw)
   acts = batch.random_actions(seed=2)
-  outs = batch.prepare_groups(acts, mix_small=(mode != 'per_family'))
+  outs = batch.prepare_groups(acts, mix_small=(mode != 'per_family'), mix_pairs=(mode not in ('per_family', 'pairs_per_family')))
   if mode == 'per_family':
     assert 9 <= len(batch._groups) <= 12         # families (+ wide-row classes), not segments
-  else:
+  elif mode == 'pairs_per_family':
     assert len(batch._groups) == 5               # deep_sea, catch, mnist + two mixed tile classes
-  if mode in ('graph', 'graph_phased'):
+  else:
+    assert len(batch._groups) == 3               # one mixed two-kernel group + two mixed tile classes
+  if mode in ('graph', 'graph_phased', 'pairs_per_family'):
     # runs sweep step 0 eagerly, captures one step; phased: advance kernels + small groups on one
     # branch, every observation stream kernel on another as soon as its advance kernel is done
-    assert batch.capture_grouped(num_streams=4 if mode == 'graph' else 2, phased=(mode == 'graph_phased')) is outs
+    assert batch.capture_grouped(num_streams=4 if mode == 'graph' else 2, phased=(mode != 'graph')) is outs
     for _ in range(reps - 1):
       batch.replay_grouped()
+  elif mode == 'streams':                        # eager on the batch's two HIP streams
+    for _ in range(reps):
+      batch.step_grouped_streams()
+    batch.join_streams()
   else:
     for _ in range(reps):
       batch.step_grouped()
-  torch.cuda.synchronize()
+  batch.sync()
   assert all(eu.raw(e).step_index == reps for e in batch.envs)
   for (bid, begin, lanes), a, out, env in zip(batch.segments, acts, outs, batch.envs):
     name = bid.split('/')[0]

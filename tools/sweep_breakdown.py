@@ -39,7 +39,7 @@ def main():
   subsets['small families together'] = [b for b in sweep.SWEEP if b.split('/')[0] not in big]
   for n in names:
     subsets[n] = [b for b in sweep.SWEEP if b.split('/')[0] == n]
-  for label, ids in subsets.items():
+  for label, ids in list(subsets.items())[:int(os.environ.get("BSX_BREAKDOWN_N", "99"))]:
     batch = sb.SweepBatch(ids, per * len(ids), device='cuda:0', seed=42,
                           env_kwargs=dict(mnist=mn, mnist_noise=mn, mnist_scale=mn))
     acts = batch.random_actions(seed=1)
