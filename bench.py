@@ -435,11 +435,12 @@ class Rank:
                           num_streams=int(os.environ.get('BSX_SWEEP_STREAMS', '32')),
                           env_kwargs=dict(mnist=mn, mnist_noise=mn, mnist_scale=mn))
     acts = batch.random_actions(seed=1)          # keyed by segment: independent of the rank assignment
-    mode = os.environ.get('BSX_SWEEP_MODE', 'grouped_streams')
+    mode = os.environ.get('BSX_SWEEP_MODE', 'grouped')
     grouped = mode in ('grouped', 'grouped_graph', 'grouped_streams')
     if grouped:
       batch.prepare_groups(acts, mix_small=os.environ.get('BSX_SWEEP_MIX_SMALL', '1') != '0',
-                           mix_pairs=os.environ.get('BSX_SWEEP_MIX_PAIRS', '1') != '0')
+                           mix_pairs=os.environ.get('BSX_SWEEP_MIX_PAIRS', '1') != '0',
+                           mix_all=os.environ.get('BSX_SWEEP_MIX_ALL', '1') != '0')
       if mode == 'grouped_graph':              # group launches as concurrent branches of one HIP graph
         batch.capture_grouped(int(os.environ.get('BSX_SWEEP_STREAMS', '2')),
                               phased=os.environ.get('BSX_SWEEP_PHASED', '1') != '0')
@@ -482,6 +483,8 @@ class Rank:
                      'algorithmic_bytes_per_launch': max_rank_bytes,
                      'algorithmic_bytes_all_ranks': total_bytes},
         'launch': (f'{len(batch._groups)} grouped launches per sweep step ({len(batch.envs)} segments on rank 0)'
+                   + (' (whole-sweep group: phase 0 advances every lane and bumps the call counter, phase 1 is the '
+                      'observation store stream)' if len(batch._groups) == 1 else '')
                    + (' as concurrent branches of one HIP graph' if mode == 'grouped_graph' else
                       ' on two HIP streams (advance -> store stream | small groups + counter bump)' if mode == 'grouped_streams'
                       else '') if grouped else

@@ -197,7 +197,7 @@ for _fam in ('deep_sea', 'catch', 'bandit', 'memory_chain', 'umbrella_chain', 'd
   _step_args, _ = _SIGS[f'bsx_{_fam}_step']
   _SIGS[f'bsx_group_set_{_fam}'] = ([_G, ctypes.c_int32] + list(_step_args), ctypes.c_int)
 FAMILY_IDS = dict(deep_sea=0, catch=1, bandit=2, memory_chain=3, umbrella_chain=4, discounting_chain=5,
-                  cartpole=6, mountain_car=7, mnist=8, small_mixed=9, pair_mixed=10)
+                  cartpole=6, mountain_car=7, mnist=8, small_mixed=9, pair_mixed=10, sweep_mixed=11)
 EXPORTED = tuple(sorted(_SIGS))
 MISSING = []
 for _name, (_args, _res) in _SIGS.items():

@@ -148,6 +148,8 @@ struct bsx_group {
   std::vector<uint8_t> is_set;
   std::vector<int32_t> tags;            // BSX_FAM_PAIR_MIXED: family of each segment (empty otherwise)
   int32_t* d_tags = nullptr;
+  uint64_t* shared_counter = nullptr;   // BSX_FAM_SWEEP_MIXED: the call counter every segment reads; phase 0 bumps it
+  uint32_t* d_ticket = nullptr;         //   ... when its last workgroup retires (device word, zero between launches)
   size_t lds_bytes = 0;                 // max dynamic LDS over segments (kernel 1)
   void* d_args = nullptr;
   void* d_args2 = nullptr;

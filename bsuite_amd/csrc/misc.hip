@@ -79,7 +79,7 @@ extern "C" int bsx_stream_dump(uint64_t seed, uint64_t lane0, int64_t n_lanes, u
 // ------------------------------------------------------------------------------ grouped launch
 extern "C" int bsx_group_create(int32_t family, int32_t n_segments, bsx_group_t** group) {
   if (group == nullptr) return BSX_ENULL;
-  if (family < BSX_FAM_DEEP_SEA || family > BSX_FAM_PAIR_MIXED || n_segments < 1 || n_segments > (1 << 20)) return BSX_EINVAL;
+  if (family < BSX_FAM_DEEP_SEA || family > BSX_FAM_SWEEP_MIXED || n_segments < 1 || n_segments > (1 << 20)) return BSX_EINVAL;
   bsx_group* g = nullptr;
   try {                                   // no C++ exception may cross the C boundary
     g = new bsx_group();
@@ -95,7 +95,7 @@ extern "C" int bsx_group_create(int32_t family, int32_t n_segments, bsx_group_t*
 
 static void group_free_device(bsx_group* g) {
   void** ptrs[] = {&g->d_args, &g->d_args2, (void**)&g->d_start, (void**)&g->d_start2, (void**)&g->d_map, (void**)&g->d_map2,
-                   (void**)&g->d_tags};
+                   (void**)&g->d_tags, (void**)&g->d_ticket};
   for (void** p : ptrs) {
     if (*p) (void)hipFree(*p);
     *p = nullptr;
@@ -138,6 +138,10 @@ static int group_commit(bsx_group* g) {
   int rc = upload(g->args.data(), g->args.size(), &g->d_args);
   if (rc == 0) rc = upload(g->args2.data(), g->args2.size(), &g->d_args2);
   if (rc == 0 && !g->tags.empty()) rc = upload(g->tags.data(), g->tags.size() * 4, (void**)&g->d_tags);
+  if (rc == 0 && g->family == BSX_FAM_SWEEP_MIXED) {   // two-level retirement ticket: word 0 + 64 shards, one line each
+    const std::vector<uint32_t> zeros(32 * 65, 0u);
+    rc = upload(zeros.data(), zeros.size() * 4, (void**)&g->d_ticket);
+  }
   if (rc == 0) rc = upload(start.data(), start.size() * 4, (void**)&g->d_start);
   if (rc == 0) rc = upload(start2.data(), start2.size() * 4, (void**)&g->d_start2);
   // (segment, local block) of every workgroup: one load per workgroup instead of a binary search;

@@ -1,14 +1,31 @@
-// pair_mixed.h — host interface of the mixed two-kernel group (BSX_FAM_PAIR_MIXED, pair_mixed.hip).
+// pair_mixed.h — host interface of the mixed groups of a heterogeneous sweep:
+//   BSX_FAM_PAIR_MIXED   deep_sea + catch + mnist segments (pair_mixed.hip): one advance launch, one stream launch
+//   BSX_FAM_SWEEP_MIXED  segments of ALL families: phase 0 = every lane of the sweep advanced by ONE launch
+//                        (small_obs.hip, sweep_phase0_kernel), phase 1 = the store stream of pair_mixed.hip
 #ifndef BSX_PAIR_MIXED_H_
 #define BSX_PAIR_MIXED_H_
 
 #include "bsx_host.h"
 
-// Records one segment of deep_sea / catch / mnist in a BSX_FAM_PAIR_MIXED group: `adv` is the family's
-// advance-kernel argument struct, `str` its observation-stream argument struct (both copied verbatim
-// into fixed-stride slots of the group's device tables), blocks1 / blocks2 their workgroup counts.
-int bsx_pair_mixed_put(bsx_group* g, int32_t family, int32_t index, const bsx_call_t* call,
-                       const void* adv, size_t adv_size, const void* str, size_t str_size,
-                       uint64_t blocks1, uint64_t blocks2);
+#define BSX_MIXED_ADV_STRIDE 1024      // phase-0 argument slot (advance args of a pair family, or a small family's args)
+#define BSX_MIXED_STR_STRIDE 1280      // phase-1 argument slot (observation stream args of a pair family)
+#define BSX_MIXED_TAG_LPB64 0x100      // tag = family | this bit: small-observation segment with 64-lane tiles
+
+// Records one segment in a BSX_FAM_PAIR_MIXED / BSX_FAM_SWEEP_MIXED group.  `adv`: the segment's phase-0
+// argument struct; `str`: its observation-stream argument struct (NULL for the small-observation families,
+// which have no phase 1); both are copied verbatim into fixed-stride slots of the group's device tables.
+// `lpb`: 256 or 64 lanes per phase-0 workgroup; `lds`: dynamic LDS the segment's phase-0 workgroups need.
+int bsx_mixed_put(bsx_group* g, int32_t family, int32_t lpb, int32_t index, const bsx_call_t* call,
+                  const void* adv, size_t adv_size, const void* str, size_t str_size,
+                  uint64_t blocks1, uint64_t blocks2, size_t lds);
+
+// launch of the mixed observation stream kernel (pair_mixed.hip) over a group's phase-1 tables
+int bsx_mixed_launch_stream(bsx_group* g, hipStream_t st);
+// phase 0 of a BSX_FAM_SWEEP_MIXED group (small_obs.hip)
+int bsx_sweep_launch_phase0(bsx_group* g, hipStream_t st);
+
+static inline bool bsx_is_mixed_pair_group(const bsx_group* g) {
+  return g->family == BSX_FAM_PAIR_MIXED || g->family == BSX_FAM_SWEEP_MIXED;
+}
 
 #endif  // BSX_PAIR_MIXED_H_

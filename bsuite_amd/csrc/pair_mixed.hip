@@ -16,8 +16,8 @@
 #include "mnist_fam.h"
 #include "pair_mixed.h"
 
-#define PAIR_ADV_STRIDE 1024
-#define PAIR_STR_STRIDE 1280
+#define PAIR_ADV_STRIDE BSX_MIXED_ADV_STRIDE
+#define PAIR_STR_STRIDE BSX_MIXED_STR_STRIDE
 #define PAIR_MNIST_K 8
 
 static_assert(sizeof(deep_sea_fam::args) <= PAIR_ADV_STRIDE && sizeof(catch_fam::args) <= PAIR_ADV_STRIDE &&
@@ -33,7 +33,7 @@ __global__ void __launch_bounds__(BSX_BLOCK) pair_mixed_advance_kernel(const uin
   __shared__ unsigned int s_cnt[2];
   const bsx_group_slot w = bsx_group_find(gi, (int)blockIdx.x);
   const uint8_t* slot = table + (size_t)w.seg * PAIR_ADV_STRIDE;
-  switch (family[w.seg]) {                          // uniform per workgroup
+  switch (family[w.seg] & 0xFF) {                   // uniform per workgroup
     case BSX_FAM_DEEP_SEA: bsx_advance_body<deep_sea_fam>(*reinterpret_cast<const deep_sea_fam::args*>(slot), w.block, s_ds, s_cnt); break;
     case BSX_FAM_CATCH: bsx_advance_body<catch_fam>(*reinterpret_cast<const catch_fam::args*>(slot), w.block, s_ca, s_cnt); break;
     case BSX_FAM_MNIST: mnist_advance_body(*reinterpret_cast<const mnist_args*>(slot), w.block, s_cnt); break;
@@ -47,7 +47,7 @@ __global__ void __launch_bounds__(BSX_BLOCK) pair_mixed_stream_kernel(const uint
   __shared__ float s_lut[256];
   const bsx_group_slot w = bsx_group_find(gi, (int)blockIdx.x);
   const uint8_t* slot = table + (size_t)w.seg * PAIR_STR_STRIDE;
-  switch (family[w.seg]) {
+  switch (family[w.seg] & 0xFF) {
     case BSX_FAM_DEEP_SEA: {
       const bsx_stream_seg<deep_sea_hot>& g = *reinterpret_cast<const bsx_stream_seg<deep_sea_hot>*>(slot);
       bsx_hot_stream_body<deep_sea_hot, 4, BSX_BLOCK>(g.obs, g.state, g.n_lanes, g.cells, g.cells_magic, g.dv, g.fn, w.block);
@@ -65,30 +65,51 @@ __global__ void __launch_bounds__(BSX_BLOCK) pair_mixed_stream_kernel(const uint
   }
 }
 
-static int pair_mixed_launch(bsx_group* g, int phase, hipStream_t st) {
-  if (phase != 1)
-    pair_mixed_advance_kernel<<<dim3((unsigned)g->total_blocks), dim3(BSX_BLOCK), 0, st>>>(
-        (const uint8_t*)g->d_args, g->d_tags, g->index1());
-  if (phase != 0)
+int bsx_mixed_launch_stream(bsx_group* g, hipStream_t st) {
+  if (g->total_blocks2 > 0)
     pair_mixed_stream_kernel<<<dim3((unsigned)g->total_blocks2), dim3(BSX_BLOCK), 0, st>>>(
         (const uint8_t*)g->d_args2, g->d_tags, g->index2());
   return (int)hipGetLastError();
 }
 
-int bsx_pair_mixed_put(bsx_group* g, int32_t family, int32_t index, const bsx_call_t* call,
-                       const void* adv, size_t adv_size, const void* str, size_t str_size,
-                       uint64_t blocks1, uint64_t blocks2) {
+static int pair_mixed_launch(bsx_group* g, int phase, hipStream_t st) {
+  if (phase != 1)
+    pair_mixed_advance_kernel<<<dim3((unsigned)g->total_blocks), dim3(BSX_BLOCK), 0, st>>>(
+        (const uint8_t*)g->d_args, g->d_tags, g->index1());
+  if (phase != 0) return bsx_mixed_launch_stream(g, st);
+  return (int)hipGetLastError();
+}
+
+// BSX_FAM_SWEEP_MIXED: phase 0 advances every lane of every family (and bumps the shared call counter
+// itself, see small_obs.hip), phase 1 is the same store stream.
+static int sweep_mixed_launch(bsx_group* g, int phase, hipStream_t st) {
+  int rc = 0;
+  if (phase != 1) rc = bsx_sweep_launch_phase0(g, st);
+  if (rc == 0 && phase != 0) rc = bsx_mixed_launch_stream(g, st);
+  return rc;
+}
+
+int bsx_mixed_put(bsx_group* g, int32_t family, int32_t lpb, int32_t index, const bsx_call_t* call,
+                  const void* adv, size_t adv_size, const void* str, size_t str_size,
+                  uint64_t blocks1, uint64_t blocks2, size_t lds) {
+  if (g == nullptr || !bsx_is_mixed_pair_group(g)) return BSX_EINVAL;
   if (adv_size > PAIR_ADV_STRIDE || str_size > PAIR_STR_STRIDE) return BSX_EINVAL;
-  int rc = bsx_group_check_set(g, BSX_FAM_PAIR_MIXED, index, call, PAIR_ADV_STRIDE, PAIR_STR_STRIDE, 0);
+  if (g->family == BSX_FAM_PAIR_MIXED && str == nullptr) return BSX_EINVAL;   // small families: sweep groups only
+  int rc = bsx_group_check_set(g, g->family, index, call, PAIR_ADV_STRIDE, PAIR_STR_STRIDE, 0);
   if (rc != 0) return rc;
   if (blocks1 > 0x3FFFFFFFull || blocks2 > 0x3FFFFFFFull) return BSX_EINVAL;
+  if (g->family == BSX_FAM_SWEEP_MIXED) {           // the group bumps ONE call counter: all segments must share it
+    if (g->shared_counter == nullptr) g->shared_counter = const_cast<uint64_t*>(call->stream.step_base);
+    else if (g->shared_counter != call->stream.step_base) return BSX_EINVAL;
+  }
   memcpy(&g->args[(size_t)index * PAIR_ADV_STRIDE], adv, adv_size);
-  memcpy(&g->args2[(size_t)index * PAIR_STR_STRIDE], str, str_size);
+  if (str != nullptr) memcpy(&g->args2[(size_t)index * PAIR_STR_STRIDE], str, str_size);
   if (g->tags.empty()) g->tags.assign((size_t)g->n, -1);
-  g->tags[index] = family;
+  g->tags[index] = family | (lpb == 64 ? BSX_MIXED_TAG_LPB64 : 0);
   g->blocks[index] = (int32_t)blocks1; g->blocks2[index] = (int32_t)blocks2;
+  if (lds > g->lds_bytes) g->lds_bytes = lds;
   g->is_set[index] = 1;
-  g->launch = pair_mixed_launch;
+  g->launch = g->family == BSX_FAM_SWEEP_MIXED ? sweep_mixed_launch : pair_mixed_launch;
   g->n_phases = 2;
   return 0;
 }

@@ -16,6 +16,10 @@
 // reference forms them and cast once.
 #include "bsx_host.h"
 #include "bsx_math.h"
+#include "catch_fam.h"
+#include "deep_sea_fam.h"
+#include "mnist_fam.h"
+#include "pair_mixed.h"
 
 // n_steps == 1 is env.step()/reset(); n_steps = T > 1 is the fused rollout: the same thread advances
 // its lane T times inside one launch (actions [T,B], outputs [T,B,...]); per-lane state columns are
@@ -116,6 +120,10 @@ static int small_obs_group_put(bsx_group* g, int32_t family, int32_t index, cons
                                const typename Env::args& a, int numel) {
   static_assert(sizeof(typename Env::args) <= SMALL_MIXED_STRIDE, "argument struct exceeds the mixed-group slot");
   const int lpb = bsx_group_small_class(numel);
+  if (g != nullptr && g->family == BSX_FAM_SWEEP_MIXED) {     // one segment of the whole-sweep group: phase 0 only
+    const uint64_t nb = (uint64_t)(a.ctl.n_lanes + lpb - 1) / lpb;
+    return bsx_mixed_put(g, family, lpb, index, call, &a, sizeof(a), nullptr, 0, nb, 0, (size_t)lpb * numel * 4);
+  }
   const bool mixed = g != nullptr && g->family == BSX_FAM_SMALL_MIXED;
   int rc = bsx_group_check_set(g, mixed ? BSX_FAM_SMALL_MIXED : family, index, call,
                                mixed ? SMALL_MIXED_STRIDE : sizeof(typename Env::args), mixed ? sizeof(int32_t) : 0, lpb);
@@ -699,5 +707,71 @@ static int small_obs_mixed_launch(bsx_group* g, int phase, hipStream_t st) {
   const int32_t* family = (const int32_t*)g->d_args2;
   if (g->klass == 256) small_obs_mixed_group_kernel<256><<<grid, block, g->lds_bytes, st>>>(table, family, g->index1());
   else small_obs_mixed_group_kernel<64><<<grid, block, g->lds_bytes, st>>>(table, family, g->index1());
+  return (int)hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------ whole-sweep group, phase 0
+// BSX_FAM_SWEEP_MIXED: ONE launch advances every lane of a heterogeneous sweep — the lane-advance of
+// deep_sea / catch / mnist segments (whose observation stream follows as phase 1, pair_mixed.hip) and the
+// complete step of every small-observation segment.  All of this is latency-bound work that moves a
+// few percent of the sweep's bytes; as separate launches (advance, 256-lane small groups, 64-lane small
+// groups, counter bump) it cost ~45 us of a ~185 us sweep step whether serialised or spread over HIP
+// streams (cross-queue waits cost ~10 us each; kernels sharing the machine with the store stream
+// stretch it: profiles/r02/ab_sweep_*.log, sweep_*_timeline*.txt).  The last workgroup to retire bumps
+// the call counter the segments share, so no other kernel has to.
+__global__ void __launch_bounds__(BSX_BLOCK) sweep_phase0_kernel(const uint8_t* __restrict__ table,
+                                                                 const int32_t* __restrict__ tags,
+                                                                 const bsx_group_index gi,
+                                                                 uint64_t* counter, uint32_t* ticket) {
+  extern __shared__ __attribute__((aligned(16))) float s_obs[];
+  __shared__ unsigned int s_cnt[2];
+  __shared__ deep_sea_fam::shared s_ds;
+  __shared__ catch_fam::shared s_ca;
+  const bsx_group_slot w = bsx_group_find(gi, (int)blockIdx.x);
+  const int tag = tags[w.seg];                       // uniform per workgroup
+  const uint32_t blk = w.block;
+  const uint8_t* slot = table + (size_t)w.seg * BSX_MIXED_ADV_STRIDE;
+#define SWEEP_SMALL_CASE(FAM, ENV)                                                                              \
+  case FAM:                                                                                                     \
+    if (tag & BSX_MIXED_TAG_LPB64) small_obs_body<ENV, 64, false, -1, -1, -1>(*reinterpret_cast<const ENV::args*>(slot), 1, blk, s_obs, s_cnt); \
+    else small_obs_body<ENV, 256, false, -1, -1, -1>(*reinterpret_cast<const ENV::args*>(slot), 1, blk, s_obs, s_cnt);                          \
+    break;
+  switch (tag & 0xFF) {
+    case BSX_FAM_DEEP_SEA: bsx_advance_body<deep_sea_fam>(*reinterpret_cast<const deep_sea_fam::args*>(slot), blk, s_ds, s_cnt); break;
+    case BSX_FAM_CATCH: bsx_advance_body<catch_fam>(*reinterpret_cast<const catch_fam::args*>(slot), blk, s_ca, s_cnt); break;
+    case BSX_FAM_MNIST: mnist_advance_body(*reinterpret_cast<const mnist_args*>(slot), blk, s_cnt); break;
+    SWEEP_SMALL_CASE(BSX_FAM_BANDIT, bandit_env)
+    SWEEP_SMALL_CASE(BSX_FAM_MEMORY_CHAIN, memory_chain_env)
+    SWEEP_SMALL_CASE(BSX_FAM_UMBRELLA_CHAIN, umbrella_chain_env)
+    SWEEP_SMALL_CASE(BSX_FAM_DISCOUNTING_CHAIN, discounting_chain_env)
+    SWEEP_SMALL_CASE(BSX_FAM_CARTPOLE, cartpole_env)
+    SWEEP_SMALL_CASE(BSX_FAM_MOUNTAIN_CAR, mountain_car_env)
+    default: break;
+  }
+#undef SWEEP_SMALL_CASE
+  // Every workgroup read the call counter when it started; the one that retires last moves it on.
+  // Two-level ticket (64 shards, one 128-byte line each, then one word): several thousand arrivals on ONE
+  // word would serialise at ~12 ns each (the lesson of the episode counters, bsx_device.h).
+  __syncthreads();
+  // (No fence: a workgroup's reads of the counter completed before its barrier, and a release fence here
+  // would write back this XCD's whole L2 once per workgroup — measured 165 us instead of 25.)
+  if (threadIdx.x == 0 && counter != nullptr) {
+    const uint32_t shard = blockIdx.x & 63u;
+    const uint32_t in_shard = (gridDim.x - shard + 63u) >> 6;            // workgroups with this shard id
+    uint32_t* word = ticket + 32u * (shard + 1u);
+    if (atomicAdd(word, 1u) == in_shard - 1u) {
+      *word = 0u;
+      const uint32_t live_shards = gridDim.x < 64u ? gridDim.x : 64u;
+      if (atomicAdd(ticket, 1u) == live_shards - 1u) {
+        *ticket = 0u;
+        *counter += 1ull;
+      }
+    }
+  }
+}
+
+int bsx_sweep_launch_phase0(bsx_group* g, hipStream_t st) {
+  sweep_phase0_kernel<<<dim3((unsigned)g->total_blocks), dim3(BSX_BLOCK), g->lds_bytes, st>>>(
+      (const uint8_t*)g->d_args, g->d_tags, g->index1(), g->shared_counter, g->d_ticket);
   return (int)hipGetLastError();
 }

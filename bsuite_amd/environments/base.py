@@ -57,7 +57,7 @@ class Environment(dm_env.EnvironmentBase):
 
   def __init__(self, obs_shape, num_actions, *, seed=None, batch=None, device=None,
                lane_offset=0, num_buffers=2, device_step_counter=False, shared_step_counter=None,
-               rng='philox', observation_mode='dense'):
+               rng='philox', observation_mode='dense', obs_allocator=None):
     self._scalar = batch is None
     self._batch = 1 if batch is None else int(batch)
     if self._batch < 1:
@@ -77,6 +77,9 @@ class Environment(dm_env.EnvironmentBase):
     # shared_step_counter: an int64[1] device tensor owned by the caller (e.g. SweepBatch) who bumps
     # it once per sweep step for all its segments instead of one bump kernel per environment.
     self._shared_step_counter = shared_step_counter
+    # obs_allocator(shape) -> float32 device tensor: lets a caller that owns many environments (SweepBatch)
+    # place all their observation buffers in one arena, in launch order, each on a 4 KiB boundary.
+    self._obs_allocator = obs_allocator
     # rng='mt19937': every lane carries the reference's own generator (np.random.RandomState(seed),
     # MT19937 + numpy's legacy samplers) in HBM, so seeded runs reproduce the reference without any
     # replay shim.  `seed` may be a sequence of B seeds; an int s seeds lane i with
@@ -259,8 +262,9 @@ class Environment(dm_env.EnvironmentBase):
             reward=torch.empty(B, dtype=torch.float32, **place),
             discount=torch.empty(B, dtype=torch.float32, **place),
             step_type=torch.empty(B, dtype=torch.int8, **place),
-            observation=(torch.zeros if self._delta else torch.empty)(
-                (B,) + self._obs_shape, dtype=torch.float32, **place))
+            observation=(self._obs_allocator((B,) + self._obs_shape)
+                         if (self._obs_allocator is not None and not self._scalar and not self._delta) else
+                         (torch.zeros if self._delta else torch.empty)((B,) + self._obs_shape, dtype=torch.float32, **place)))
         self._out.append(o)
         self._out_ptrs.append(_native.TimeStepPtrs(
             o['reward'].data_ptr(), o['discount'].data_ptr(), o['step_type'].data_ptr(),

@@ -70,16 +70,25 @@ class SweepBatch:
     self.device = torch.device('cuda:0' if device is None else device)
     env_kwargs = env_kwargs or {}
     probe = []
+    self._numel = []
     for bid, _, lanes in self.table:
       name = bid.split(_sweep.SEPARATOR)[0]
       kw = dict(env_kwargs.get(name, {}))
       env = bsuite_amd.load_from_id(bid, **kw)      # host-only construction: specs for the cost model
-      probe.append(lanes * bytes_per_step(int(np.prod(env.observation_spec().shape))))
+      self._numel.append(int(np.prod(env.observation_spec().shape)))
+      probe.append(lanes * bytes_per_step(self._numel[-1]))
     self.rank_of = assign_segments(probe, world_size)
     self.local = [i for i, r in enumerate(self.rank_of) if r == rank]
     self.envs, self.segments = [], []
     # one device-resident call counter for the whole sweep: bumped once per sweep step
     self._step_counter = torch.zeros(1, dtype=torch.int64, device=self.device)
+    # One arena for every segment's observation buffer, in segment order, each on a 4 KiB boundary: the
+    # grouped store-stream kernels then walk one ascending address range in whole 4 KiB runs, like the
+    # single-environment kernels do, instead of several hundred separately placed allocations.
+    self._arena = None
+    self._arena_used = 0
+    self._arena_floats = sum((self.table[i][2] * p_numel + 1023) // 1024 * 1024
+                             for i, p_numel in ((i, self._numel[i]) for i in self.local))
     for i in self.local:
       bid, begin, lanes = self.table[i]
       name = bid.split(_sweep.SEPARATOR)[0]
@@ -90,7 +99,8 @@ class SweepBatch:
       elif 'seed' not in settings:
         kw.setdefault('seed', seed)
       env = bsuite_amd.load_from_id(bid, batch=lanes, device=self.device, lane_offset=begin,
-                                    num_buffers=1, shared_step_counter=self._step_counter, **kw)
+                                    num_buffers=1, shared_step_counter=self._step_counter,
+                                    obs_allocator=self._alloc_obs, **kw)
       self.envs.append(env)
       self.segments.append((bid, begin, lanes))
     self.num_streams = max(1, int(num_streams))
@@ -102,6 +112,17 @@ class SweepBatch:
     self._pipe = None                          # step_grouped_streams(): the two HIP streams + their events
     self._small = None
     self._pending_steps = 0
+
+  def _alloc_obs(self, shape):
+    n = int(np.prod(shape))
+    if self._arena is None:
+      self._arena = torch.empty(self._arena_floats + 1024, dtype=torch.float32, device=self.device)
+      self._arena_used = (-self._arena.data_ptr() // 4) % 1024            # first 4 KiB boundary
+    begin = self._arena_used
+    if begin + n > self._arena.numel():
+      return torch.empty(shape, dtype=torch.float32, device=self.device)  # (never in practice) plain allocation
+    self._arena_used = begin + (n + 1023) // 1024 * 1024
+    return self._arena[begin:begin + n].view(shape)
 
   # ---------------------------------------------------------------------------------------
   def random_actions(self, seed: int = 0) -> List[torch.Tensor]:
@@ -116,7 +137,9 @@ class SweepBatch:
                                dtype=torch.int32))
     return out
 
-  def _bump(self):
+  def _bump(self, grouped: bool = False):
+    if grouped and getattr(self, '_self_bump', False):
+      return                                 # BSX_FAM_SWEEP_MIXED: phase 0 bumps the counter when its last workgroup retires
     from bsuite_amd import _native  # pylint: disable=import-outside-toplevel
     _native.check(_native.lib.bsx_counter_add(self._step_counter.data_ptr(), 1,
                                               torch.cuda.current_stream(self.device).cuda_stream),
@@ -130,8 +153,13 @@ class SweepBatch:
     return outs
 
   # -- grouped launches --------------------------------------------------------------------
-  def prepare_groups(self, actions: Sequence[torch.Tensor], mix_small: bool = True, mix_pairs: bool = True):
-    """Builds the launch groups.  With `mix_pairs` (default) ONE mixed group for the two-kernel families
+  def prepare_groups(self, actions: Sequence[torch.Tensor], mix_small: bool = True, mix_pairs: bool = True,
+                     mix_all: bool = True):
+    """Builds the launch groups.  With `mix_all` (default) ONE group for the whole sweep
+    (BSX_FAM_SWEEP_MIXED): a sweep step is two launches — phase 0 advances every lane of every family
+    and bumps the shared call counter, phase 1 is the observation store stream of the two-kernel
+    families — and `step_grouped()` needs nothing else.  Otherwise (A/B, and what the ABI offers
+    piecewise): with `mix_pairs` ONE mixed group for the two-kernel families
     deep_sea, catch and mnist together (BSX_FAM_PAIR_MIXED: one advance launch + one observation-stream
     launch for all their segments), else one group per family; with `mix_small` ONE mixed group per
     tile class for all small-observation families together (BSX_FAM_SMALL_MIXED), else one per
@@ -150,8 +178,10 @@ class SweepBatch:
       numel = int(np.prod(raw.observation_spec().shape))
       small = raw._abi_name not in ('deep_sea', 'catch', 'mnist')  # pylint: disable=protected-access
       klass = _native.lib.bsx_group_small_class(numel) if small else 0
-      group_family = ('small_mixed' if (small and mix_small) else
+      group_family = ('sweep_mixed' if mix_all else 'small_mixed' if (small and mix_small) else
                       'pair_mixed' if (not small and mix_pairs) else raw._abi_name)  # pylint: disable=protected-access
+      if mix_all:
+        klass = 0
       buckets.setdefault((group_family, klass), []).append(k)
     outs = [None] * len(self.envs)
     costs = []
@@ -171,6 +201,7 @@ class SweepBatch:
                        for k in members))
     order = sorted(range(len(costs)), key=lambda j: -costs[j])
     self._groups_by_cost = [self._groups[j] for j in order]     # heaviest store streams first
+    self._self_bump = mix_all                 # a whole-sweep group moves the call counter on by itself
     self._group_actions = list(actions)      # keep the static action tensors alive
     self._group_outs = outs
     return outs
@@ -183,57 +214,73 @@ class SweepBatch:
       rc = _native.lib.bsx_group_step(handle, stream)
       if rc != 0:
         _native.check(rc, 'bsx_group_step')
-    self._bump()
+    self._bump(grouped=True)
     self._pending_steps += 1                   # host-side call index: settled lazily (flush_step_indices)
     return self._group_outs
 
   # -- eager two-stream schedule ----------------------------------------------------------
   def step_grouped_streams(self):
-    """One sweep step, eager, on two HIP streams owned by the batch (no graph): the `pipe` stream runs
-    the advance kernel(s) of the two-kernel families followed by their observation stream kernel(s);
-    the `small` stream runs the small-observation groups beside them and bumps the shared call counter
-    as soon as the advance and small kernels — its only readers — are done.  Consecutive kernels of a
-    stream start within a few microseconds of each other, where dependent nodes of a captured HIP graph
-    start 6-14 us apart and consecutive graph launches ~20 us apart on this stack
-    (profiles/r02/sweep_graph_timeline_*.txt): for a step of ~165 us that is the difference.  Call
-    `join_streams()` before reading the outputs on the current stream."""
+    """One sweep step, eager, on HIP streams owned by the batch (no graph).  Two phases, separated by what
+    bounds the kernels:
+      1. everything latency-bound at once — the advance kernel of the two-kernel families on the `pipe`
+         stream, each small-observation group on a stream of its own;
+      2. the observation store stream (HBM-bound, ~96 % of the sweep's bytes) alone on the machine.
+    The shared call counter is bumped as soon as phase 1 — its only readers — is done, i.e. beside the
+    store stream.  (Schedules that let the small groups run beside the store stream measured slower and
+    bimodal: both kernels stretch, profiles/r02/sweep_streams_timeline_overlapped.txt; a captured HIP
+    graph starts dependent nodes 6-14 us apart and consecutive replays ~20 us apart,
+    profiles/r02/sweep_graph_timeline_*.txt.)  Call `join_streams()` before reading the outputs on
+    the current stream."""
     from bsuite_amd import _native  # pylint: disable=import-outside-toplevel
     if self._pipe is None:
       cur = torch.cuda.current_stream(self.device)
-      self._pipe, self._small = torch.cuda.Stream(device=self.device), torch.cuda.Stream(device=self.device)
-      self._ev_adv, self._ev_bump, self._ev_small = torch.cuda.Event(), torch.cuda.Event(), torch.cuda.Event()
-      import os  # pylint: disable=import-outside-toplevel
-      self._small_beside_advance = os.environ.get('BSX_SWEEP_SMALL_BESIDE', 'stream') == 'advance'
-      self._pipe.wait_stream(cur)
-      self._small.wait_stream(cur)
       self._pairs = [h for h in self._groups_by_cost if _native.lib.bsx_group_phases(h) == 2]
       self._singles = [h for h in self._groups_by_cost if _native.lib.bsx_group_phases(h) == 1]
+      self._pipe = torch.cuda.Stream(device=self.device)
+      self._smalls = [torch.cuda.Stream(device=self.device) for _ in self._singles] or [torch.cuda.Stream(device=self.device)]
+      self._small = self._smalls[0]
+      self._ev_adv, self._ev_bump, self._ev_stream = torch.cuda.Event(), torch.cuda.Event(), torch.cuda.Event()
+      self._ev_small = [torch.cuda.Event() for _ in self._smalls]
+      import os  # pylint: disable=import-outside-toplevel
+      self._small_beside_stream = os.environ.get('BSX_SWEEP_SMALL_BESIDE', 'advance') == 'stream'
+      for st in [self._pipe] + self._smalls:
+        st.wait_stream(cur)
+      first = True
     else:
-      self._pipe.wait_event(self._ev_bump)     # this step's kernels read the counter the last step bumped
-    pipe, small = self._pipe.cuda_stream, self._small.cuda_stream
+      first = False
     step_phase = _native.lib.bsx_group_step_phase
+    pipe = self._pipe.cuda_stream
+    if not first:
+      self._pipe.wait_event(self._ev_bump)     # this step's kernels read the counter the last step bumped
     for handle in self._pairs:
       rc = step_phase(handle, 0, pipe)
       if rc != 0:
         _native.check(rc, 'bsx_group_step_phase')
     self._ev_adv.record(self._pipe)
-    for handle in self._singles:
-      rc = step_phase(handle, 0, small)
+    for j, handle in enumerate(self._singles):
+      st = self._smalls[j]
+      if not first:
+        st.wait_event(self._ev_bump)
+        if not self._small_beside_stream:
+          st.wait_event(self._ev_stream)       # not beside the previous step's store stream
+      rc = step_phase(handle, 0, st.cuda_stream)
       if rc != 0:
         _native.check(rc, 'bsx_group_step_phase')
-    if self._small_beside_advance:
-      # A/B knob BSX_SWEEP_SMALL_BESIDE=advance: the store stream starts only when the small groups are
-      # done too (everything latency-bound overlaps, then the HBM-bound stream has the machine to
-      # itself) — measured 3-5 % slower than letting them run beside the stream
-      # (profiles/r02/ab_sweep_pair_mixed.log)
-      self._ev_small.record(self._small)
-      self._pipe.wait_event(self._ev_small)
+      self._ev_small[j].record(st)
+    if not self._small_beside_stream:
+      for j in range(len(self._singles)):
+        self._pipe.wait_event(self._ev_small[j])
     for handle in self._pairs:
       rc = step_phase(handle, 1, pipe)
       if rc != 0:
         _native.check(rc, 'bsx_group_step_phase')
+    self._ev_stream.record(self._pipe)
+    # the bump: after the advance kernel and every small group of this step
     self._small.wait_event(self._ev_adv)
-    _native.check(_native.lib.bsx_counter_add(self._step_counter.data_ptr(), 1, small), 'sweep step counter')
+    for j in range(1, len(self._singles)):
+      self._small.wait_event(self._ev_small[j])
+    if not self._self_bump:
+      _native.check(_native.lib.bsx_counter_add(self._step_counter.data_ptr(), 1, self._small.cuda_stream), 'sweep step counter')
     self._ev_bump.record(self._small)
     self._pending_steps += 1                   # host-side call index: settled lazily (flush_step_indices)
     return self._group_outs
@@ -260,7 +307,8 @@ class SweepBatch:
     if self._pipe is not None:
       cur = torch.cuda.current_stream(self.device)
       cur.wait_stream(self._pipe)
-      cur.wait_stream(self._small)
+      for st in self._smalls:
+        cur.wait_stream(st)
 
   def capture_grouped(self, num_streams: int = 2, phased: bool = True):
     """Captures one grouped sweep step as a HIP graph.
@@ -310,7 +358,7 @@ class SweepBatch:
           # states): bump it as soon as THOSE are done, beside the store streams, not after them.
           if small is not main:
             main.wait_stream(small)
-          self._bump()
+          self._bump(grouped=True)
           bumped = True
         else:
           lanes = [main] + side
@@ -320,7 +368,7 @@ class SweepBatch:
         for st in side:
           main.wait_stream(st)                 # join
         if not bumped:
-          self._bump()
+          self._bump(grouped=True)
     torch.cuda.current_stream(self.device).wait_stream(main)
     self._grouped_graph = graph
     self._grouped_streams = [main] + side

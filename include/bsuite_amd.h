@@ -318,6 +318,12 @@ typedef struct bsx_group bsx_group_t;
 #define BSX_FAM_PAIR_MIXED 10  /* segments of deep_sea, catch and mnist together: ONE advance launch + ONE
                                   observation-stream launch for all of them (bsx_group_set_deep_sea /
                                   _catch / _mnist accept such a group); csrc/pair_mixed.hip */
+#define BSX_FAM_SWEEP_MIXED 11 /* segments of ALL families (every bsx_group_set_<family> accepts such a group):
+                                  phase 0 advances every lane of the sweep in ONE launch — the advance of the
+                                  two-kernel families and the whole step of the small-observation families —
+                                  and, when its last workgroup retires, bumps the call counter itself (all
+                                  segments must share one stream.step_base; do NOT bsx_counter_add it);
+                                  phase 1 is the one observation store stream of BSX_FAM_PAIR_MIXED */
 int bsx_group_create(int32_t family, int32_t n_segments, bsx_group_t** group);
 int bsx_group_set_deep_sea(bsx_group_t* g, int32_t index, const bsx_deep_sea_t* cfg, const bsx_call_t* call,
                            const int32_t* action, int32_t* state, bsx_timestep_t out, double* info);

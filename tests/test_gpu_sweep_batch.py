@@ -73,7 +73,8 @@ def test_sweep_rank_assignment_is_a_partition():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize('mode', ['eager', 'streams', 'graph', 'graph_phased', 'per_family', 'pairs_per_family'])
+@pytest.mark.parametrize('mode', ['whole_sweep', 'whole_sweep_graph', 'eager', 'streams', 'graph', 'graph_phased', 'per_family',
+                                  'pairs_per_family'])
 def test_grouped_sweep_equals_standalone_envs(tmp_path, mode):
   """One grouped launch per family advances every segment exactly like its standalone environment
   (eager on one stream, or as concurrent branches of one captured HIP graph)."""
@@ -88,14 +89,17 @@ def test_grouped_sweep_equals_standalone_envs(tmp_path, mode):
   total, seed, reps = len(ids) * 257 + 3, 77, 23
   batch = sb.SweepBatch(ids, total, seed=seed, env_kwargs=kw)
   acts = batch.random_actions(seed=2)
-  outs = batch.prepare_groups(acts, mix_small=(mode != 'per_family'), mix_pairs=(mode not in ('per_family', 'pairs_per_family')))
-  if mode == 'per_family':
+  outs = batch.prepare_groups(acts, mix_small=(mode != 'per_family'), mix_pairs=(mode not in ('per_family', 'pairs_per_family')),
+                              mix_all=mode.startswith('whole_sweep'))
+  if mode.startswith('whole_sweep'):
+    assert len(batch._groups) == 1               # ONE group: two launches per sweep step, nothing else
+  elif mode == 'per_family':
     assert 9 <= len(batch._groups) <= 12         # families (+ wide-row classes), not segments
   elif mode == 'pairs_per_family':
     assert len(batch._groups) == 5               # deep_sea, catch, mnist + two mixed tile classes
   else:
     assert len(batch._groups) == 3               # one mixed two-kernel group + two mixed tile classes
-  if mode in ('graph', 'graph_phased', 'pairs_per_family'):
+  if mode in ('graph', 'graph_phased', 'pairs_per_family', 'whole_sweep_graph'):
     # runs sweep step 0 eagerly, captures one step; phased: advance kernels + small groups on one
     # branch, every observation stream kernel on another as soon as its advance kernel is done
     assert batch.capture_grouped(num_streams=4 if mode == 'graph' else 2, phased=(mode != 'graph')) is outs
