@@ -1,13 +1,14 @@
 #!/bin/bash
-# A/B inside one gpurun call: config-5 sweep step.
-#   per_family / mixed : one grouped launch per (family, tile class) vs the small families merged
-#   grouped / grouped_graph:N : serial launches vs N concurrent branches of one HIP graph
-#   map0 / map1 : workgroup -> segment by binary search vs by the per-workgroup map
-for rep in 1 2; do
-  for cfg in per_family:grouped:1:0 mixed:grouped:1:0 mixed:grouped:1:1 mixed:grouped_graph:2:0 mixed:grouped_graph:2:1 mixed:grouped_graph:3:1; do
-    IFS=: read mix m st map <<< "$cfg"
-    [ "$mix" = mixed ] && mx=1 || mx=0
-    BSX_GROUP_MAP=$map BSX_SWEEP_MIX_SMALL=$mx BSX_SWEEP_MODE=$m BSX_SWEEP_STREAMS=$st timeout 200 python bench.py --workload sweep --steps 200 --warmup 20 2>/dev/null | \
-      python -c "import sys,json; d=json.loads(sys.stdin.readlines()[-1]); print('$mix $m streams=$st map=$map', round(d['value']/1e9,3),'Gsteps/s', round(d['roofline']['kernel_ms'],4),'ms/sweep-step frac', round(d['roofline']['frac'],3))"
+# A/B inside one gpurun call (boxes differ by several percent): config-5 sweep step schedules.
+#   whole   BSX_FAM_SWEEP_MIXED: two launches per sweep step (phase 0 = every lane + counter bump, phase 1 = store stream)
+#   pairs   mixed two-kernel group + two mixed small groups, serial / two HIP streams / HIP graph
+#   r01     one group per two-kernel family + two mixed small groups as two branches of one HIP graph
+for rep in 1 2 3; do
+  for cfg in "whole 1 1 grouped 1" "whole_graph 1 1 grouped_graph 1" "pairs_serial 0 1 grouped 1" "pairs_streams 0 1 grouped_streams 1" \
+             "pairs_graph 0 1 grouped_graph 1" "r01_graph 0 0 grouped_graph 0"; do
+    set -- $cfg
+    BSX_SWEEP_MIX_ALL=$2 BSX_SWEEP_MIX_PAIRS=$3 BSX_SWEEP_MODE=$4 BSX_SWEEP_PHASED=$5 BSX_SWEEP_SMALL_BESIDE=stream \
+      timeout 200 python bench.py --workload sweep --steps 200 --warmup 20 2>/dev/null | \
+      python -c "import sys,json; d=json.loads(sys.stdin.readlines()[-1]); print('$1', round(d['value']/1e9,3),'Gsteps/s', round(d['roofline']['kernel_ms']*1e3,1),'us/sweep-step frac', round(d['roofline']['frac'],3))"
   done
 done
