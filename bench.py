@@ -248,9 +248,14 @@ class Rank:
     backend = os.environ.get('BSX_BENCH_BACKEND', 'nccl')
     if os.environ.get('BSX_BENCH_SINGLE_DEVICE'):
       local_rank = 0
-    if self.world > 1:
+    # BSX_BENCH_FORCE_PG=1: create the process group even for one rank, so that the RCCL code path (init,
+    # barrier, all-reduce, all-gather on device tensors) is exercised on a single-GPU box.
+    self.collective = self.world > 1 or bool(os.environ.get('BSX_BENCH_FORCE_PG'))
+    if self.collective:
       os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-      dist.init_process_group(backend)
+      if 'MASTER_PORT' not in os.environ:
+        os.environ['MASTER_PORT'] = str(_free_port())
+      dist.init_process_group(backend, rank=self.rank, world_size=self.world)
     if args.gpus != self.world:
       raise SystemExit(f'--gpus {args.gpus} but WORLD_SIZE={self.world}')
     torch.cuda.set_device(local_rank)
@@ -259,13 +264,13 @@ class Rank:
 
   def sync_all(self):
     self.torch.cuda.synchronize(self.dev)
-    if self.world > 1:
+    if self.collective:
       self.dist.barrier()
       self.torch.cuda.synchronize(self.dev)
 
   def reduce_times(self, *vals):
     """MAX over ranks of host-side floats."""
-    if self.world == 1:
+    if not self.collective:
       return vals
     t = self.torch.tensor(list(vals), dtype=self.torch.float64,
                           device=self.dev if self.dist.get_backend() == 'nccl' else 'cpu')
@@ -482,9 +487,10 @@ class Rank:
                      'frac': achieved / HBM_PEAK_GBPS, 'traffic': None, 'kernel_ms': step_ms,
                      'algorithmic_bytes_per_launch': max_rank_bytes,
                      'algorithmic_bytes_all_ranks': total_bytes},
-        'launch': (f'{len(batch._groups)} grouped launches per sweep step ({len(batch.envs)} segments on rank 0)'
-                   + (' (whole-sweep group: phase 0 advances every lane and bumps the call counter, phase 1 is the '
-                      'observation store stream)' if len(batch._groups) == 1 else '')
+        'launch': ((f'2 launches per sweep step ({len(batch.envs)} segments on rank 0 in one whole-sweep group: phase 0 '
+                    'advances every lane and bumps the call counter, phase 1 is the observation store stream)'
+                    if len(batch._groups) == 1 else
+                    f'{len(batch._groups)} grouped launches per sweep step ({len(batch.envs)} segments on rank 0)')
                    + (' as concurrent branches of one HIP graph' if mode == 'grouped_graph' else
                       ' on two HIP streams (advance -> store stream | small groups + counter bump)' if mode == 'grouped_streams'
                       else '') if grouped else
@@ -585,7 +591,7 @@ class Rank:
       print(json.dumps(line), flush=True)
 
   def close(self):
-    if self.world > 1:
+    if self.collective:
       self.dist.destroy_process_group()
 
 

@@ -139,3 +139,19 @@ def test_two_rank_real_summaries_equal_one_rank():
   assert red0 == red1 == ref_red and ref_red['lanes'] == 3000 and ref_red['episodes_finished'] > 0
   assert merged0 == merged1 == ref_merged
   assert keys0 and keys1 and sorted(keys0 + keys1) == sorted(IDS)
+
+
+@pytest.mark.timeout(600)
+def test_rccl_code_path_on_one_rank():
+  """backend nccl (= RCCL) with a one-rank process group: init, barrier, all-reduce of the timings and the
+  all-gather of the summaries run on device tensors exactly as they do with N ranks."""
+  env = dict(os.environ, BSX_BENCH_FORCE_PG='1')
+  env.pop('WORLD_SIZE', None)
+  p = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--no-cpu-baseline', '--no-also', '--workload', 'catch',
+                      '--lanes', '8192', '--steps', '32', '--warmup', '8'],
+                     env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=500)
+  assert p.returncode == 0, p.stderr[-3000:]
+  line = json.loads([l for l in p.stdout.splitlines() if l.startswith('{')][0])
+  plain = _bench('--no-also', '--workload', 'catch', '--lanes', '8192', '--steps', '32', '--warmup', '8')
+  assert line['episodes_finished'] == plain['episodes_finished'] > 0
+  assert line['bsuite_info_sums'] == plain['bsuite_info_sums']

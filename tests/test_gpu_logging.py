@@ -67,3 +67,74 @@ def test_scalar_load_and_record_to_csv(tmp_path):
     bsuite_amd.load_and_record('catch/0', str(tmp_path), logging_mode='sqlite')
   with pytest.raises(ValueError):
     bsuite_amd.load_and_record_to_csv('catch/0', str(tmp_path))              # file exists, overwrite=False
+
+
+class _Collect:
+  def __init__(self):
+    self.rows = []
+
+  def write(self, data):
+    self.rows.append(dict(data))
+
+
+def test_scalar_log_every_never_fills_the_row_buffer():
+  """with log_every=True the reference logs every episode; the scalar view hands each row to
+  the logger right after the step and rewinds its (8-row) buffer, so a run far longer than any buffer
+  keeps logging (it used to stop after 4096 rows)."""
+  from bsuite_amd.environments import bandit
+  sink = _Collect()
+  env = wrappers.Logging(bandit.SimpleBandit(3, seed=1), sink, log_every=True)
+  n = 5000
+  for _ in range(n):
+    env.reset()
+    env.step(2)
+  assert len(sink.rows) == n and [r['episode'] for r in sink.rows[:3]] == [1, 2, 3] and sink.rows[-1]['episode'] == n
+  assert sink.rows[-1]['steps'] == n
+
+
+def test_by_step_logging_rows_fit_and_overflow_is_loud():
+  """log_by_step logs a log-point LAST and the FIRST after it (same step count, wrappers.py:96-102): the
+  default buffer holds both; an undersized buffer raises instead of silently dropping rows."""
+  B, T = 64, 400
+  env = eu.make_env('bandit', dict(mapping_seed=1), batch=B, lane_offset=0, seed=2)
+  log = wrappers.Logging(env, None, log_by_step=True)
+  orc = coracle.OracleEnv('bandit', dict(mapping_seed=1), np.arange(B, dtype=np.uint64), seed=2)
+  trk = logging_oracle.TrackOracle(B, list(orc.bsuite_info()), log_by_step=True)
+  a = np.zeros(B, np.int32)
+  for t in range(T):
+    log.step(torch.from_numpy(a).cuda())
+    st, r, _, _ = orc.call(a, t)
+    trk.track(st, r, orc.bsuite_info())
+  assert not bool(log.overflowed().any())
+  rows = log.all_rows()
+  assert [len(r) for r in rows] == [len(r) for r in trk.rows] and len(rows[0]) > 40     # LAST + FIRST at each point
+  small = wrappers.Logging(eu.make_env('bandit', dict(mapping_seed=1), batch=4, lane_offset=0, seed=2), None,
+                           log_every=True, max_rows=5)
+  for _ in range(40):
+    small.step(torch.zeros(4, dtype=torch.int32, device='cuda'))
+  assert bool(small.overflowed().all())
+  with pytest.raises(RuntimeError):
+    small.rows(0)
+  with pytest.raises(RuntimeError):
+    small.all_rows()
+
+
+def test_state_dict_carries_logging_and_wrapper_state():
+  """Resuming under Logging + RewardNoise: counters, rows and the fused wrapper configuration travel."""
+  B = 300
+  mk = lambda: wrappers.Logging(eu.make_env('catch', {}, batch=B, lane_offset=0, seed=4, wrap=('noise', 0.5)), None)
+  a, b = mk(), mk()
+  g = torch.Generator(device='cuda'); g.manual_seed(1)
+  acts = torch.randint(3, (90, B), generator=g, device='cuda', dtype=torch.int32)
+  for t in range(40):
+    a.step(acts[t])
+  b.raw_env.load_state_dict(a.raw_env.state_dict())
+  for t in range(40, 90):
+    ta, tb = a.step(acts[t]), b.step(acts[t])
+    assert torch.equal(ta.reward, tb.reward) and torch.equal(ta.step_type, tb.step_type)
+  for k, v in a.counters().items():
+    assert torch.equal(v, b.counters()[k]), k
+  assert torch.equal(a.num_rows(), b.num_rows()) and a.all_rows() == b.all_rows()
+  plain = eu.make_env('catch', {}, batch=B, lane_offset=0, seed=4)
+  with pytest.raises(ValueError):
+    plain.load_state_dict(a.raw_env.state_dict())            # taken with Logging, loaded without

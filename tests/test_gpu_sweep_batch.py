@@ -128,3 +128,20 @@ def test_grouped_sweep_equals_standalone_envs(tmp_path, mode):
       torch.testing.assert_close(env.bsuite_info()[k], v, rtol=0, atol=0)
     torch.testing.assert_close(eu.raw(env).episode_counters(), eu.raw(ref).episode_counters(), rtol=0, atol=0)
   batch.release_groups()
+
+
+@pytest.mark.gpu
+def test_group_set_rejects_actions_it_would_misread():
+  """grouped launches read the action tensor in place every step — an int64 / strided /
+  wrong-shape tensor must be refused, not reinterpreted."""
+  batch = sb.SweepBatch(['catch/0', 'bandit/0'], 600, seed=1)
+  acts = batch.random_actions(seed=0)
+  with pytest.raises(ValueError):
+    batch.prepare_groups([acts[0].to(torch.int64), acts[1]])
+  with pytest.raises(ValueError):
+    batch.prepare_groups([acts[0][:-1], acts[1]])
+  with pytest.raises(ValueError):
+    batch.prepare_groups([torch.zeros((300, 2), dtype=torch.int32, device='cuda')[:, 0], acts[1]])
+  batch.prepare_groups(acts)                                   # and the right ones are accepted
+  batch.step_grouped()
+  batch.sync()

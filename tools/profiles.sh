@@ -8,21 +8,23 @@ repo=$PWD
 B=1048576
 ( time timeout 1500 python -m pytest tests -m gpu -q ) > $out/pytest_gpu.log 2>&1; tail -3 $out/pytest_gpu.log
 timeout 300 python bench.py > $out/bench_default.json 2> $out/bench_default.err
+# the multi-rank path, executed for real on this ONE GPU (both ranks on cuda:0, gloo): functional evidence, NOT a scaling number
+BSX_BENCH_BACKEND=gloo BSX_BENCH_SINGLE_DEVICE=1 timeout 400 python bench.py --gpus 2 --lanes 524288 --no-cpu-baseline 2>/dev/null | grep '^{' > $out/bench_2ranks_on_one_gpu_gloo.json
 cd /tmp && export TMPDIR=/tmp
 timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_default -- python $repo/bench.py --no-cpu-baseline > $out/bench_default_under_rocprof.json 2>$out/rocprof_default.err
 f=$(find /tmp/prof_default -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp "$f" $out/bench_default_kernel_stats.csv
 timeout 300 rocprofv3 --kernel-trace --output-format csv -d /tmp/prof_sweep -- python $repo/bench.py --workload sweep --steps 40 --warmup 10 > $out/bench_sweep_under_rocprof.json 2>/dev/null
 f=$(find /tmp/prof_sweep -name "*kernel_trace.csv" | head -1)
-python - "$f" > $out/sweep_streams_timeline.txt <<'PY'
+python - "$f" > $out/sweep_whole_group_timeline.txt <<'PY'
 import csv, sys
 rows=list(csv.DictReader(open(sys.argv[1])))
-rows=[r for r in rows if 'group_kernel' in r['Kernel_Name'] or 'counter_add' in r['Kernel_Name'] or 'pair_mixed' in r['Kernel_Name']]
+rows=[r for r in rows if 'group_kernel' in r['Kernel_Name'] or 'counter_add' in r['Kernel_Name'] or 'pair_mixed' in r['Kernel_Name'] or 'sweep_phase0' in r['Kernel_Name']]
 rows.sort(key=lambda r:int(r['Start_Timestamp']))
-idx=[i for i,r in enumerate(rows) if 'pair_mixed_advance' in r['Kernel_Name']]
+idx=[i for i,r in enumerate(rows) if 'sweep_phase0' in r['Kernel_Name']]
 for s in (-4,-3,-2):
     a,b=idx[s], idx[s+1]
     t0=int(rows[a]['Start_Timestamp'])
-    print('--- sweep step (eager, two HIP streams)')
+    print('--- sweep step (whole-sweep group: two launches)')
     for r in rows[a:b]:
         n=r['Kernel_Name'].split('(')[0][-60:]
         print(f"{(int(r['Start_Timestamp'])-t0)/1e3:8.1f} -> {(int(r['End_Timestamp'])-t0)/1e3:8.1f} us  {n}")
