@@ -28,7 +28,7 @@
 // LOG / NOISE / MT: -1 = decide at run time, 0 = compiled out, 1 = always on.  The common call (no
 // Logging wrapper, no RewardNoise, counter-based draws) runs the <0,0,0> instantiation: without the
 // MT19937 twist, the f64 normal transform and the row snapshots the kernel is a fifth of the size.
-template <class Env, int LPB, bool ROLLOUT, int LOG, int NOISE, int MT>
+template <class Env, int LPB, bool ROLLOUT, int LOG, int NOISE, int MT, bool DIRECT = false>
 __device__ __forceinline__ void small_obs_body(const typename Env::args& a, const int n_steps_arg,
                                                const uint32_t block_id, float* s_obs, unsigned int* s_cnt) {
   const int n_steps = ROLLOUT ? n_steps_arg : 1;   // the single-step instantiation has no loop: keeping
@@ -44,6 +44,35 @@ __device__ __forceinline__ void small_obs_body(const typename Env::args& a, cons
 
 #pragma unroll 1
   for (int t = 0; t < n_steps; ++t) {
+    if (DIRECT) {
+      // Rows of at most 8 floats: the thread that advances a lane stores its row itself (8-byte stores
+      // when the row length is even) — no LDS tile, no barrier, so the waves of a block (and the steps of
+      // a fused rollout) never wait for each other.  A wave's 64 rows are one contiguous range, written
+      // by back-to-back instructions that the L2 merges line by line.
+      const int64_t i = lane0 + threadIdx.x;
+      int type = -1;
+      if ((int)threadIdx.x < lanes_here) {
+        const uint64_t lane = a.ctl.lane_offset + (uint64_t)i;
+        const int64_t oi = (int64_t)t * B + i;
+        double reward = 0.0;
+        float o[8];
+        type = Env::template step<LOG, MT>(a, i, oi, lane, step0 + (uint64_t)t, o, reward);
+        bsx_emit_at<LOG, NOISE>(a.ctl, a.out, i, oi, lane, step0 + (uint64_t)t, type, reward);
+        float* __restrict__ dst = a.out.observation + oi * (int64_t)numel;
+        if ((numel & 1) == 0) {
+          float2* __restrict__ d2 = reinterpret_cast<float2*>(dst);
+#pragma unroll
+          for (int k = 0; k < 4; ++k)
+            if (2 * k < numel) d2[k] = make_float2(o[2 * k], o[2 * k + 1]);
+        } else {
+#pragma unroll
+          for (int k = 0; k < 8; ++k)
+            if (k < numel) dst[k] = o[k];
+        }
+      }
+      bsx_count_types(a.ctl, type, s_cnt);
+      continue;
+    }
     if (LPB == BSX_BLOCK || threadIdx.x < LPB) {
       const int64_t i = lane0 + threadIdx.x;
       int type = -1;
@@ -73,11 +102,11 @@ __device__ __forceinline__ void small_obs_body(const typename Env::args& a, cons
   bsx_flush_counts(a.ctl, s_cnt, block_id);
 }
 
-template <class Env, int LPB, bool ROLLOUT, int LOG, int NOISE, int MT>
+template <class Env, int LPB, bool ROLLOUT, int LOG, int NOISE, int MT, bool DIRECT = false>
 __global__ void __launch_bounds__(BSX_BLOCK) small_obs_kernel(const typename Env::args a, const int n_steps) {
   extern __shared__ __attribute__((aligned(16))) float s_obs[];
   __shared__ unsigned int s_cnt[2];
-  small_obs_body<Env, LPB, ROLLOUT, LOG, NOISE, MT>(a, n_steps, blockIdx.x, s_obs, s_cnt);
+  small_obs_body<Env, LPB, ROLLOUT, LOG, NOISE, MT, DIRECT>(a, n_steps, blockIdx.x, s_obs, s_cnt);
 }
 
 // Grouped launch: every workgroup looks up its segment and runs the single-step body on that
@@ -146,13 +175,21 @@ static int launch_small_obs(const typename Env::args& a, int numel, int n_steps,
   if (n_steps < 1) return BSX_EINVAL;
   const bool logging = a.ctl.log.steps != nullptr, noise = a.ctl.wrap_kind == BSX_WRAP_NOISE;
   const bool lean = !logging && !noise && a.ctl.mt_state == nullptr;
+  // rows of 1 float or an even number <= 8: per-thread stores (coalesced 4-byte / 8-byte stores), no LDS
+  // tile, no barrier — measured on bandit, discounting_chain, cartpole: eager equal or 2-4 % faster, fused
+  // rollout 12-15 % faster; odd rows (memory_len, mountain_car: 4-byte stores at stride 12) are 5-8 %
+  // slower that way and keep the tile (profiles/r02/ab_small_direct_stores.log).  BSX_SMALL_DIRECT=0: A/B.
+  static const int direct_env = bsx_env_int("BSX_SMALL_DIRECT", 1);
+  const bool direct = direct_env != 0 && numel <= 8 && (numel == 1 || (numel & 1) == 0);
 #define SMALL_OBS_LAUNCH(LPB)                                                                              \
   {                                                                                                        \
     const int64_t blocks = (a.ctl.n_lanes + (LPB) - 1) / (LPB);                                            \
     if (blocks > 0x7FFFFFFF) return BSX_EINVAL;                                                            \
     const size_t lds = (size_t)(LPB) * numel * 4;                                                          \
     const dim3 g((unsigned)blocks), b(BSX_BLOCK);                                                          \
-    if (n_steps == 1 && lean) small_obs_kernel<Env, LPB, false, 0, 0, 0><<<g, b, lds, st>>>(a, 1);         \
+    if (n_steps == 1 && lean && direct && (LPB) == 256) small_obs_kernel<Env, 256, false, 0, 0, 0, true><<<g, b, 0, st>>>(a, 1); \
+    else if (n_steps > 1 && lean && direct && (LPB) == 256) small_obs_kernel<Env, 256, true, 0, 0, 0, true><<<g, b, 0, st>>>(a, n_steps); \
+    else if (n_steps == 1 && lean) small_obs_kernel<Env, LPB, false, 0, 0, 0><<<g, b, lds, st>>>(a, 1);    \
     else if (n_steps == 1) small_obs_kernel<Env, LPB, false, -1, -1, -1><<<g, b, lds, st>>>(a, 1);         \
     else if (logging && noise) small_obs_kernel<Env, LPB, true, 1, 1, -1><<<g, b, lds, st>>>(a, n_steps);  \
     else if (logging) small_obs_kernel<Env, LPB, true, 1, 0, -1><<<g, b, lds, st>>>(a, n_steps);           \
