@@ -41,9 +41,26 @@ __device__ __forceinline__ void small_obs_body(const typename Env::args& a, cons
   const int64_t remaining = B - lane0;
   const int lanes_here = remaining < LPB ? (int)remaining : LPB;
   const uint64_t step0 = bsx_step_of(a.ctl);
+  // Fused rollout of a family with HAS_REGS: the lane's state lives in registers for the T steps and the
+  // action of step t+1 is in flight while step t computes.
+  constexpr bool REGS = ROLLOUT && Env::HAS_REGS;
+  const bool mine = (LPB == BSX_BLOCK || threadIdx.x < LPB) && (int)threadIdx.x < lanes_here;
+  typename Env::regs rg;
+  int act_next = 0;
+  if constexpr (REGS) {
+    if (mine) {
+      Env::load(a, lane0 + threadIdx.x, rg);
+      act_next = a.action[lane0 + threadIdx.x];
+    }
+  }
 
 #pragma unroll 1
   for (int t = 0; t < n_steps; ++t) {
+    int act = 0;
+    if constexpr (REGS) {
+      act = act_next;
+      if (mine && t + 1 < n_steps) act_next = a.action[(int64_t)(t + 1) * B + lane0 + threadIdx.x];
+    }
     if (DIRECT) {
       // Rows of at most 8 floats: the thread that advances a lane stores its row itself (8-byte stores
       // when the row length is even) — no LDS tile, no barrier, so the waves of a block (and the steps of
@@ -56,7 +73,8 @@ __device__ __forceinline__ void small_obs_body(const typename Env::args& a, cons
         const int64_t oi = (int64_t)t * B + i;
         double reward = 0.0;
         float o[8];
-        type = Env::template step<LOG, MT>(a, i, oi, lane, step0 + (uint64_t)t, o, reward);
+        if constexpr (REGS) type = Env::template core<LOG, MT>(a, rg, act, i, lane, step0 + (uint64_t)t, o, reward);
+        else type = Env::template step<LOG, MT>(a, i, oi, lane, step0 + (uint64_t)t, o, reward);
         bsx_emit_at<LOG, NOISE>(a.ctl, a.out, i, oi, lane, step0 + (uint64_t)t, type, reward);
         float* __restrict__ dst = a.out.observation + oi * (int64_t)numel;
         if ((numel & 1) == 0) {
@@ -80,7 +98,8 @@ __device__ __forceinline__ void small_obs_body(const typename Env::args& a, cons
         const uint64_t lane = a.ctl.lane_offset + (uint64_t)i;
         const int64_t oi = (int64_t)t * B + i;
         double reward = 0.0;
-        type = Env::template step<LOG, MT>(a, i, oi, lane, step0 + (uint64_t)t, s_obs + (int)threadIdx.x * numel, reward);
+        if constexpr (REGS) type = Env::template core<LOG, MT>(a, rg, act, i, lane, step0 + (uint64_t)t, s_obs + (int)threadIdx.x * numel, reward);
+        else type = Env::template step<LOG, MT>(a, i, oi, lane, step0 + (uint64_t)t, s_obs + (int)threadIdx.x * numel, reward);
         bsx_emit_at<LOG, NOISE>(a.ctl, a.out, i, oi, lane, step0 + (uint64_t)t, type, reward);
       }
       bsx_count_types(a.ctl, type, s_cnt);
@@ -97,6 +116,9 @@ __device__ __forceinline__ void small_obs_body(const typename Env::args& a, cons
     for (int ch = threadIdx.x; ch < n_chunks; ch += BSX_BLOCK) t4[ch] = s4[ch];
     for (int f = (n_chunks << 2) + (int)threadIdx.x; f < total; f += BSX_BLOCK) tile[f] = s_obs[f];
     if (t + 1 < n_steps) __syncthreads();                              // tile is rewritten next step
+  }
+  if constexpr (REGS) {
+    if (mine) Env::store(a, lane0 + threadIdx.x, rg);
   }
   __syncthreads();
   bsx_flush_counts(a.ctl, s_cnt, block_id);
@@ -207,6 +229,8 @@ static int launch_small_obs(const typename Env::args& a, int numel, int n_steps,
 
 // ------------------------------------------------------------------------------ bandit
 struct bandit_env {
+  static constexpr bool HAS_REGS = false;
+  struct regs { int unused; };
   struct args {
     bsx_ctl ctl; const int32_t* action; int32_t* state; bsx_timestep_t out; double* info;
     int32_t obs_numel; int32_t num_actions; double rewards[BSX_BANDIT_MAX_ACTIONS];
@@ -260,6 +284,8 @@ extern "C" int bsx_group_set_bandit(bsx_group_t* g, int32_t index, const bsx_ban
 // ------------------------------------------------------------------------------ memory_chain
 #define MC_RESET_BIT (1 << 28)
 struct memory_chain_env {
+  static constexpr bool HAS_REGS = false;
+  struct regs { int unused; };
   struct args {
     bsx_ctl ctl; const int32_t* action; int32_t* state; uint64_t* context; bsx_timestep_t out;
     double* info; int32_t obs_numel; int32_t L; int32_t nb;
@@ -332,6 +358,8 @@ extern "C" int bsx_group_set_memory_chain(bsx_group_t* g, int32_t index, const b
 // ------------------------------------------------------------------------------ umbrella_chain
 #define UC_RESET_BIT (1 << 22)
 struct umbrella_chain_env {
+  static constexpr bool HAS_REGS = false;
+  struct regs { int unused; };
   struct args {
     bsx_ctl ctl; const int32_t* action; int32_t* state; bsx_timestep_t out; double* info;
     int32_t obs_numel; int32_t L; int32_t nd;
@@ -411,6 +439,8 @@ extern "C" int bsx_group_set_umbrella_chain(bsx_group_t* g, int32_t index, const
 // ------------------------------------------------------------------------------ discounting_chain
 #define DC_RESET_BIT (1 << 12)
 struct discounting_chain_env {
+  static constexpr bool HAS_REGS = false;
+  struct regs { int unused; };
   struct args {
     bsx_ctl ctl; const int32_t* action; int32_t* state; bsx_timestep_t out;
     int32_t obs_numel; int32_t bonus;
@@ -489,12 +519,36 @@ struct cartpole_env {
     // derived on the host in f64, rounded once (cartpole_make)
     float inv_m_total, pole_ml, pole_ml_over_mt, den_a, den_b, inv_x_threshold;
   };
+  // The lane's state in registers: step() = load + core + store; the fused rollout loads once, runs core
+  // T times and stores once (small_obs_body), instead of a round trip through L2 every step.
+  static constexpr bool HAS_REGS = true;
+  struct regs { float x, xd, th, thd; int32_t sk; };
+  __device__ static __forceinline__ void load(const args& a, int64_t i, regs& r) {
+    const int64_t B = a.ctl.n_lanes;
+    r.sk = a.steps[i];
+    r.x = a.state[i]; r.xd = a.state[B + i]; r.th = a.state[2 * B + i]; r.thd = a.state[3 * B + i];
+  }
+  __device__ static __forceinline__ void store(const args& a, int64_t i, const regs& r) {
+    const int64_t B = a.ctl.n_lanes;
+    a.state[i] = r.x; a.state[B + i] = r.xd; a.state[2 * B + i] = r.th; a.state[3 * B + i] = r.thd;
+    a.steps[i] = r.sk;
+  }
   template <int LOG, int MT>
   __device__ static int step(const args& a, int64_t i, int64_t oi, uint64_t lane, uint64_t step, float* o, double& reward) {
+    regs r;
+    load(a, i, r);
+    const int act = a.ctl.force_reset ? 0 : a.action[oi];
+    const int type = core<LOG, MT>(a, r, act, i, lane, step, o, reward);
+    store(a, i, r);
+    return type;
+  }
+  template <int LOG, int MT>
+  __device__ static __forceinline__ int core(const args& a, regs& rg, const int act, int64_t i, uint64_t lane, uint64_t step,
+                                             float* o, double& reward) {
     BSX_NO_CONTRACT
     const int64_t B = a.ctl.n_lanes;
     const bsx_cartpole_t& g = a.cfg;
-    const int32_t sk = a.steps[i];
+    const int32_t sk = rg.sk;
     const bool per_step_info = g.swingup || LOG == 1 || (LOG == -1 && a.ctl.log.steps != nullptr);
     int k = sk & 0x3FFFFFFF;
     float x, xd, th, thd, si, co;
@@ -515,8 +569,7 @@ struct cartpole_env {
       bsx_sincosf(th, &si, &co);                               // |theta_offset| + init_range <= 32 (cartpole_make)
       type = BSX_FIRST;
     } else {
-      x = a.state[i]; xd = a.state[B + i]; th = a.state[2 * B + i]; thd = a.state[3 * B + i];
-      const int act = a.action[oi];
+      x = rg.x; xd = rg.xd; th = rg.th; thd = rg.thd;
       // step_cartpole, cartpole.py:37-65, in f32.  One sine/cosine pair per step: that of the OLD
       // angle; the new angle's pair follows from it by the angle-addition formulas below.
       float s0, c0;
@@ -576,8 +629,8 @@ struct cartpole_env {
         a.info[B + i] = ep > best ? ep : best;
       }
     }
-    a.state[i] = x; a.state[B + i] = xd; a.state[2 * B + i] = th; a.state[3 * B + i] = thd;
-    a.steps[i] = k | (type == BSX_LAST ? CP_RESET_BIT : 0);
+    rg.x = x; rg.xd = xd; rg.th = th; rg.thd = thd;
+    rg.sk = k | (type == BSX_LAST ? CP_RESET_BIT : 0);
     o[0] = x * a.inv_x_threshold;                               // cartpole.py:171-176
     o[1] = xd * a.inv_x_threshold;
     o[2] = si;
@@ -642,11 +695,28 @@ struct mountain_car_env {
     bsx_ctl ctl; const int32_t* action; float* state; int32_t* steps; bsx_timestep_t out;
     double* info; int32_t obs_numel; int32_t max_steps;
   };
+  static constexpr bool HAS_REGS = true;
+  struct regs { float pos, vel; int32_t sk; };
+  __device__ static __forceinline__ void load(const args& a, int64_t i, regs& r) {
+    r.sk = a.steps[i]; r.pos = a.state[i]; r.vel = a.state[a.ctl.n_lanes + i];
+  }
+  __device__ static __forceinline__ void store(const args& a, int64_t i, const regs& r) {
+    a.state[i] = r.pos; a.state[a.ctl.n_lanes + i] = r.vel; a.steps[i] = r.sk;
+  }
   template <int LOG, int MT>
   __device__ static int step(const args& a, int64_t i, int64_t oi, uint64_t lane, uint64_t step, float* o, double& reward) {
+    regs r;
+    load(a, i, r);
+    const int act = a.ctl.force_reset ? 0 : a.action[oi];
+    const int type = core<LOG, MT>(a, r, act, i, lane, step, o, reward);
+    store(a, i, r);
+    return type;
+  }
+  template <int LOG, int MT>
+  __device__ static __forceinline__ int core(const args& a, regs& rg, const int act, int64_t i, uint64_t lane, uint64_t step,
+                                             float* o, double& reward) {
     BSX_NO_CONTRACT
-    const int64_t B = a.ctl.n_lanes;
-    const int32_t sk = a.steps[i];
+    const int32_t sk = rg.sk;
     int t = sk & 0x3FFFFFFF;
     float pos, vel;
     int type;
@@ -661,12 +731,12 @@ struct mountain_car_env {
       vel = 0.0f;
       type = BSX_FIRST;
     } else {
-      pos = a.state[i]; vel = a.state[B + i];
+      pos = rg.pos; vel = rg.vel;
       t += 1;                                                   // :74
       reward = -1.0;
       float sn, cs;
       bsx_sincosf(3.0f * pos, &sn, &cs);                        // position is clipped to [-1.2, 0.6]
-      vel += (float)(a.action[oi] - 1) * 0.001f + cs * -0.0025f;   // :79-80
+      vel += (float)(act - 1) * 0.001f + cs * -0.0025f;            // :79-80
       vel = fminf(fmaxf(vel, -0.07f), 0.07f);                   // :81
       pos += vel;                                               // :82
       pos = fminf(fmaxf(pos, -1.2f), 0.6f);                     // :83
@@ -675,8 +745,8 @@ struct mountain_car_env {
       if (LOG == 1 || (LOG == -1 && a.ctl.log.steps != nullptr)) a.info[i] += reward;   // :76, per step under Logging
       else if (type == BSX_LAST) a.info[i] -= (double)t;        // the episode's t rewards of -1, exact
     }
-    a.state[i] = pos; a.state[B + i] = vel;
-    a.steps[i] = t | (type == BSX_LAST ? CP_RESET_BIT : 0);
+    rg.pos = pos; rg.vel = vel;
+    rg.sk = t | (type == BSX_LAST ? CP_RESET_BIT : 0);
     o[0] = pos;                                                 // :62-64
     o[1] = vel;
     o[2] = (float)t / (float)a.max_steps;                       // both exact in f32; correctly rounded quotient
