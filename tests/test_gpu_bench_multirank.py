@@ -63,7 +63,7 @@ def test_default_line_two_ranks_has_strong_and_sweep_records():
   sweep = also['sweep']
   assert sum(sweep['segments_per_rank']) == 468 and min(sweep['segments_per_rank']) > 0
   assert sweep['global_lanes'] == 8192
-  one = _bench('--gpus', '1', '--workload', 'sweep', '--lanes', '8192', '--steps', '20', '--warmup', '5')
+  one = _bench('--gpus', '1', '--workload', 'sweep', '--lanes', '8192', '--steps', '100', '--warmup', '20')   # the sub-record's K / W
   assert one['episodes_finished'] == sweep['episodes_finished'] > 0
 
 

@@ -102,3 +102,22 @@ def test_host_rule_selection_matches_to_image():
   assert (c.radius_y, c.radius_x) == (0, 0)
   with pytest.raises(AssertionError):
     w._image_cfg((8,), (1, 2))
+
+
+def test_host_half_kernels_are_scipys():
+  """The anti-aliasing weights handed to the kernel == scipy.ndimage's own Gaussian kernel (truncate 4) for
+  skimage's sigma = (in/out - 1)/2, element for element; an axis scipy would skip gets no kernel."""
+  filters = pytest.importorskip('scipy.ndimage._filters')
+  from bsuite_amd.utils import wrappers as w
+  for n_in, n_out in [(10, 6), (5, 4), (30, 12), (103, 84), (28, 7), (28, 9), (50, 10), (412, 84), (64, 3), (64, 2), (200, 20),
+                      (7, 6), (9, 9), (5, 84)]:
+    half = w._gaussian_half_kernel(n_in, n_out)
+    sigma = max(0.0, (n_in / n_out - 1) / 2)
+    radius = int(4.0 * sigma + 0.5)
+    if sigma <= 1e-15 or radius == 0:
+      assert half is None
+      continue
+    ref = filters._gaussian_kernel1d(sigma, 0, radius)
+    np.testing.assert_array_equal(half, ref[radius:])
+    np.testing.assert_array_equal(ref[:radius][::-1], ref[radius + 1:])      # symmetric: one half suffices
+    np.testing.assert_array_equal(half, io.gaussian_half_kernel(n_in, n_out))
