@@ -249,7 +249,9 @@ __device__ __forceinline__ bsx_group_slot bsx_group_find(const bsx_group_index& 
 // Fam provides: struct args { bsx_ctl ctl; const int32_t* action; int32_t* state; bsx_timestep_t out;
 //                             double* info; ... };  struct shared;  static stage(args, shared&);
 //   static int advance(args, shared, i, lane, step, st, act, nst&, reward&)
-template <class Fam>
+// LEAN: no Logging wrapper, no RewardNoise, counter-based draws — those branches are compiled out (the
+// launcher picks it when the call has none of them).
+template <class Fam, bool LEAN = false>
 __device__ __forceinline__ void bsx_advance_body(const typename Fam::args& a, uint32_t block_id,
                                                  typename Fam::shared& s_fam, unsigned int* s_cnt) {
   if (threadIdx.x < 2) s_cnt[threadIdx.x] = 0;
@@ -262,20 +264,21 @@ __device__ __forceinline__ void bsx_advance_body(const typename Fam::args& a, ui
     const uint64_t step = bsx_step_of(a.ctl);
     int32_t nst; double reward;
     const int act = a.ctl.force_reset ? 0 : a.action[i];
-    type = Fam::advance(a, s_fam, i, lane, step, a.state[i], act, nst, reward);
+    type = Fam::template advance<LEAN>(a, s_fam, i, lane, step, a.state[i], act, nst, reward);
     a.state[i] = nst;
-    bsx_emit(a.ctl, a.out, i, lane, step, type, reward);
+    if (LEAN) bsx_emit_at<0, 0>(a.ctl, a.out, i, i, lane, step, type, reward);
+    else bsx_emit(a.ctl, a.out, i, lane, step, type, reward);
   }
   bsx_count_types(a.ctl, type, s_cnt);
   __syncthreads();
   bsx_flush_counts(a.ctl, s_cnt, block_id);
 }
 
-template <class Fam>
+template <class Fam, bool LEAN = false>
 __global__ void __launch_bounds__(BSX_BLOCK) bsx_advance_kernel(const typename Fam::args a) {
   __shared__ typename Fam::shared s_fam;
   __shared__ unsigned int s_cnt[2];
-  bsx_advance_body<Fam>(a, blockIdx.x, s_fam, s_cnt);
+  bsx_advance_body<Fam, LEAN>(a, blockIdx.x, s_fam, s_cnt);
 }
 
 template <class Fam>
@@ -439,7 +442,7 @@ __global__ void __launch_bounds__(BSX_BLOCK) bsx_advance_delta_kernel(const type
     int32_t nst; double reward;
     const int act = a.ctl.force_reset ? 0 : a.action[i];
     const int32_t was = paint[i];
-    type = Fam::advance(a, s_fam, i, lane, step, a.state[i], act, nst, reward);
+    type = Fam::template advance<false>(a, s_fam, i, lane, step, a.state[i], act, nst, reward);
     a.state[i] = nst;
     bsx_patch_board(a.out.observation + i * (int64_t)cells, was, nst, fn);
     paint[i] = nst;

@@ -82,7 +82,11 @@ template <class Fam>
 static inline int bsx_launch_advance(const typename Fam::args& a, hipStream_t st) {
   const int64_t blocks = (a.ctl.n_lanes + BSX_BLOCK - 1) / BSX_BLOCK;
   if (blocks > 0x7FFFFFFF) return BSX_EINVAL;
-  bsx_advance_kernel<Fam><<<dim3((unsigned)blocks), dim3(BSX_BLOCK), 0, st>>>(a);
+  static const int lean_env = bsx_env_int("BSX_ADVANCE_LEAN", 1);
+  const bool lean = lean_env != 0 && a.ctl.log.steps == nullptr && a.ctl.wrap_kind != BSX_WRAP_NOISE &&
+                    a.ctl.mt_state == nullptr;
+  if (lean) bsx_advance_kernel<Fam, true><<<dim3((unsigned)blocks), dim3(BSX_BLOCK), 0, st>>>(a);
+  else bsx_advance_kernel<Fam, false><<<dim3((unsigned)blocks), dim3(BSX_BLOCK), 0, st>>>(a);
   return 0;
 }
 

@@ -20,6 +20,8 @@ struct catch_fam {
   struct shared { int unused; };
   __device__ static __forceinline__ void stage(const args&, shared&) {}
 
+  // LEAN: counter-based draws only (the MT19937-exact mode is compiled out)
+  template <bool LEAN = false>
   __device__ static __forceinline__ int advance(const args& a, const shared&, int64_t i, uint64_t lane,
                                                 uint64_t step, int32_t st, int act, int32_t& nst,
                                                 double& reward) {
@@ -29,9 +31,9 @@ struct catch_fam {
     reward = 0.0;
     if (a.ctl.force_reset || (st & CATCH_RESET_BIT)) {         // catch.py:80-81 -> :68-76
       bsx_draws d;
-      bsx_draws_begin(&d, a.ctl, i, lane, step);
+      bsx_draws_begin<LEAN ? 0 : -1>(&d, a.ctl, i, lane, step);
       ball_x = (int)bsx_randint(&d, (uint32_t)cols);            // :71
-      bsx_draws_end(&d, a.ctl, i);
+      bsx_draws_end<LEAN ? 0 : -1>(&d, a.ctl, i);
       ball_y = 0;
       paddle_x = cols / 2;
       type = BSX_FIRST;

@@ -30,6 +30,8 @@ struct deep_sea_fam {
   }
 
   // One lane's reset()/step() (base.py:59-65 -> deep_sea.py:110-144).
+  // LEAN: counter-based draws only (the MT19937-exact mode is compiled out)
+  template <bool LEAN = false>
   __device__ static __forceinline__ int advance(const args& a, const shared& s, int64_t i, uint64_t lane,
                                                 uint64_t step, int32_t st, int act, int32_t& nst,
                                                 double& reward) {
@@ -46,7 +48,7 @@ struct deep_sea_fam {
       const int mapped = (int)((s.map[cell >> 5] >> (cell & 31)) & 1u);
       const bool right = (act == mapped);                       // deep_sea.py:118
       bsx_draws d;
-      bsx_draws_begin(&d, a.ctl, i, lane, step);
+      bsx_draws_begin<LEAN ? 0 : -1>(&d, a.ctl, i, lane, step);
       if (col == N - 1 && right) {                              // :121-123
         reward += 1.0;
         a.info[a.ctl.n_lanes + i] += 1.0;
@@ -58,7 +60,7 @@ struct deep_sea_fam {
         // counter-based stream restarts at every call, so an unused draw leaves no trace and is
         // skipped; the lane's own MT19937 generator (exact mode) must advance, so there it is drawn.
         bool moves = true;
-        if (!a.deterministic || a.ctl.mt_state != nullptr) {
+        if (!a.deterministic || (!LEAN && a.ctl.mt_state != nullptr)) {
           const double u = bsx_uniform(&d);
           moves = (u > a.inv_size) || a.deterministic;
         }
@@ -68,7 +70,7 @@ struct deep_sea_fam {
         if (row == col) bad = 1;
         col = col - 1 < 0 ? 0 : col - 1;
       }
-      bsx_draws_end(&d, a.ctl, i);
+      bsx_draws_end<LEAN ? 0 : -1>(&d, a.ctl, i);
       row += 1;                                                 // :137
       if (row == N) {                                           // :140-143
         if (bad) a.info[i] += 1.0;
