@@ -64,7 +64,11 @@ def run_case(rng, case_id):
                     observation_mode='delta' if delta else 'dense')
   raw = eu.raw(env)
   raw._step_index = step0
-  log = wrappers.Logging(env, None, log_by_step=by_step, max_rows=400)
+  # half of the cases run WITHOUT the Logging wrapper: the lean kernel instantiations, per-thread
+  # observation stores and episode-end info folding of cartpole / mountain_car are then the ones tested
+  use_log = bool(rng.integers(2))
+  log = wrappers.Logging(env, None, log_by_step=by_step, max_rows=400) if use_log else env
+  chk = eu.PhysicsChecker(fam, kw, B) if phys else None
   orc = coracle.OracleEnv(fam, kw, np.arange(off, off + B, dtype=np.uint64), seed=seed, wrap=wrap)
   trk = logging_oracle.TrackOracle(B, list(orc.bsuite_info()), log_by_step=by_step)
   T = int(rng.integers(5, 60))
@@ -99,31 +103,20 @@ def run_case(rng, case_id):
         g = (ts.step_type, ts.reward, ts.discount, ts.observation)
       gst, gr, gd, go = [x.cpu().numpy() for x in g]
       live = st != 0
-      if phys:
-        same = gst == st
-        assert (~same).sum() <= 1, (case_id, fam, kw, 'step_type flips', int((~same).sum()))
-        if fam == 'cartpole_swingup':
-          # obs[6], obs[7] are sign flags of |x| < x_reward_threshold, |theta_dot| < 1 (swingup:147-149):
-          # an f32 state within rounding of a threshold may flip one, like a step_type tie
-          flips = (go[..., 6:] != o[..., 6:]).reshape(len(st), -1).any(axis=1) & same
-          assert flips.sum() <= 1, (case_id, fam, kw, 'sign-flag flips', int(flips.sum()))
-          np.testing.assert_allclose(go[same][..., :6], o[same][..., :6], rtol=1e-6, atol=1e-6)
-          if flips.any():
-            return 'tie'
-        else:
-          np.testing.assert_allclose(go[same], o[same], rtol=1e-6, atol=1e-6)
-        np.testing.assert_allclose(gr[live & same], r[live & same], rtol=1e-6, atol=1e-6)
-        if not same.all():
-          return 'tie'
+      if phys:   # |a-b| <= 1e-6*max(1,|b|); a lane may differ in step_type / reward / sign flag only on a verified tie
+        chk.check((gst, gr, gd, go), (st, r, d, o), eu.oracle_physics_state(orc, fam), msg=str((case_id, fam, kw, wrap, B, t + j)))
       else:
         np.testing.assert_array_equal(gst, st, err_msg=str((case_id, fam, kw, wrap, B, off, t + j)))
         np.testing.assert_array_equal(eu.f32_bits(gr[live]), eu.f32_bits(r[live].astype(np.float32)),
                                       err_msg=str((case_id, fam, kw, wrap, B, t + j)))
         np.testing.assert_array_equal(eu.f32_bits(go), eu.f32_bits(o), err_msg=str((case_id, fam, kw, B, t + j)))
     t += n
-  if not phys:
-    for k_, v in orc.bsuite_info().items():
-      np.testing.assert_array_equal(raw.bsuite_info()[k_].cpu().numpy(), v, err_msg=str((case_id, fam, k_)))
+  clean = ~chk.tainted if phys else np.ones(B, bool)
+  for k_, v in orc.bsuite_info().items():
+    np.testing.assert_array_equal(raw.bsuite_info()[k_].cpu().numpy()[clean], v[clean], err_msg=str((case_id, fam, kw, k_, use_log)))
+  if phys:
+    return 'tie' if chk.ties else 'ok'
+  if use_log:
     c = log.counters()
     np.testing.assert_array_equal(c['steps'].cpu().numpy(), trk.steps)
     np.testing.assert_array_equal(c['total_return'].cpu().numpy(), trk.total_return)
