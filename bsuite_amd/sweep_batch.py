@@ -227,7 +227,7 @@ class SweepBatch:
       2. the observation store stream (HBM-bound, ~96 % of the sweep's bytes) alone on the machine.
     The shared call counter is bumped as soon as phase 1 — its only readers — is done, i.e. beside the
     store stream.  (Schedules that let the small groups run beside the store stream measured slower and
-    bimodal: both kernels stretch, profiles/r02/sweep_streams_timeline_overlapped.txt; a captured HIP
+    bimodal: both kernels stretch (profiles/r02/ab_sweep_pair_mixed.log); a captured HIP
     graph starts dependent nodes 6-14 us apart and consecutive replays ~20 us apart,
     profiles/r02/sweep_graph_timeline_*.txt.)  Call `join_streams()` before reading the outputs on
     the current stream."""
