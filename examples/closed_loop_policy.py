@@ -7,12 +7,14 @@ This is the batched counterpart of the reference run loop (bsuite/baselines/expe
 `timestep = env.step(agent.select_action(timestep))`, with 2^20 environments per call.
 """
 import json
+import os
 import sys
 import time
 
 import torch
 
-import bsuite_amd
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))   # run from a checkout
+import bsuite_amd  # noqa: E402
 
 
 def main():
