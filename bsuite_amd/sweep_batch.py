@@ -185,7 +185,18 @@ class SweepBatch:
       buckets.setdefault((group_family, klass), []).append(k)
     outs = [None] * len(self.envs)
     costs = []
+    import os  # pylint: disable=import-outside-toplevel
+    heavy_first = os.environ.get('BSX_SWEEP_HEAVY_FIRST', '1') != '0'
     for (name, _), members in sorted(buckets.items()):
+      if name == 'sweep_mixed' and heavy_first:
+        # Phase 0 ends when its slowest workgroup retires: put the long-running ones — wide observation rows
+        # (umbrella_distract draws and writes up to 103 floats per lane) — at the front of the grid and the
+        # cheap lane-advance workgroups of the two-kernel families at its end.
+        def weight(k):
+          raw_k = self.envs[k].raw_env if hasattr(self.envs[k], 'raw_env') else self.envs[k]
+          small_k = raw_k._abi_name not in ('deep_sea', 'catch', 'mnist')  # pylint: disable=protected-access
+          return -int(np.prod(raw_k.observation_spec().shape)) if small_k else 1
+        members = sorted(members, key=weight)
       handle = ctypes.c_void_p()
       _native.check(_native.lib.bsx_group_create(_native.FAMILY_IDS[name], len(members), ctypes.byref(handle)),
                     'bsx_group_create')
