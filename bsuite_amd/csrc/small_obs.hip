@@ -82,6 +82,11 @@ __device__ __forceinline__ void small_obs_body(const typename Env::args& a, cons
 #pragma unroll
           for (int k = 0; k < 4; ++k)
             if (2 * k < numel) d2[k] = make_float2(o[2 * k], o[2 * k + 1]);
+        } else if (numel == 3) {
+          // one 12-byte store per lane (global_store_dwordx3): a wave's 64 rows are 768 contiguous bytes
+          struct __attribute__((packed, aligned(4))) row3 { float a, b, c; };
+          row3 v; v.a = o[0]; v.b = o[1]; v.c = o[2];
+          *reinterpret_cast<row3*>(dst) = v;
         } else {
 #pragma unroll
           for (int k = 0; k < 8; ++k)
@@ -197,12 +202,14 @@ static int launch_small_obs(const typename Env::args& a, int numel, int n_steps,
   if (n_steps < 1) return BSX_EINVAL;
   const bool logging = a.ctl.log.steps != nullptr, noise = a.ctl.wrap_kind == BSX_WRAP_NOISE;
   const bool lean = !logging && !noise && a.ctl.mt_state == nullptr;
-  // rows of 1 float or an even number <= 8: per-thread stores (coalesced 4-byte / 8-byte stores), no LDS
-  // tile, no barrier — measured on bandit, discounting_chain, cartpole: eager equal or 2-4 % faster, fused
-  // rollout 12-15 % faster; odd rows (memory_len, mountain_car: 4-byte stores at stride 12) are 5-8 %
-  // slower that way and keep the tile (profiles/r02/ab_small_direct_stores.log).  BSX_SMALL_DIRECT=0: A/B.
+  // rows of 1 float, 3 floats or an even number <= 8: per-thread stores (4-byte / 12-byte / 8-byte stores,
+  // each wave writing one contiguous range), no LDS tile, no barrier — measured on bandit,
+  // discounting_chain, cartpole, mountain_car, memory_len: eager equal or 2-4 % faster, fused rollout
+  // 3-15 % faster (profiles/r02/ab_small_direct_stores.log).  Three 4-byte stores at stride 12 for the
+  // 3-float rows were 5-8 % SLOWER than the tile; one global_store_dwordx3 is faster.  Other odd rows keep
+  // the tile.  BSX_SMALL_DIRECT=0: A/B.
   static const int direct_env = bsx_env_int("BSX_SMALL_DIRECT", 1);
-  const bool direct = direct_env != 0 && numel <= 8 && (numel == 1 || (numel & 1) == 0);
+  const bool direct = direct_env != 0 && numel <= 8 && (numel == 1 || numel == 3 || (numel & 1) == 0);
 #define SMALL_OBS_LAUNCH(LPB)                                                                              \
   {                                                                                                        \
     const int64_t blocks = (a.ctl.n_lanes + (LPB) - 1) / (LPB);                                            \
