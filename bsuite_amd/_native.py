@@ -13,7 +13,7 @@ SO_PATH = os.path.join(_HERE, '_lib', 'libbsuite_amd.so')
 
 FIRST, MID, LAST = 0, 1, 2
 BSX_EINVAL, BSX_ENULL, BSX_EALIGN, BSX_ERANGE, BSX_EMODE, BSX_ENOMEM = -1, -2, -3, -4, -5, -6
-WRAP_NONE, WRAP_SCALE, WRAP_NOISE = 0, 1, 2
+WRAP_NONE, WRAP_SCALE, WRAP_NOISE, WRAP_SCALE_NOISE, WRAP_NOISE_SCALE = 0, 1, 2, 3, 4
 COUNTER_SHARDS, COUNTER_STRIDE = 256, 16
 DEEP_SEA_MAX_SIZE = 64
 BANDIT_MAX_ACTIONS = 32
@@ -65,7 +65,7 @@ class Stream(ctypes.Structure):
 class RewardWrap(ctypes.Structure):
   _fields_ = [('kind', ctypes.c_int32), ('_pad', ctypes.c_int32), ('param', ctypes.c_double),
               ('seed', ctypes.c_uint64), ('mt_state', ctypes.c_void_p), ('mt_pos', ctypes.c_void_p),
-              ('mt_gauss', ctypes.c_void_p), ('mt_has_gauss', ctypes.c_void_p)]
+              ('mt_gauss', ctypes.c_void_p), ('mt_has_gauss', ctypes.c_void_p), ('param2', ctypes.c_double)]
 
 
 class TimeStepPtrs(ctypes.Structure):

@@ -26,6 +26,7 @@ struct bsx_ctl {
   const uint64_t* step_base;
   uint64_t* counters;
   double wrap_param;
+  double wrap_param2;       // stacked wrappers: the outer wrapper's parameter
   uint64_t wrap_seed;
   int32_t wrap_kind;
   int32_t force_reset;
@@ -77,22 +78,30 @@ __device__ __forceinline__ double bsx_wrap_reward(const bsx_ctl& c, int64_t i, u
                                                   double reward) {
   BSX_NO_CONTRACT
   if (c.wrap_kind == BSX_WRAP_SCALE) return reward * c.wrap_param;
-  if (NOISE != 0 && c.wrap_kind == BSX_WRAP_NOISE) {
+  if (NOISE != 0 && c.wrap_kind >= BSX_WRAP_NOISE) {
+    // RewardNoise alone, or stacked with RewardScale in either order (each wrapper acts on what the one
+    // inside it returned): SCALE_NOISE = r*s + sigma*z, NOISE_SCALE = (r + sigma*z)*s
+    const double sigma = c.wrap_kind == BSX_WRAP_SCALE_NOISE ? c.wrap_param2 : c.wrap_param;
+    if (c.wrap_kind == BSX_WRAP_SCALE_NOISE) reward = reward * c.wrap_param;
     bsx_draws w;
     bsx_draws_init(&w, c.wrap_seed, lane, step, BSX_STREAM_WRAP);
+    double z;
     if (c.wrap_mt_state != nullptr) {       // MT19937-exact mode: the wrapper's own RandomState (wrappers.py:267)
       w.mt = c.wrap_mt_state + i;
       w.mt_stride = c.n_lanes;
       w.mt_pos = c.wrap_mt_pos[i];
       w.mt_has_gauss = c.wrap_mt_has_gauss[i];
       w.mt_gauss = c.wrap_mt_gauss[i];
-      const double z = bsx_normal(&w);
+      z = bsx_normal(&w);
       c.wrap_mt_pos[i] = w.mt_pos;
       c.wrap_mt_has_gauss[i] = w.mt_has_gauss;
       c.wrap_mt_gauss[i] = w.mt_gauss;
-      return reward + c.wrap_param * z;
+    } else {
+      z = bsx_normal(&w);
     }
-    return reward + c.wrap_param * bsx_normal(&w);
+    reward = reward + sigma * z;
+    if (c.wrap_kind == BSX_WRAP_NOISE_SCALE) reward = reward * c.wrap_param2;
+    return reward;
   }
   return reward;
 }

@@ -20,11 +20,11 @@ static inline int bsx_check_call(const bsx_call_t* call, const void* action, con
     return BSX_ENULL;
   if (action == nullptr && !call->force_reset) return BSX_ENULL;
   if ((reinterpret_cast<uintptr_t>(out.observation) & 15u) != 0) return BSX_EALIGN;
-  if (call->wrap.kind < BSX_WRAP_NONE || call->wrap.kind > BSX_WRAP_NOISE) return BSX_EINVAL;
+  if (call->wrap.kind < BSX_WRAP_NONE || call->wrap.kind > BSX_WRAP_NOISE_SCALE) return BSX_EINVAL;
   if (call->n_steps < 0 || (call->n_steps > 1 && call->force_reset)) return BSX_EINVAL;
   if ((call->stream.mt_state == nullptr) != (call->stream.mt_pos == nullptr)) return BSX_ENULL;
   if ((call->stream.mt_gauss == nullptr) != (call->stream.mt_has_gauss == nullptr)) return BSX_ENULL;
-  if (call->stream.mt_state != nullptr && call->wrap.kind == BSX_WRAP_NOISE &&
+  if (call->stream.mt_state != nullptr && call->wrap.kind >= BSX_WRAP_NOISE &&
       (call->wrap.mt_state == nullptr || call->wrap.mt_pos == nullptr || call->wrap.mt_gauss == nullptr ||
        call->wrap.mt_has_gauss == nullptr))
     return BSX_ENULL;                      // MT19937-exact RewardNoise needs the wrapper's own generator
@@ -49,6 +49,7 @@ static inline bsx_ctl bsx_make_ctl(const bsx_call_t* call) {
   c.step_base = call->stream.step_base;
   c.counters = call->counters;
   c.wrap_param = call->wrap.param;
+  c.wrap_param2 = call->wrap.param2;
   c.wrap_seed = call->wrap.seed;
   c.wrap_kind = call->wrap.kind;
   c.force_reset = call->force_reset;
@@ -56,7 +57,7 @@ static inline bsx_ctl bsx_make_ctl(const bsx_call_t* call) {
   c.mt_pos = call->stream.mt_pos;
   c.mt_gauss = call->stream.mt_gauss;
   c.mt_has_gauss = call->stream.mt_has_gauss;
-  const bool wrap_mt = call->stream.mt_state != nullptr && call->wrap.kind == BSX_WRAP_NOISE;
+  const bool wrap_mt = call->stream.mt_state != nullptr && call->wrap.kind >= BSX_WRAP_NOISE;
   c.wrap_mt_state = wrap_mt ? call->wrap.mt_state : nullptr;
   c.wrap_mt_pos = wrap_mt ? call->wrap.mt_pos : nullptr;
   c.wrap_mt_gauss = wrap_mt ? call->wrap.mt_gauss : nullptr;
@@ -83,7 +84,7 @@ static inline int bsx_launch_advance(const typename Fam::args& a, hipStream_t st
   const int64_t blocks = (a.ctl.n_lanes + BSX_BLOCK - 1) / BSX_BLOCK;
   if (blocks > 0x7FFFFFFF) return BSX_EINVAL;
   static const int lean_env = bsx_env_int("BSX_ADVANCE_LEAN", 1);
-  const bool lean = lean_env != 0 && a.ctl.log.steps == nullptr && a.ctl.wrap_kind != BSX_WRAP_NOISE &&
+  const bool lean = lean_env != 0 && a.ctl.log.steps == nullptr && a.ctl.wrap_kind < BSX_WRAP_NOISE &&
                     a.ctl.mt_state == nullptr;
   if (lean) bsx_advance_kernel<Fam, true><<<dim3((unsigned)blocks), dim3(BSX_BLOCK), 0, st>>>(a);
   else bsx_advance_kernel<Fam, false><<<dim3((unsigned)blocks), dim3(BSX_BLOCK), 0, st>>>(a);

@@ -200,7 +200,7 @@ template <class Env>
 static int launch_small_obs(const typename Env::args& a, int numel, int n_steps, void* hip_stream) {
   hipStream_t st = (hipStream_t)hip_stream;
   if (n_steps < 1) return BSX_EINVAL;
-  const bool logging = a.ctl.log.steps != nullptr, noise = a.ctl.wrap_kind == BSX_WRAP_NOISE;
+  const bool logging = a.ctl.log.steps != nullptr, noise = a.ctl.wrap_kind >= BSX_WRAP_NOISE;
   const bool lean = !logging && !noise && a.ctl.mt_state == nullptr;
   // rows of 1 float, 3 floats or an even number <= 8: per-thread stores (4-byte / 12-byte / 8-byte stores,
   // each wave writing one contiguous range), no LDS tile, no barrier — measured on bandit,

@@ -105,7 +105,7 @@ class Environment(dm_env.EnvironmentBase):
         self._mt_seeds = [int(x) for x in seed]
         if len(self._mt_seeds) != self._batch:
           raise ValueError('need one seed per lane')
-    self._wrap = (_native.WRAP_NONE, 0.0, 0)
+    self._wrap = (_native.WRAP_NONE, 0.0, 0, 0.0)   # fused reward epilogue: kind, param, wrapper seed, param2
     self._wrap_mt_seeds = None         # rng='mt19937' + RewardNoise: the wrapper's own RandomState seeds
     self._wrap_mt = None
     self._logging = None
@@ -192,8 +192,8 @@ class Environment(dm_env.EnvironmentBase):
       raise ValueError("grouped launches write dense observations; use observation_mode='dense'")
     call = self._call_desc
     call.force_reset, call.n_steps = 0, 0
-    kind, param, wseed = self._wrap
-    call.wrap.kind, call.wrap.param, call.wrap.seed = kind, param, wseed
+    kind, param, wseed, param2 = self._wrap
+    call.wrap.kind, call.wrap.param, call.wrap.seed, call.wrap.param2 = kind, param, wseed, param2
     call.stream.step_index = 0
     self._buf = 1 % self._num_buffers
     return getattr(_native.lib, f'bsx_group_set_{self._abi_name}')(
@@ -291,7 +291,7 @@ class Environment(dm_env.EnvironmentBase):
         stream=_native.Stream(self._seed, self._lane_offset, 0,
                               self._step_base.data_ptr() if self._device_step_counter else None,
                               mt_state_ptr, mt_pos_ptr, mt_gauss_ptr, mt_has_ptr),
-        wrap=_native.RewardWrap(_native.WRAP_NONE, 0, 0.0, 0, None, None, None, None),
+        wrap=_native.RewardWrap(_native.WRAP_NONE, 0, 0.0, 0, None, None, None, None, 0.0),
         counters=self._counters.data_ptr(), hip_stream=None)
     if self._reward_f64 is not None:
       self._call_desc.reward_f64 = self._reward_f64.data_ptr()
@@ -314,8 +314,8 @@ class Environment(dm_env.EnvironmentBase):
     self._buf = (self._buf + 1) % self._num_buffers
     call = self._call_desc
     call.force_reset = 1 if force_reset else 0
-    kind, param, wseed = self._wrap
-    call.wrap.kind, call.wrap.param, call.wrap.seed = kind, param, wseed
+    kind, param, wseed, param2 = self._wrap
+    call.wrap.kind, call.wrap.param, call.wrap.seed, call.wrap.param2 = kind, param, wseed, param2
     hip_stream = torch.cuda.current_stream(self._device).cuda_stream
     call.hip_stream = hip_stream
     if self._device_step_counter and self._deferred_steps is not None:
@@ -488,8 +488,8 @@ class Environment(dm_env.EnvironmentBase):
     call = self._call_desc
     call.force_reset = 0
     call.n_steps = T
-    kind, param, wseed = self._wrap
-    call.wrap.kind, call.wrap.param, call.wrap.seed = kind, param, wseed
+    kind, param, wseed, param2 = self._wrap
+    call.wrap.kind, call.wrap.param, call.wrap.seed, call.wrap.param2 = kind, param, wseed, param2
     hip_stream = torch.cuda.current_stream(self._device).cuda_stream
     call.hip_stream = hip_stream
     try:
@@ -607,7 +607,7 @@ class Environment(dm_env.EnvironmentBase):
         for k, v in self._wrap_mt.items():
           v.copy_(d['__wrap_mt_' + k])
     if '__wrap' in d:
-      self._wrap = tuple(d['__wrap'])
+      self._wrap = (tuple(d['__wrap']) + (0.0,))[:4]
     has_log = '__logging_steps' in d
     if has_log != (self._logging is not None):
       raise ValueError('state_dict was taken %s the Logging wrapper but this environment runs %s it: '

@@ -30,11 +30,16 @@ from bsuite_amd.environments import base
 class _RewardWrapper(dm_env.EnvironmentBase):
   """Shared surface of the two reward wrappers."""
 
-  def __init__(self, env: base.Environment):
-    if not isinstance(env, base.Environment):
+  def __init__(self, env):
+    # `env` is an engine environment or another wrapper around one: the reference composes its wrappers
+    # freely (utils/wrappers_test.py:123-131 stacks RewardNoise on RewardScale); here every reward
+    # wrapper in the stack folds into the ONE fused epilogue of the raw environment's kernel.
+    raw = env.raw_env if hasattr(env, 'raw_env') else env
+    if not isinstance(raw, base.Environment):
       raise TypeError('bsuite_amd reward wrappers fuse into a bsuite_amd environment kernel; got '
                       f'{type(env).__name__}')
     self._env = env
+    self._raw = raw
 
   def reset(self):
     return self._env.reset()
@@ -83,20 +88,29 @@ class RewardNoise(_RewardWrapper):
     # here that is stream_id 1 of the draw stream, keyed by this seed.  In the MT19937-exact mode it
     # IS a second np.random.RandomState per lane (lane i: seed + i, or seed[i] for a sequence), whose
     # legacy randn the kernels reproduce bit for bit (include/bsx_stream.h bsx_mt_gauss).
-    if getattr(env, '_rng_mode', 'philox') == 'mt19937':
+    raw = self._raw
+    if getattr(raw, '_rng_mode', 'philox') == 'mt19937':
       if seed is None:
-        seeds = list(env._mt_seeds)  # pylint: disable=protected-access
+        seeds = list(raw._mt_seeds)  # pylint: disable=protected-access
       elif isinstance(seed, (int, np.integer)):
-        seeds = [(int(seed) + i) & 0xFFFFFFFF for i in range(env.batch_size)]
+        seeds = [(int(seed) + i) & 0xFFFFFFFF for i in range(raw.batch_size)]
       else:
         seeds = [int(x) for x in seed]
-        if len(seeds) != env.batch_size:
+        if len(seeds) != raw.batch_size:
           raise ValueError('need one wrapper seed per lane')
-      env._set_wrap_mt_seeds(seeds)  # pylint: disable=protected-access
+      raw._set_wrap_mt_seeds(seeds)  # pylint: disable=protected-access
       wrap_seed = seeds[0]
     else:
-      wrap_seed = env.seed if seed is None else int(seed)
-    env._wrap = (_native.WRAP_NOISE, float(noise_scale), wrap_seed & ((1 << 63) - 1))  # pylint: disable=protected-access
+      wrap_seed = raw.seed if seed is None else int(seed)
+    wrap_seed &= (1 << 63) - 1
+    kind, param, _, _ = raw._wrap  # pylint: disable=protected-access
+    if kind == _native.WRAP_NONE:
+      raw._wrap = (_native.WRAP_NOISE, float(noise_scale), wrap_seed, 0.0)  # pylint: disable=protected-access
+    elif kind == _native.WRAP_SCALE:          # RewardNoise(RewardScale(env)): r*s + sigma*z
+      raw._wrap = (_native.WRAP_SCALE_NOISE, param, wrap_seed, float(noise_scale))  # pylint: disable=protected-access
+    else:
+      raise NotImplementedError('the fused reward epilogue holds one RewardNoise and one RewardScale; '
+                                'this environment already carries a RewardNoise')
 
 
 class RewardScale(_RewardWrapper):
@@ -106,7 +120,15 @@ class RewardScale(_RewardWrapper):
     super().__init__(env)
     self._reward_scale = reward_scale
     del seed  # the reference builds an unused RandomState (wrappers.py:330)
-    env._wrap = (_native.WRAP_SCALE, float(reward_scale), 0)  # pylint: disable=protected-access
+    raw = self._raw
+    kind, param, wseed, _ = raw._wrap  # pylint: disable=protected-access
+    if kind == _native.WRAP_NONE:
+      raw._wrap = (_native.WRAP_SCALE, float(reward_scale), 0, 0.0)  # pylint: disable=protected-access
+    elif kind == _native.WRAP_NOISE:          # RewardScale(RewardNoise(env)): (r + sigma*z)*s
+      raw._wrap = (_native.WRAP_NOISE_SCALE, param, wseed, float(reward_scale))  # pylint: disable=protected-access
+    else:
+      raise NotImplementedError('the fused reward epilogue holds one RewardNoise and one RewardScale; '
+                                'this environment already carries a RewardScale')
 
 
 # Keys that are present for all experiments (wrappers.py:30-31).

@@ -69,18 +69,22 @@ typedef struct {
 #define BSX_WRAP_NONE 0
 #define BSX_WRAP_SCALE 1
 #define BSX_WRAP_NOISE 2
+/* the two wrappers stacked (the reference composes them freely, utils/wrappers_test.py:123-131):       */
+#define BSX_WRAP_SCALE_NOISE 3   /* RewardNoise(RewardScale(env)): r * param  + param2 * randn()          */
+#define BSX_WRAP_NOISE_SCALE 4   /* RewardScale(RewardNoise(env)): (r + param * randn()) * param2        */
 typedef struct {
   int32_t kind;
   int32_t _pad;
-  double param;        /* reward_scale or noise_scale (sigma)                                   */
+  double param;        /* reward_scale or noise_scale (sigma); stacked kinds: the INNER wrapper's        */
   uint64_t seed;       /* key of the wrapper's own stream (RewardNoise has its own RNG, :267)   */
   /* MT19937-exact mode (ABI v8): RewardNoise owns a second np.random.RandomState(seed) per lane
    * (wrappers.py:267) that only ever draws randn; same layout as the bsx_stream_t members.  All four
-   * non-NULL when kind == BSX_WRAP_NOISE and stream.mt_state != NULL, else ignored.             */
+   * non-NULL when kind involves noise (>= BSX_WRAP_NOISE) and stream.mt_state != NULL, else ignored.             */
   uint32_t* mt_state;
   int32_t* mt_pos;
   double* mt_gauss;
   int32_t* mt_has_gauss;
+  double param2;       /* stacked kinds: the OUTER wrapper's parameter                                  */
 } bsx_reward_wrap_t;
 
 /* The batched dm_env.TimeStep, written in full on every call (dense contract). */

@@ -17,7 +17,9 @@ _SO = os.path.join(_HERE, 'liboracle.so')
 _SRC = os.path.join(_HERE, 'oracle.c')
 
 FIRST, MID, LAST = 0, 1, 2
-WRAP = {None: 0, 'scale': 1, 'noise': 2}
+WRAP = {None: 0, 'scale': 1, 'noise': 2,
+        'scale_noise': 3,     # RewardNoise(RewardScale(env)): wrap = ('scale_noise', scale, sigma)
+        'noise_scale': 4}     # RewardScale(RewardNoise(env)): wrap = ('noise_scale', sigma, scale)
 
 
 def build(force=False):
@@ -33,7 +35,7 @@ class _Call(ctypes.Structure):
               ('wrap_kind', ctypes.c_int32), ('wrap_param', ctypes.c_double),
               ('wrap_seed', ctypes.c_uint64), ('action', ctypes.c_void_p),
               ('step_type', ctypes.c_void_p), ('reward', ctypes.c_void_p),
-              ('discount', ctypes.c_void_p), ('obs', ctypes.c_void_p)]
+              ('discount', ctypes.c_void_p), ('obs', ctypes.c_void_p), ('wrap_param2', ctypes.c_double)]
 
 
 class _CartpoleCfg(ctypes.Structure):
@@ -217,9 +219,10 @@ class OracleEnv:
     assert actions.shape == (self.B,)
     kind = WRAP[self.wrap[0]] if self.wrap else 0
     param = float(self.wrap[1]) if self.wrap else 0.0
+    param2 = float(self.wrap[2]) if self.wrap and len(self.wrap) > 2 else 0.0
     c = _Call(self.B, _p(self.lane_ids), self.seed, int(step), int(bool(force_reset)), kind, param,
               self.wrap_seed, _p(actions), _p(self.step_type), _p(self.reward), _p(self.discount),
-              _p(self.obs))
+              _p(self.obs), param2)
     self._fn(ctypes.byref(c))
     return self.step_type, self.reward, self.discount, self.obs
 

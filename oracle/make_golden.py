@@ -57,11 +57,19 @@ def _make_env(bs, family, kwargs, wrap, wrap_seed=None):
     warnings.simplefilter('ignore')
     env = ctor(**kwargs)
   if wrap is not None:
-    kind, param = wrap
+    kind, param = wrap[0], wrap[1]
     if kind == 'noise':
       env = wrappers.RewardNoise(env=env, noise_scale=param, seed=wrap_seed)
-    else:
+    elif kind == 'scale':
       env = wrappers.RewardScale(env=env, reward_scale=param, seed=wrap_seed)
+    elif kind == 'scale_noise':      # the reference composes its wrappers freely (utils/wrappers_test.py:123-131)
+      env = wrappers.RewardNoise(env=wrappers.RewardScale(env=env, reward_scale=param, seed=wrap_seed),
+                                 noise_scale=wrap[2], seed=wrap_seed)
+    elif kind == 'noise_scale':
+      env = wrappers.RewardScale(env=wrappers.RewardNoise(env=env, noise_scale=param, seed=wrap_seed),
+                                 reward_scale=wrap[2], seed=wrap_seed)
+    else:
+      raise KeyError(kind)
   return env
 
 
@@ -334,6 +342,11 @@ def cases():
   add('mt_deep_sea_stochastic_noise', 'deep_sea', dict(size=5, deterministic=False, mapping_seed=1), SEEDS[:4], 40,
       wrap=('noise', 0.3), policies=ds_pol, **mt)
   add('mt_logging_catch_noise', 'catch', dict(), SEEDS[:4], 120, wrap=('noise', 1.0), log='by_episode', **mt)
+  # both wrappers stacked, either order (replay stream and the reference's own generators)
+  add('catch_scale_then_noise', 'catch', dict(), LANES[:4], 60, wrap=('scale_noise', 30.0, 0.5), policies=['optimal'])
+  add('bandit_noise_then_scale', 'bandit', dict(mapping_seed=2), LANES[:4], 40, wrap=('noise_scale', 0.3, 0.001))
+  add('mt_catch_scale_then_noise', 'catch', dict(), SEEDS[:4], 60, wrap=('scale_noise', 0.03, 1.0), **mt)
+  add('mt_cartpole_noise_then_scale', 'cartpole', dict(), SEEDS[:3], 120, wrap=('noise_scale', 0.1, 30.0), **mt)
   return c
 
 

@@ -138,7 +138,7 @@ void orc_normals(const uint64_t* k, int64_t n, double* out) {
 
 /* ------------------------------------------------------------------ call plumbing */
 enum { FIRST = 0, MID = 1, LAST = 2 };
-enum { WRAP_NONE = 0, WRAP_SCALE = 1, WRAP_NOISE = 2 };
+enum { WRAP_NONE = 0, WRAP_SCALE = 1, WRAP_NOISE = 2, WRAP_SCALE_NOISE = 3, WRAP_NOISE_SCALE = 4 };
 
 typedef struct {
   int64_t n_lanes;
@@ -154,6 +154,7 @@ typedef struct {
   double* reward;             /* NaN where the reference returns None */
   double* discount;           /* NaN where the reference returns None */
   float* obs;                 /* [n_lanes, obs_numel] */
+  double wrap_param2;         /* stacked wrappers: the outer wrapper's parameter */
 } orc_call;
 
 static void emit(const orc_call* c, int64_t i, int type, double reward) {
@@ -168,6 +169,14 @@ static void emit(const orc_call* c, int64_t i, int type, double reward) {
     reward = reward + c->wrap_param * draw_normal(&w);
   } else if (c->wrap_kind == WRAP_SCALE) {
     reward = reward * c->wrap_param;
+  } else if (c->wrap_kind == WRAP_SCALE_NOISE) {          /* RewardNoise(RewardScale(env)): inner first */
+    draws_t w; draws_begin(&w, c->wrap_seed, c->lane_ids[i], c->step, 1);
+    reward = reward * c->wrap_param;
+    reward = reward + c->wrap_param2 * draw_normal(&w);
+  } else if (c->wrap_kind == WRAP_NOISE_SCALE) {          /* RewardScale(RewardNoise(env)) */
+    draws_t w; draws_begin(&w, c->wrap_seed, c->lane_ids[i], c->step, 1);
+    reward = reward + c->wrap_param * draw_normal(&w);
+    reward = reward * c->wrap_param2;
   }
   c->reward[i] = reward;
   c->discount[i] = (type == LAST) ? 0.0 : 1.0;   /* dm_env.termination / transition */

@@ -74,11 +74,13 @@ def attach_replay(env, seed, lane, wrap_seed=None):
   """Swap the reference env's RandomState(s) for replays; returns the list to `begin_step` on."""
   rngs = []
   inner = env
-  if hasattr(env, '_env') and hasattr(env, '_rng'):  # RewardNoise / RewardScale wrapper (utils/wrappers.py:250,313)
+  while hasattr(inner, '_env') and hasattr(inner, '_rng'):  # RewardNoise / RewardScale wrappers, possibly stacked
+    # (utils/wrappers.py:250,313).  Only RewardNoise draws; every wrapper of a stack replays the one
+    # wrapper stream (RewardScale's generator is never used, wrappers.py:330).
     w = ReplayRNG(seed if wrap_seed is None else wrap_seed, lane, S.STREAM_WRAP)
-    env._rng = w  # pylint: disable=protected-access
+    inner._rng = w  # pylint: disable=protected-access
     rngs.append(w)
-    inner = env._env  # pylint: disable=protected-access
+    inner = inner._env  # pylint: disable=protected-access
   r = ReplayRNG(seed, lane, S.STREAM_ENV)
   inner._rng = r  # pylint: disable=protected-access
   rngs.append(r)

@@ -23,12 +23,23 @@ def make_env(family, kwargs, batch, lane_offset, seed, wrap=None, num_buffers=1,
     env = CTORS[family](**kw, seed=seed, batch=batch, lane_offset=lane_offset,
                         num_buffers=num_buffers, **engine_kwargs)
   if wrap:
-    kind, param = wrap
-    if kind == 'noise':
-      env = wrappers.RewardNoise(env, noise_scale=param, seed=seed)
-    else:
-      env = wrappers.RewardScale(env, reward_scale=param, seed=seed)
+    env = apply_wrap(env, wrap, seed)
   return env
+
+
+def apply_wrap(env, wrap, seed):
+  """wrap: ('noise', sigma) | ('scale', s) | ('scale_noise', s, sigma) = RewardNoise(RewardScale(env)) |
+  ('noise_scale', sigma, s) = RewardScale(RewardNoise(env)) — the reference composes them freely."""
+  kind = wrap[0]
+  if kind == 'noise':
+    return wrappers.RewardNoise(env, noise_scale=wrap[1], seed=seed)
+  if kind == 'scale':
+    return wrappers.RewardScale(env, reward_scale=wrap[1], seed=seed)
+  if kind == 'scale_noise':
+    return wrappers.RewardNoise(wrappers.RewardScale(env, reward_scale=wrap[1], seed=seed), noise_scale=wrap[2], seed=seed)
+  if kind == 'noise_scale':
+    return wrappers.RewardScale(wrappers.RewardNoise(env, noise_scale=wrap[1], seed=seed), reward_scale=wrap[2], seed=seed)
+  raise KeyError(kind)
 
 
 def raw(env):

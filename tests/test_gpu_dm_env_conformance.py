@@ -124,3 +124,35 @@ def test_wrappers_keep_the_reference_surface():
     if not ts.first():
       rewards.append(ts.reward)
   assert len(set(rewards)) > 5                               # noise_scale 0.1 perturbs every reward
+
+
+def test_reward_wrappers_stack_like_the_reference():
+  """utils/wrappers_test.py:123-131 (`test_unwrap`): RewardNoise(RewardScale(env)) under Logging unwraps to
+  the raw environment; both stacking orders fold into the one fused epilogue; a second wrapper of the
+  same kind is refused (the epilogue holds one of each)."""
+  from bsuite_amd.utils import wrappers
+  raw_env = catch.Catch(seed=3)
+  scale_env = wrappers.RewardScale(raw_env, reward_scale=30.)
+  noise_env = wrappers.RewardNoise(scale_env, noise_scale=1., seed=3)
+  logging_env = wrappers.Logging(noise_env, logger=None)
+  assert logging_env.raw_env is raw_env and noise_env.raw_env is raw_env
+  plain = catch.Catch(seed=3)
+  only_noise = wrappers.RewardNoise(catch.Catch(seed=3), noise_scale=1., seed=3)
+  rs = np.random.RandomState(0)
+  for _ in range(40):
+    a = int(rs.randint(3))
+    ts, tp, tn = logging_env.step(a), plain.step(a), only_noise.step(a)
+    if not ts.first():
+      z = tn.reward - tp.reward                      # the wrapper stream's draw of this call
+      assert ts.reward == tp.reward * 30. + 1. * z   # r*s + sigma*z, in f64 like the reference
+  other = wrappers.RewardScale(wrappers.RewardNoise(catch.Catch(seed=3), noise_scale=1., seed=3), reward_scale=30.)
+  plain2, noise2 = catch.Catch(seed=3), wrappers.RewardNoise(catch.Catch(seed=3), noise_scale=1., seed=3)
+  for _ in range(40):
+    a = int(rs.randint(3))
+    ts, tp, tn = other.step(a), plain2.step(a), noise2.step(a)
+    if not ts.first():
+      assert ts.reward == tn.reward * 30.            # (r + sigma*z) * s
+  with pytest.raises(NotImplementedError):
+    wrappers.RewardScale(scale_env, reward_scale=2.)
+  with pytest.raises(NotImplementedError):
+    wrappers.RewardNoise(noise_env, noise_scale=2.)

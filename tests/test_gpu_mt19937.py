@@ -32,9 +32,7 @@ def test_engine_reproduces_reference_on_its_own_rng(name):
     warnings.simplefilter('ignore')
     env = eu.CTORS[fam](**kwargs, seed=seeds, batch=n, rng='mt19937', num_buffers=1)
   if meta['wrap']:       # the <exp>_noise / _scale loaders give the wrapper the environment's seed
-    kind, param = meta['wrap']
-    env = (wrappers.RewardNoise(env, noise_scale=param, seed=seeds) if kind == 'noise'
-           else wrappers.RewardScale(env, reward_scale=param))
+    env = eu.apply_wrap(env, tuple(meta['wrap']), seeds)
   logged = None
   if meta.get('log'):
     env = logged = wrappers.Logging(env, None, max_rows=g['log_rows'].shape[1] + 2)
