@@ -8,13 +8,16 @@ independent, so:
 * across GPUs — whole segments are bin-packed onto ranks by `lanes x bytes-per-step` (longest
   processing time first); no communication per step; summaries are all-gathered at the end
   (`bsuite_amd.distributed`);
-* on one GPU — **grouped launches** (`prepare_groups` / `step_grouped`): all segments of one family
-  are advanced by ONE kernel launch (pair); every workgroup finds its segment's arguments —
-  configuration, state columns, output buffers, exactly what `bsx_<family>_step` takes — in a
-  device-resident table (include/bsuite_amd.h `bsx_group_*`).  A sweep step is then ~15 launches
-  instead of ~10^3.  The older path (`capture` / `replay`) spreads per-segment launches over HIP
-  streams and replays them as one HIP graph.  Either way call indices of the draw stream live in
-  one device-resident counter bumped once per sweep step, so steps stay reproducible.
+* on one GPU — **grouped launches** (`prepare_groups` / `step_grouped`): every workgroup finds its
+  segment's arguments — configuration, state columns, output buffers, exactly what
+  `bsx_<family>_step` takes — in a device-resident table (include/bsuite_amd.h `bsx_group_*`).  By
+  default the whole sweep is ONE group (`BSX_FAM_SWEEP_MIXED`) and a sweep step is TWO launches: phase 0
+  advances every lane of every family and bumps the shared call counter, phase 1 is the observation
+  store stream of deep_sea / catch / mnist.  The finer-grained groups (one per family,
+  mixed small families, mixed two-kernel families) and other schedules (`step_grouped_streams`,
+  `capture_grouped`) are kept for A/B; the oldest path (`capture` / `replay`) spreads per-segment
+  launches over HIP streams and replays them as one HIP graph.  Call indices of the draw stream live
+  in one device-resident counter, so steps stay reproducible.
 
 Global lane ids are unique across the sweep (segment k starts where segment k-1 ended), so any
 assignment of segments to ranks reproduces the same per-lane trajectories.
