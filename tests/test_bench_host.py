@@ -1,0 +1,61 @@
+"""CPU: the host-side pieces of bench.py — byte accounting, the shardable synthetic action
+stream, the reference CPU baseline record, and the self-launch refusal without devices."""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import bench  # noqa: E402
+
+
+def test_algorithmic_bytes_match_the_survey():
+  # deep_sea N=30 3621 B, catch 10x5 221 B, cartpole 85 B, mountain_car 49 B
+  for w, want in (('deep_sea', 3621), ('catch', 221), ('cartpole', 85), ('mountain_car', 49)):
+    _, _, _, numel, state_bytes, _ = bench.WORKLOADS[w]
+    assert bench.algorithmic_bytes_per_step(numel, state_bytes) == want
+
+
+def test_synthetic_actions_are_a_function_of_global_lane_and_step():
+  dev = torch.device('cpu')
+  full = bench.synthetic_actions(torch, 3, 32, 0, 4096, dev)
+  assert full.dtype == torch.int32 and full.shape == (32, 4096)
+  assert int(full.min()) == 0 and int(full.max()) == 2
+  # any sharding sees the same per-lane sequences
+  a = bench.synthetic_actions(torch, 3, 32, 0, 1000, dev)
+  b = bench.synthetic_actions(torch, 3, 32, 1000, 3096, dev)
+  assert torch.equal(torch.cat([a, b], dim=1), full)
+  # and they are close to uniform, per step and per lane
+  counts = torch.bincount(full.flatten().long(), minlength=3).double() / full.numel()
+  assert float((counts - 1 / 3).abs().max()) < 0.01
+  per_step = torch.stack([torch.bincount(full[t].long(), minlength=3) for t in range(32)]).double() / 4096
+  assert float((per_step - 1 / 3).abs().max()) < 0.04
+  big = bench.synthetic_actions(torch, 11, 4, (1 << 20) * 7, 8, dev)          # lane offsets of an 8-GPU run
+  assert int(big.min()) >= 0 and int(big.max()) <= 10
+
+
+def test_reference_cpu_baseline_record_is_committed_and_consistent():
+  import glob
+  hits = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*', 'cpu_reference_numpy.json')))
+  assert hits, 'tools/cpu_reference_numpy.py output missing'
+  d = json.load(open(hits[-1]))
+  for bid in ('deep_sea/10', 'catch/0', 'cartpole/0', 'mountain_car/0'):
+    rec = d['results'][bid]
+    assert 2e4 < rec['single_core']['value'] < 2e6                     # the numpy reference: ~1e5 env-steps/s per core
+    assert rec['all_cores']['cores'] == d['host']['cores'] >= 1
+    assert rec['all_cores']['value'] > rec['single_core']['value'] * 0.8
+
+
+def test_self_launch_refuses_when_devices_are_missing():
+  if torch.cuda.is_available() and torch.cuda.device_count() >= 2:
+    return
+  env = dict(os.environ)
+  env.pop('WORLD_SIZE', None)
+  env.pop('BSX_BENCH_SINGLE_DEVICE', None)
+  p = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2'], env=env, stdout=subprocess.PIPE,
+                     stderr=subprocess.PIPE, text=True, timeout=300)
+  assert p.returncode != 0 and 'HIP device' in (p.stderr + p.stdout)
