@@ -44,6 +44,8 @@ WORKLOADS = {
     'bandit': ('bandit/0', 'bandit', dict(mapping_seed=0), 1, 8, 2),
     'memory_len': ('memory_len/10', 'memory_chain', dict(memory_length=12, num_bits=1), 3, 24, 14),
     'umbrella_length': ('umbrella_length/10', 'umbrella_chain', dict(chain_length=12, n_distractor=20), 23, 8, 13),
+    'umbrella_distract': ('umbrella_distract/22', 'umbrella_chain', dict(chain_length=20, n_distractor=100), 103, 8, 21),
+    'memory_size': ('memory_size/16', 'memory_chain', dict(memory_length=2, num_bits=40), 42, 24, 4),
     'discounting_chain': ('discounting_chain/0', 'discounting_chain', dict(mapping_seed=0), 2, 8, 101),
     # the MNIST files cannot be fetched here: tests/golden/mnist_synthetic_dataset.npz (same idx wire format)
     'mnist': ('mnist/0', 'mnist', dict(), 784, 8, 2),

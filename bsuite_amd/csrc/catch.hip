@@ -69,7 +69,7 @@ extern "C" int bsx_group_set_catch(bsx_group_t* g, int32_t index, const bsx_catc
     bsx_stream_seg<catch_hot> sg;
     sg.obs = out.observation; sg.state = state; sg.n_lanes = a.ctl.n_lanes; sg.cells = cells;
     sg.cells_magic = bsx_div_magic(cells); sg.dv = bsx_make_div64(cells); sg.fn = catch_hot{cfg->rows, cfg->columns};
-    return bsx_mixed_put(g, BSX_FAM_CATCH, 256, index, call, &a, sizeof(a), &sg, sizeof(sg),
+    return bsx_mixed_put(g, BSX_FAM_CATCH, index, call, &a, sizeof(a), &sg, sizeof(sg),
                               (uint64_t)(a.ctl.n_lanes + BSX_BLOCK - 1) / BSX_BLOCK,
                               bsx_flat_blocks((uint64_t)a.ctl.n_lanes * cells, 2), 0);
   }

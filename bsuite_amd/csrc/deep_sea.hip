@@ -83,7 +83,7 @@ extern "C" int bsx_group_set_deep_sea(bsx_group_t* g, int32_t index, const bsx_d
     bsx_stream_seg<deep_sea_hot> sg;
     sg.obs = out.observation; sg.state = state; sg.n_lanes = a.ctl.n_lanes; sg.cells = cells;
     sg.cells_magic = bsx_div_magic(cells); sg.dv = bsx_make_div64(cells); sg.fn = deep_sea_hot{cfg->size};
-    return bsx_mixed_put(g, BSX_FAM_DEEP_SEA, 256, index, call, &a, sizeof(a), &sg, sizeof(sg),
+    return bsx_mixed_put(g, BSX_FAM_DEEP_SEA, index, call, &a, sizeof(a), &sg, sizeof(sg),
                               (uint64_t)(a.ctl.n_lanes + BSX_BLOCK - 1) / BSX_BLOCK,
                               bsx_flat_blocks((uint64_t)a.ctl.n_lanes * cells, 4), 0);
   }

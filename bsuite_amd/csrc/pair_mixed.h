@@ -9,13 +9,12 @@
 
 #define BSX_MIXED_ADV_STRIDE 1024      // phase-0 argument slot (advance args of a pair family, or a small family's args)
 #define BSX_MIXED_STR_STRIDE 1280      // phase-1 argument slot (observation stream args of a pair family)
-#define BSX_MIXED_TAG_LPB64 0x100      // tag = family | this bit: small-observation segment with 64-lane tiles
 
 // Records one segment in a BSX_FAM_PAIR_MIXED / BSX_FAM_SWEEP_MIXED group.  `adv`: the segment's phase-0
 // argument struct; `str`: its observation-stream argument struct (NULL for the small-observation families,
 // which have no phase 1); both are copied verbatim into fixed-stride slots of the group's device tables.
-// `lpb`: 256 or 64 lanes per phase-0 workgroup; `lds`: dynamic LDS the segment's phase-0 workgroups need.
-int bsx_mixed_put(bsx_group* g, int32_t family, int32_t lpb, int32_t index, const bsx_call_t* call,
+// `lds`: dynamic LDS the segment's phase-0 workgroups need (packed observation records, small_obs.hip).
+int bsx_mixed_put(bsx_group* g, int32_t family, int32_t index, const bsx_call_t* call,
                   const void* adv, size_t adv_size, const void* str, size_t str_size,
                   uint64_t blocks1, uint64_t blocks2, size_t lds);
 

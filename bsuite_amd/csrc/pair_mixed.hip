@@ -89,7 +89,7 @@ static int sweep_mixed_launch(bsx_group* g, int phase, hipStream_t st) {
   return rc;
 }
 
-int bsx_mixed_put(bsx_group* g, int32_t family, int32_t lpb, int32_t index, const bsx_call_t* call,
+int bsx_mixed_put(bsx_group* g, int32_t family, int32_t index, const bsx_call_t* call,
                   const void* adv, size_t adv_size, const void* str, size_t str_size,
                   uint64_t blocks1, uint64_t blocks2, size_t lds) {
   if (g == nullptr || !bsx_is_mixed_pair_group(g)) return BSX_EINVAL;
@@ -105,7 +105,7 @@ int bsx_mixed_put(bsx_group* g, int32_t family, int32_t lpb, int32_t index, cons
   memcpy(&g->args[(size_t)index * PAIR_ADV_STRIDE], adv, adv_size);
   if (str != nullptr) memcpy(&g->args2[(size_t)index * PAIR_STR_STRIDE], str, str_size);
   if (g->tags.empty()) g->tags.assign((size_t)g->n, -1);
-  g->tags[index] = family | (lpb == 64 ? BSX_MIXED_TAG_LPB64 : 0);
+  g->tags[index] = family;
   g->blocks[index] = (int32_t)blocks1; g->blocks2[index] = (int32_t)blocks2;
   if (lds > g->lds_bytes) g->lds_bytes = lds;
   g->is_set[index] = 1;

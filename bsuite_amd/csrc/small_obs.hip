@@ -28,29 +28,49 @@
 // LOG / NOISE / MT: -1 = decide at run time, 0 = compiled out, 1 = always on.  The common call (no
 // Logging wrapper, no RewardNoise, counter-based draws) runs the <0,0,0> instantiation: without the
 // MT19937 twist, the f64 normal transform and the row snapshots the kernel is a fifth of the size.
-template <class Env, int LPB, bool ROLLOUT, int LOG, int NOISE, int MT, bool DIRECT = false>
+//
+// Two ways for a row to reach HBM:
+//   DIRECT  rows of 1, 3 or an even number <= 8 floats: the thread that advances a lane stores its row
+//           itself — no LDS, no barrier.  Every family with a fixed short row (bandit, discounting_chain,
+//           cartpole, mountain_car) always takes it.
+//   PACKED  the families whose row length is a parameter (memory_chain: nb+2, umbrella_chain: 3+nd, up to
+//           256 floats) and whose row is a few floats followed by BITS: the thread leaves a packed record
+//           (Env::rec_words() words: the leading floats verbatim, then the bits 32 to a word) in LDS and,
+//           after one barrier, the block streams the [256 x numel] tile to HBM as consecutive 16-byte
+//           chunks, expanding bits to floats on the way (a lane-per-row store would be a stride-(4*numel)
+//           scatter).  A record is at most 11 words where the f32 row was up to 256: the workgroup's LDS
+//           is <= 11 KiB (was 26-32 KiB with f32 tiles of 64 or 256 lanes), so LDS no longer caps the
+//           resident workgroups per CU — which is what the one-launch sweep phase 0 is bound by.
+__host__ __device__ static inline bool bsx_small_direct_shape(int numel) {
+  return numel <= 8 && (numel == 1 || numel == 3 || (numel & 1) == 0);
+}
+
+template <class Env, bool ROLLOUT, int LOG, int NOISE, int MT, bool DIRECT_ARG>
 __device__ __forceinline__ void small_obs_body(const typename Env::args& a, const int n_steps_arg,
                                                const uint32_t block_id, float* s_obs, unsigned int* s_cnt) {
+  constexpr bool DIRECT = DIRECT_ARG || !Env::PACKED;
   const int n_steps = ROLLOUT ? n_steps_arg : 1;   // the single-step instantiation has no loop: keeping
                                                     // every kernarg live across iterations costs ~120 VGPRs
   if (threadIdx.x < 2) s_cnt[threadIdx.x] = 0;
   __syncthreads();
   const int numel = a.obs_numel;
   const int64_t B = a.ctl.n_lanes;
-  const int64_t lane0 = (int64_t)block_id * LPB;
+  const int64_t lane0 = (int64_t)block_id * BSX_BLOCK;
   const int64_t remaining = B - lane0;
-  const int lanes_here = remaining < LPB ? (int)remaining : LPB;
+  const int lanes_here = remaining < BSX_BLOCK ? (int)remaining : BSX_BLOCK;
   const uint64_t step0 = bsx_step_of(a.ctl);
   // Fused rollout of a family with HAS_REGS: the lane's state lives in registers for the T steps and the
   // action of step t+1 is in flight while step t computes.
   constexpr bool REGS = ROLLOUT && Env::HAS_REGS;
-  const bool mine = (LPB == BSX_BLOCK || threadIdx.x < LPB) && (int)threadIdx.x < lanes_here;
+  const bool mine = (int)threadIdx.x < lanes_here;
+  const int64_t i = lane0 + threadIdx.x;
+  const uint64_t lane = a.ctl.lane_offset + (uint64_t)i;
   typename Env::regs rg;
   int act_next = 0;
   if constexpr (REGS) {
     if (mine) {
-      Env::load(a, lane0 + threadIdx.x, rg);
-      act_next = a.action[lane0 + threadIdx.x];
+      Env::load(a, i, rg);
+      act_next = a.action[i];
     }
   }
 
@@ -59,18 +79,14 @@ __device__ __forceinline__ void small_obs_body(const typename Env::args& a, cons
     int act = 0;
     if constexpr (REGS) {
       act = act_next;
-      if (mine && t + 1 < n_steps) act_next = a.action[(int64_t)(t + 1) * B + lane0 + threadIdx.x];
+      if (mine && t + 1 < n_steps) act_next = a.action[(int64_t)(t + 1) * B + i];
     }
-    if (DIRECT) {
-      // Rows of at most 8 floats: the thread that advances a lane stores its row itself (8-byte stores
-      // when the row length is even) — no LDS tile, no barrier, so the waves of a block (and the steps of
-      // a fused rollout) never wait for each other.  A wave's 64 rows are one contiguous range, written
-      // by back-to-back instructions that the L2 merges line by line.
-      const int64_t i = lane0 + threadIdx.x;
-      int type = -1;
-      if ((int)threadIdx.x < lanes_here) {
-        const uint64_t lane = a.ctl.lane_offset + (uint64_t)i;
-        const int64_t oi = (int64_t)t * B + i;
+    const int64_t oi = (int64_t)t * B + i;
+    int type = -1;
+    if constexpr (DIRECT) {
+      // A wave's 64 rows are one contiguous range, written by back-to-back instructions that the L2 merges
+      // line by line; the waves of a block (and the steps of a fused rollout) never wait for each other.
+      if (mine) {
         double reward = 0.0;
         float o[8];
         if constexpr (REGS) type = Env::template core<LOG, MT>(a, rg, act, i, lane, step0 + (uint64_t)t, o, reward);
@@ -88,63 +104,100 @@ __device__ __forceinline__ void small_obs_body(const typename Env::args& a, cons
           row3 v; v.a = o[0]; v.b = o[1]; v.c = o[2];
           *reinterpret_cast<row3*>(dst) = v;
         } else {
-#pragma unroll
-          for (int k = 0; k < 8; ++k)
-            if (k < numel) dst[k] = o[k];
+          dst[0] = o[0];                                                // numel == 1
         }
       }
       bsx_count_types(a.ctl, type, s_cnt);
-      continue;
-    }
-    if (LPB == BSX_BLOCK || threadIdx.x < LPB) {
-      const int64_t i = lane0 + threadIdx.x;
-      int type = -1;
-      if ((int)threadIdx.x < lanes_here) {
-        const uint64_t lane = a.ctl.lane_offset + (uint64_t)i;
-        const int64_t oi = (int64_t)t * B + i;
+    } else {
+      const int cw = Env::rec_words(a);
+      if (mine) {
         double reward = 0.0;
-        if constexpr (REGS) type = Env::template core<LOG, MT>(a, rg, act, i, lane, step0 + (uint64_t)t, s_obs + (int)threadIdx.x * numel, reward);
-        else type = Env::template step<LOG, MT>(a, i, oi, lane, step0 + (uint64_t)t, s_obs + (int)threadIdx.x * numel, reward);
+        type = Env::template step<LOG, MT, true>(a, i, oi, lane, step0 + (uint64_t)t, s_obs + (int)threadIdx.x * cw, reward);
         bsx_emit_at<LOG, NOISE>(a.ctl, a.out, i, oi, lane, step0 + (uint64_t)t, type, reward);
       }
       bsx_count_types(a.ctl, type, s_cnt);
-    }
-    __syncthreads();
+      __syncthreads();
 
-    // stream the tile: [lanes_here x numel] floats, contiguous in HBM, 16-byte aligned start
-    float* __restrict__ tile = a.out.observation + ((int64_t)t * B + lane0) * (int64_t)numel;
-    const int total = lanes_here * numel;
-    const bool vec = ((((int64_t)t * B * numel) & 3) == 0);            // [t] slice 16-byte aligned?
-    const int n_chunks = vec ? total >> 2 : 0;
-    const bsx_f4* s4 = reinterpret_cast<const bsx_f4*>(s_obs);
-    bsx_f4* __restrict__ t4 = reinterpret_cast<bsx_f4*>(tile);
-    for (int ch = threadIdx.x; ch < n_chunks; ch += BSX_BLOCK) t4[ch] = s4[ch];
-    for (int f = (n_chunks << 2) + (int)threadIdx.x; f < total; f += BSX_BLOCK) tile[f] = s_obs[f];
-    if (t + 1 < n_steps) __syncthreads();                              // tile is rewritten next step
+      // stream the tile: [lanes_here x numel] floats, contiguous in HBM, 16-byte aligned start.  Thread
+      // k owns floats [4k, 4k+4) + multiples of 4*BSX_BLOCK; their (lane, element) split advances by a
+      // constant, so there is one division per thread, not one per chunk.
+      const uint32_t* __restrict__ rec = reinterpret_cast<const uint32_t*>(s_obs);
+      float* __restrict__ tile = a.out.observation + ((int64_t)t * B + lane0) * (int64_t)numel;
+      const int total = lanes_here * numel;
+      const bool vec = ((((int64_t)t * B * numel) & 3) == 0);            // [t] slice 16-byte aligned?
+      const int n_chunks = vec ? total >> 2 : 0;
+      bsx_f4* __restrict__ t4 = reinterpret_cast<bsx_f4*>(tile);
+      const int l0 = (4 * (int)threadIdx.x) / numel;
+      int j = 4 * (int)threadIdx.x - l0 * numel, ro = l0 * cw;          // element in the row, record offset
+      const int dl = (4 * BSX_BLOCK) / numel, dj = 4 * BSX_BLOCK - dl * numel, dro = dl * cw;
+      for (int ch = threadIdx.x; ch < n_chunks; ch += BSX_BLOCK) {
+        // Env::expand is branch-free: the four LDS reads of a chunk are issued together, one wait
+        float v[4];
+        int rr = ro, jj = j;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          v[k] = Env::expand(a, rec + rr, jj);
+          const bool wrap = ++jj == numel;
+          jj = wrap ? 0 : jj;
+          rr = wrap ? rr + cw : rr;
+        }
+        bsx_f4 q; q.x = v[0]; q.y = v[1]; q.z = v[2]; q.w = v[3];
+        t4[ch] = q;
+        j += dj; ro += dro;
+        const bool wrap = j >= numel;
+        j = wrap ? j - numel : j;
+        ro = wrap ? ro + cw : ro;
+      }
+      for (int f = (n_chunks << 2) + (int)threadIdx.x; f < total; f += BSX_BLOCK) {
+        const int fl = f / numel;
+        tile[f] = Env::expand(a, rec + fl * cw, f - fl * numel);
+      }
+      if (t + 1 < n_steps) __syncthreads();                              // records are rewritten next step
+    }
   }
   if constexpr (REGS) {
-    if (mine) Env::store(a, lane0 + threadIdx.x, rg);
+    if (mine) Env::store(a, i, rg);
   }
   __syncthreads();
   bsx_flush_counts(a.ctl, s_cnt, block_id);
 }
 
-template <class Env, int LPB, bool ROLLOUT, int LOG, int NOISE, int MT, bool DIRECT = false>
+template <class Env, bool ROLLOUT, int LOG, int NOISE, int MT, bool DIRECT>
 __global__ void __launch_bounds__(BSX_BLOCK) small_obs_kernel(const typename Env::args a, const int n_steps) {
   extern __shared__ __attribute__((aligned(16))) float s_obs[];
   __shared__ unsigned int s_cnt[2];
-  small_obs_body<Env, LPB, ROLLOUT, LOG, NOISE, MT, DIRECT>(a, n_steps, blockIdx.x, s_obs, s_cnt);
+  small_obs_body<Env, ROLLOUT, LOG, NOISE, MT, DIRECT>(a, n_steps, blockIdx.x, s_obs, s_cnt);
+}
+
+// Dynamic LDS of one workgroup stepping `a`.
+template <class Env>
+static size_t small_obs_lds(const typename Env::args& a) {
+  if constexpr (Env::PACKED) return bsx_small_direct_shape(a.obs_numel) ? 0 : (size_t)BSX_BLOCK * Env::rec_words(a) * 4;
+  else return 0;
+}
+
+// One workgroup of a grouped launch: the single-step body with everything decided at run time.
+template <class Env>
+__device__ __forceinline__ void small_obs_group_body(const typename Env::args& a, const uint32_t blk, float* s_obs,
+                                                     unsigned int* s_cnt) {
+  if constexpr (Env::PACKED) {
+    if (!bsx_small_direct_shape(a.obs_numel)) {                 // uniform per workgroup
+      small_obs_body<Env, false, -1, -1, -1, false>(a, 1, blk, s_obs, s_cnt);
+      return;
+    }
+  }
+  small_obs_body<Env, false, -1, -1, -1, true>(a, 1, blk, s_obs, s_cnt);
 }
 
 // Grouped launch: every workgroup looks up its segment and runs the single-step body on that
 // segment's argument struct (device memory).
-template <class Env, int LPB>
+template <class Env>
 __global__ void __launch_bounds__(BSX_BLOCK) small_obs_group_kernel(const typename Env::args* __restrict__ table,
                                                                     const bsx_group_index gi) {
   extern __shared__ __attribute__((aligned(16))) float s_obs[];
   __shared__ unsigned int s_cnt[2];
   const bsx_group_slot w = bsx_group_find(gi, (int)blockIdx.x);
-  small_obs_body<Env, LPB, false, -1, -1, -1>(table[w.seg], 1, w.block, s_obs, s_cnt);
+  small_obs_group_body<Env>(table[w.seg], w.block, s_obs, s_cnt);
 }
 
 template <class Env>
@@ -152,44 +205,39 @@ static int small_obs_group_launch(bsx_group* g, int phase, hipStream_t st) {
   if (phase == 1) return 0;                 // one kernel per step: everything happens in phase 0
   const dim3 grid((unsigned)g->total_blocks), block(BSX_BLOCK);
   const typename Env::args* table = (const typename Env::args*)g->d_args;
-  if (g->klass == 256) small_obs_group_kernel<Env, 256><<<grid, block, g->lds_bytes, st>>>(table, g->index1());
-  else small_obs_group_kernel<Env, 64><<<grid, block, g->lds_bytes, st>>>(table, g->index1());
+  small_obs_group_kernel<Env><<<grid, block, g->lds_bytes, st>>>(table, g->index1());
   return (int)hipGetLastError();
 }
 
 // A BSX_FAM_SMALL_MIXED group holds segments of ANY of the families in this file: every segment's
-// argument struct sits in a fixed-stride slot next to a family tag, and one launch per tile class
+// argument struct sits in a fixed-stride slot next to a family tag, and one launch
 // advances them all (the kernel switches on the tag per workgroup).  Six ~8 us launches of a
 // heterogeneous sweep become one.
 #define SMALL_MIXED_STRIDE 1024
 static int small_obs_mixed_launch(bsx_group* g, int phase, hipStream_t st);
 
-// Tile class of a segment inside a GROUPED launch (segments of one group must share it): 256-lane tiles
-// while the observation row is at most 32 floats, 64-lane tiles beyond — the rule of launch_small_obs.
-// (Splitting at 8 or 3 floats, so that the 256-lane launch of a sweep needs only 8 KiB of LDS per
-// workgroup, changed nothing: profiles/r02/ab_sweep_small_class.log.)
-extern "C" int bsx_group_small_class(int32_t numel) { return numel <= 32 ? 256 : 64; }
+// Tile class of a segment inside a grouped launch (segments of one group must share it).  Always 256 since
+// the packed records: the 64-lane class for rows wider than 32 floats is gone (kept in the ABI so that a
+// caller that buckets segments by class keeps working).
+extern "C" int bsx_group_small_class(int32_t numel) { (void)numel; return BSX_BLOCK; }
 
 // Records one segment of a small-observation family in a group (of its own family, or mixed).
 template <class Env>
 static int small_obs_group_put(bsx_group* g, int32_t family, int32_t index, const bsx_call_t* call,
-                               const typename Env::args& a, int numel) {
+                               const typename Env::args& a) {
   static_assert(sizeof(typename Env::args) <= SMALL_MIXED_STRIDE, "argument struct exceeds the mixed-group slot");
-  const int lpb = bsx_group_small_class(numel);
-  if (g != nullptr && g->family == BSX_FAM_SWEEP_MIXED) {     // one segment of the whole-sweep group: phase 0 only
-    const uint64_t nb = (uint64_t)(a.ctl.n_lanes + lpb - 1) / lpb;
-    return bsx_mixed_put(g, family, lpb, index, call, &a, sizeof(a), nullptr, 0, nb, 0, (size_t)lpb * numel * 4);
-  }
+  const uint64_t nb = (uint64_t)(a.ctl.n_lanes + BSX_BLOCK - 1) / BSX_BLOCK;
+  const size_t lds = small_obs_lds<Env>(a);
+  if (g != nullptr && g->family == BSX_FAM_SWEEP_MIXED)       // one segment of the whole-sweep group: phase 0 only
+    return bsx_mixed_put(g, family, index, call, &a, sizeof(a), nullptr, 0, nb, 0, lds);
   const bool mixed = g != nullptr && g->family == BSX_FAM_SMALL_MIXED;
   int rc = bsx_group_check_set(g, mixed ? BSX_FAM_SMALL_MIXED : family, index, call,
-                               mixed ? SMALL_MIXED_STRIDE : sizeof(typename Env::args), mixed ? sizeof(int32_t) : 0, lpb);
+                               mixed ? SMALL_MIXED_STRIDE : sizeof(typename Env::args), mixed ? sizeof(int32_t) : 0, BSX_BLOCK);
   if (rc != 0) return rc;
   memcpy(&g->args[(size_t)index * g->arg_size], &a, sizeof(a));
   if (mixed) memcpy(&g->args2[(size_t)index * sizeof(int32_t)], &family, sizeof(int32_t));
-  const uint64_t b = (uint64_t)(a.ctl.n_lanes + lpb - 1) / lpb;
-  if (b > 0x3FFFFFFFull) return BSX_EINVAL;
-  g->blocks[index] = (int32_t)b;
-  const size_t lds = (size_t)lpb * numel * 4;
+  if (nb > 0x3FFFFFFFull) return BSX_EINVAL;
+  g->blocks[index] = (int32_t)nb;
   if (lds > g->lds_bytes) g->lds_bytes = lds;
   g->is_set[index] = 1;
   g->launch = mixed ? small_obs_mixed_launch : small_obs_group_launch<Env>;
@@ -197,46 +245,44 @@ static int small_obs_group_put(bsx_group* g, int32_t family, int32_t index, cons
 }
 
 template <class Env>
-static int launch_small_obs(const typename Env::args& a, int numel, int n_steps, void* hip_stream) {
+static int launch_small_obs(const typename Env::args& a, int n_steps, void* hip_stream) {
   hipStream_t st = (hipStream_t)hip_stream;
   if (n_steps < 1) return BSX_EINVAL;
   const bool logging = a.ctl.log.steps != nullptr, noise = a.ctl.wrap_kind >= BSX_WRAP_NOISE;
   const bool lean = !logging && !noise && a.ctl.mt_state == nullptr;
-  // rows of 1 float, 3 floats or an even number <= 8: per-thread stores (4-byte / 12-byte / 8-byte stores,
-  // each wave writing one contiguous range), no LDS tile, no barrier — measured on bandit,
-  // discounting_chain, cartpole, mountain_car, memory_len: eager equal or 2-4 % faster, fused rollout
-  // 3-15 % faster (profiles/r02/ab_small_direct_stores.log).  Three 4-byte stores at stride 12 for the
-  // 3-float rows were 5-8 % SLOWER than the tile; one global_store_dwordx3 is faster.  Other odd rows keep
-  // the tile.  BSX_SMALL_DIRECT=0: A/B.
-  static const int direct_env = bsx_env_int("BSX_SMALL_DIRECT", 1);
-  const bool direct = direct_env != 0 && numel <= 8 && (numel == 1 || numel == 3 || (numel & 1) == 0);
-#define SMALL_OBS_LAUNCH(LPB)                                                                              \
+  const int64_t blocks = (a.ctl.n_lanes + BSX_BLOCK - 1) / BSX_BLOCK;
+  if (blocks > 0x7FFFFFFF) return BSX_EINVAL;
+  const size_t lds = small_obs_lds<Env>(a);
+  const dim3 g((unsigned)blocks), b(BSX_BLOCK);
+  // Per-thread stores (4-byte / 12-byte / 8-byte stores, each wave writing one contiguous range) against
+  // an f32 LDS tile, measured on bandit, discounting_chain, cartpole, mountain_car, memory_len: eager equal
+  // or 2-4 % faster, fused rollout 3-15 % faster (profiles/r02/ab_small_direct_stores.log).  Three 4-byte
+  // stores at stride 12 for the 3-float rows were 5-8 % SLOWER than the tile; one global_store_dwordx3 is
+  // faster.
+#define SMALL_OBS_LAUNCH(D)                                                                                \
   {                                                                                                        \
-    const int64_t blocks = (a.ctl.n_lanes + (LPB) - 1) / (LPB);                                            \
-    if (blocks > 0x7FFFFFFF) return BSX_EINVAL;                                                            \
-    const size_t lds = (size_t)(LPB) * numel * 4;                                                          \
-    const dim3 g((unsigned)blocks), b(BSX_BLOCK);                                                          \
-    if (n_steps == 1 && lean && direct && (LPB) == 256) small_obs_kernel<Env, 256, false, 0, 0, 0, true><<<g, b, 0, st>>>(a, 1); \
-    else if (n_steps > 1 && lean && direct && (LPB) == 256) small_obs_kernel<Env, 256, true, 0, 0, 0, true><<<g, b, 0, st>>>(a, n_steps); \
-    else if (n_steps == 1 && lean) small_obs_kernel<Env, LPB, false, 0, 0, 0><<<g, b, lds, st>>>(a, 1);    \
-    else if (n_steps == 1) small_obs_kernel<Env, LPB, false, -1, -1, -1><<<g, b, lds, st>>>(a, 1);         \
-    else if (logging && noise) small_obs_kernel<Env, LPB, true, 1, 1, -1><<<g, b, lds, st>>>(a, n_steps);  \
-    else if (logging) small_obs_kernel<Env, LPB, true, 1, 0, -1><<<g, b, lds, st>>>(a, n_steps);           \
-    else if (noise) small_obs_kernel<Env, LPB, true, 0, 1, -1><<<g, b, lds, st>>>(a, n_steps);             \
-    else if (lean) small_obs_kernel<Env, LPB, true, 0, 0, 0><<<g, b, lds, st>>>(a, n_steps);               \
-    else small_obs_kernel<Env, LPB, true, 0, 0, -1><<<g, b, lds, st>>>(a, n_steps);                        \
+    if (n_steps == 1 && lean) small_obs_kernel<Env, false, 0, 0, 0, D><<<g, b, lds, st>>>(a, 1);           \
+    else if (n_steps == 1) small_obs_kernel<Env, false, -1, -1, -1, D><<<g, b, lds, st>>>(a, 1);           \
+    else if (logging && noise) small_obs_kernel<Env, true, 1, 1, -1, D><<<g, b, lds, st>>>(a, n_steps);    \
+    else if (logging) small_obs_kernel<Env, true, 1, 0, -1, D><<<g, b, lds, st>>>(a, n_steps);             \
+    else if (noise) small_obs_kernel<Env, true, 0, 1, -1, D><<<g, b, lds, st>>>(a, n_steps);               \
+    else if (lean) small_obs_kernel<Env, true, 0, 0, 0, D><<<g, b, lds, st>>>(a, n_steps);                 \
+    else small_obs_kernel<Env, true, 0, 0, -1, D><<<g, b, lds, st>>>(a, n_steps);                          \
   }
-  // Full 256-lane tiles while the LDS tile stays <= 32 KiB (8 resident blocks/CU); 64-lane tiles
-  // for the wide umbrella/memory rows.
-  if (numel <= 32) SMALL_OBS_LAUNCH(256)
-  else SMALL_OBS_LAUNCH(64)
+  if constexpr (Env::PACKED) {
+    if (!bsx_small_direct_shape(a.obs_numel)) {
+      SMALL_OBS_LAUNCH(false)
+      return bsx_launch_status();
+    }
+  }
+  SMALL_OBS_LAUNCH(true)
 #undef SMALL_OBS_LAUNCH
   return bsx_launch_status();
 }
 
 // ------------------------------------------------------------------------------ bandit
 struct bandit_env {
-  static constexpr bool HAS_REGS = false;
+  static constexpr bool HAS_REGS = false, PACKED = false;
   struct regs { int unused; };
   struct args {
     bsx_ctl ctl; const int32_t* action; int32_t* state; bsx_timestep_t out; double* info;
@@ -276,7 +322,7 @@ extern "C" int bsx_bandit_step(const bsx_bandit_t* cfg, const bsx_call_t* call, 
   int rc = bandit_make(cfg, call, action, state, out, info, &a);
   if (rc != 0) return rc;
   if (call->n_lanes == 0) return 0;
-  return launch_small_obs<bandit_env>(a, 1, bsx_n_steps(call), call->hip_stream);
+  return launch_small_obs<bandit_env>(a, bsx_n_steps(call), call->hip_stream);
 }
 
 extern "C" int bsx_group_set_bandit(bsx_group_t* g, int32_t index, const bsx_bandit_t* cfg, const bsx_call_t* call,
@@ -285,26 +331,46 @@ extern "C" int bsx_group_set_bandit(bsx_group_t* g, int32_t index, const bsx_ban
   bandit_env::args a;
   int rc = bandit_make(cfg, call, action, state, out, info, &a);
   if (rc != 0) return rc;
-  return small_obs_group_put<bandit_env>(g, BSX_FAM_BANDIT, index, call, a, 1);
+  return small_obs_group_put<bandit_env>(g, BSX_FAM_BANDIT, index, call, a);
 }
 
 // ------------------------------------------------------------------------------ memory_chain
 #define MC_RESET_BIT (1 << 28)
 struct memory_chain_env {
-  static constexpr bool HAS_REGS = false;
+  static constexpr bool HAS_REGS = false, PACKED = true;
   struct regs { int unused; };
   struct args {
     bsx_ctl ctl; const int32_t* action; int32_t* state; uint64_t* context; bsx_timestep_t out;
     double* info; int32_t obs_numel; int32_t L; int32_t nb;
   };
+  // Packed record: [time f32, query f32, (t == 0), context bits 0-31, context bits 32-63].
+  __host__ __device__ static int rec_words(const args&) { return 5; }
+  // Branch-free on purpose (integer selects): the four LDS reads of a chunk in small_obs_body are then
+  // issued together and waited for once; with `?:` on floats the compiler branches and waits four times.
+  __device__ static float expand(const args&, const uint32_t* rec, int j) {
+    const int b = j - 2;
+    const uint32_t head = (uint32_t)(b >> 31);                          // all ones for the two leading floats
+    const uint32_t w = rec[(head & (uint32_t)j) | (~head & (uint32_t)(3 + (b >> 5)))];
+    const uint32_t first = 0u - (rec[2] != 0u ? 1u : 0u);
+    const uint32_t pm1 = 0xBF800000u ^ (((w >> (b & 31)) & 1u) << 31);  // bit ? 1.0f : -1.0f
+    return __uint_as_float((head & w) | (~head & first & pm1));
+  }
+  template <bool PACK>
   __device__ static void observe(const args& a, float* o, int t, int query, uint64_t ctx) {
     BSX_NO_CONTRACT
     o[0] = (float)(1.0 - (double)t / (double)a.L);              // memory_chain.py:64
     o[1] = (t == a.L - 1) ? (float)query : 0.0f;                // :66-67
-    for (int b = 0; b < a.nb; ++b)                              // :69-70
-      o[2 + b] = (t == 0) ? (float)(2 * (int)((ctx >> b) & 1ull) - 1) : 0.0f;
+    if constexpr (PACK) {
+      uint32_t* w = reinterpret_cast<uint32_t*>(o);
+      w[2] = (t == 0) ? 1u : 0u;
+      w[3] = (uint32_t)ctx;
+      w[4] = (uint32_t)(ctx >> 32);
+    } else {
+      for (int b = 0; b < a.nb; ++b)                            // :69-70
+        o[2 + b] = (t == 0) ? (float)(2 * (int)((ctx >> b) & 1ull) - 1) : 0.0f;
+    }
   }
-  template <int LOG, int MT>
+  template <int LOG, int MT, bool PACK = false>
   __device__ static int step(const args& a, int64_t i, int64_t oi, uint64_t lane, uint64_t step, float* o, double& reward) {
     int32_t st = a.state[i];
     int t = st & 0xFFFFF, query = (st >> 20) & 0xFF;
@@ -320,10 +386,10 @@ struct memory_chain_env {
       t = 0;
       a.context[i] = ctx;
       a.state[i] = t | (query << 20);
-      observe(a, o, t, query, ctx);
+      observe<PACK>(a, o, t, query, ctx);
       return BSX_FIRST;
     }
-    observe(a, o, t, query, ctx);                               // :74 — before the increment
+    observe<PACK>(a, o, t, query, ctx);                         // :74 — before the increment
     t += 1;                                                     // :75
     if (t - 1 < a.L) { a.state[i] = t | (query << 20); return BSX_MID; }   // :77-79
     if (a.action[oi] == (int)((ctx >> query) & 1ull)) { reward = 1.0; a.info[i] += 1.0; }   // :83-85
@@ -350,7 +416,7 @@ extern "C" int bsx_memory_chain_step(const bsx_memory_chain_t* cfg, const bsx_ca
   int rc = memory_chain_make(cfg, call, action, state, context, out, info, &a);
   if (rc != 0) return rc;
   if (call->n_lanes == 0) return 0;
-  return launch_small_obs<memory_chain_env>(a, a.obs_numel, bsx_n_steps(call), call->hip_stream);
+  return launch_small_obs<memory_chain_env>(a, bsx_n_steps(call), call->hip_stream);
 }
 
 extern "C" int bsx_group_set_memory_chain(bsx_group_t* g, int32_t index, const bsx_memory_chain_t* cfg, const bsx_call_t* call,
@@ -359,27 +425,47 @@ extern "C" int bsx_group_set_memory_chain(bsx_group_t* g, int32_t index, const b
   memory_chain_env::args a;
   int rc = memory_chain_make(cfg, call, action, state, context, out, info, &a);
   if (rc != 0) return rc;
-  return small_obs_group_put<memory_chain_env>(g, BSX_FAM_MEMORY_CHAIN, index, call, a, a.obs_numel);
+  return small_obs_group_put<memory_chain_env>(g, BSX_FAM_MEMORY_CHAIN, index, call, a);
 }
 
 // ------------------------------------------------------------------------------ umbrella_chain
 #define UC_RESET_BIT (1 << 22)
 struct umbrella_chain_env {
-  static constexpr bool HAS_REGS = false;
+  static constexpr bool HAS_REGS = false, PACKED = true;
   struct regs { int unused; };
   struct args {
     bsx_ctl ctl; const int32_t* action; int32_t* state; bsx_timestep_t out; double* info;
     int32_t obs_numel; int32_t L; int32_t nd;
   };
+  // Packed record: [need f32, has f32, time f32, distractor bits 32 to a word].
+  __host__ __device__ static int rec_words(const args& a) { return 3 + ((a.nd + 31) >> 5); }
+  // Branch-free on purpose (see memory_chain_env::expand).
+  __device__ static float expand(const args&, const uint32_t* rec, int j) {
+    const int b = j - 3;
+    const uint32_t head = (uint32_t)(b >> 31);                          // all ones for the three leading floats
+    const uint32_t w = rec[(head & (uint32_t)j) | (~head & (uint32_t)(3 + (b >> 5)))];
+    const uint32_t one = (0u - ((w >> (b & 31)) & 1u)) & 0x3F800000u;   // bit ? 1.0f : 0.0f
+    return __uint_as_float((head & w) | (~head & one));
+  }
+  template <bool PACK>
   __device__ static void observe(const args& a, float* o, int t, int need, int has, bsx_draws* d) {
     BSX_NO_CONTRACT
     o[0] = (float)need;                                         // umbrella_chain.py:62
     o[1] = (float)has;                                          // :63
     o[2] = (float)(1.0 - (double)t / (double)a.L);              // :64
     uint32_t w = 0;
-    for (int b = 0; b < a.nd; ++b) o[3 + b] = (float)bsx_bern_vec_bit(d, b, &w);   // :65 BernVec(nd)
+    if constexpr (PACK) {
+      uint32_t* bits = reinterpret_cast<uint32_t*>(o + 3);
+      uint32_t acc = 0;
+      for (int b = 0; b < a.nd; ++b) {                          // :65 BernVec(nd)
+        acc |= bsx_bern_vec_bit(d, b, &w) << (b & 31);
+        if ((b & 31) == 31 || b == a.nd - 1) { bits[b >> 5] = acc; acc = 0; }
+      }
+    } else {
+      for (int b = 0; b < a.nd; ++b) o[3 + b] = (float)bsx_bern_vec_bit(d, b, &w);   // :65 BernVec(nd)
+    }
   }
-  template <int LOG, int MT>
+  template <int LOG, int MT, bool PACK = false>
   __device__ static int step(const args& a, int64_t i, int64_t oi, uint64_t lane, uint64_t step, float* o, double& reward) {
     BSX_NO_CONTRACT
     int32_t st = a.state[i];
@@ -390,7 +476,7 @@ struct umbrella_chain_env {
       t = 0;
       need = (int)bsx_bern(&d);
       has = (int)bsx_bern(&d);
-      observe(a, o, t, need, has, &d);
+      observe<PACK>(a, o, t, need, has, &d);
       bsx_draws_end<MT>(&d, a.ctl, i);
       a.state[i] = t | (need << 20) | (has << 21);
       return BSX_FIRST;
@@ -401,11 +487,11 @@ struct umbrella_chain_env {
     if (t == a.L) {                                             // :74-81
       if (has == need) reward = 1.0;
       else { reward = -1.0; a.info[i] += 2.0; }
-      observe(a, o, t, need, has, &d);
+      observe<PACK>(a, o, t, need, has, &d);
       type = BSX_LAST;
     } else {                                                    // :83-85
       reward = 2.0 * (double)bsx_bern(&d) - 1.0;
-      observe(a, o, t, need, has, &d);
+      observe<PACK>(a, o, t, need, has, &d);
       type = BSX_MID;
     }
     bsx_draws_end<MT>(&d, a.ctl, i);
@@ -431,7 +517,7 @@ extern "C" int bsx_umbrella_chain_step(const bsx_umbrella_chain_t* cfg, const bs
   int rc = umbrella_chain_make(cfg, call, action, state, out, info, &a);
   if (rc != 0) return rc;
   if (call->n_lanes == 0) return 0;
-  return launch_small_obs<umbrella_chain_env>(a, a.obs_numel, bsx_n_steps(call), call->hip_stream);
+  return launch_small_obs<umbrella_chain_env>(a, bsx_n_steps(call), call->hip_stream);
 }
 
 extern "C" int bsx_group_set_umbrella_chain(bsx_group_t* g, int32_t index, const bsx_umbrella_chain_t* cfg, const bsx_call_t* call,
@@ -440,13 +526,13 @@ extern "C" int bsx_group_set_umbrella_chain(bsx_group_t* g, int32_t index, const
   umbrella_chain_env::args a;
   int rc = umbrella_chain_make(cfg, call, action, state, out, info, &a);
   if (rc != 0) return rc;
-  return small_obs_group_put<umbrella_chain_env>(g, BSX_FAM_UMBRELLA_CHAIN, index, call, a, a.obs_numel);
+  return small_obs_group_put<umbrella_chain_env>(g, BSX_FAM_UMBRELLA_CHAIN, index, call, a);
 }
 
 // ------------------------------------------------------------------------------ discounting_chain
 #define DC_RESET_BIT (1 << 12)
 struct discounting_chain_env {
-  static constexpr bool HAS_REGS = false;
+  static constexpr bool HAS_REGS = false, PACKED = false;
   struct regs { int unused; };
   struct args {
     bsx_ctl ctl; const int32_t* action; int32_t* state; bsx_timestep_t out;
@@ -497,7 +583,7 @@ extern "C" int bsx_discounting_chain_step(const bsx_discounting_chain_t* cfg, co
   int rc = discounting_chain_make(cfg, call, action, state, out, &a);
   if (rc != 0) return rc;
   if (call->n_lanes == 0) return 0;
-  return launch_small_obs<discounting_chain_env>(a, 2, bsx_n_steps(call), call->hip_stream);
+  return launch_small_obs<discounting_chain_env>(a, bsx_n_steps(call), call->hip_stream);
 }
 
 extern "C" int bsx_group_set_discounting_chain(bsx_group_t* g, int32_t index, const bsx_discounting_chain_t* cfg, const bsx_call_t* call,
@@ -506,7 +592,7 @@ extern "C" int bsx_group_set_discounting_chain(bsx_group_t* g, int32_t index, co
   discounting_chain_env::args a;
   int rc = discounting_chain_make(cfg, call, action, state, out, &a);
   if (rc != 0) return rc;
-  return small_obs_group_put<discounting_chain_env>(g, BSX_FAM_DISCOUNTING_CHAIN, index, call, a, 2);
+  return small_obs_group_put<discounting_chain_env>(g, BSX_FAM_DISCOUNTING_CHAIN, index, call, a);
 }
 
 // ------------------------------------------------------------------------------ cartpole / swingup
@@ -528,7 +614,7 @@ struct cartpole_env {
   };
   // The lane's state in registers: step() = load + core + store; the fused rollout loads once, runs core
   // T times and stores once (small_obs_body), instead of a round trip through L2 every step.
-  static constexpr bool HAS_REGS = true;
+  static constexpr bool HAS_REGS = true, PACKED = false;
   struct regs { float x, xd, th, thd; int32_t sk; };
   __device__ static __forceinline__ void load(const args& a, int64_t i, regs& r) {
     const int64_t B = a.ctl.n_lanes;
@@ -681,7 +767,7 @@ extern "C" int bsx_cartpole_step(const bsx_cartpole_t* cfg, const bsx_call_t* ca
   int rc = cartpole_make(cfg, call, action, state, steps, out, info, &a);
   if (rc != 0) return rc;
   if (call->n_lanes == 0) return 0;
-  return launch_small_obs<cartpole_env>(a, a.obs_numel, bsx_n_steps(call), call->hip_stream);
+  return launch_small_obs<cartpole_env>(a, bsx_n_steps(call), call->hip_stream);
 }
 
 extern "C" int bsx_group_set_cartpole(bsx_group_t* g, int32_t index, const bsx_cartpole_t* cfg, const bsx_call_t* call,
@@ -690,7 +776,7 @@ extern "C" int bsx_group_set_cartpole(bsx_group_t* g, int32_t index, const bsx_c
   cartpole_env::args a;
   int rc = cartpole_make(cfg, call, action, state, steps, out, info, &a);
   if (rc != 0) return rc;
-  return small_obs_group_put<cartpole_env>(g, BSX_FAM_CARTPOLE, index, call, a, a.obs_numel);
+  return small_obs_group_put<cartpole_env>(g, BSX_FAM_CARTPOLE, index, call, a);
 }
 
 // ------------------------------------------------------------------------------ mountain_car
@@ -702,7 +788,7 @@ struct mountain_car_env {
     bsx_ctl ctl; const int32_t* action; float* state; int32_t* steps; bsx_timestep_t out;
     double* info; int32_t obs_numel; int32_t max_steps;
   };
-  static constexpr bool HAS_REGS = true;
+  static constexpr bool HAS_REGS = true, PACKED = false;
   struct regs { float pos, vel; int32_t sk; };
   __device__ static __forceinline__ void load(const args& a, int64_t i, regs& r) {
     r.sk = a.steps[i]; r.pos = a.state[i]; r.vel = a.state[a.ctl.n_lanes + i];
@@ -777,7 +863,7 @@ extern "C" int bsx_mountain_car_step(const bsx_mountain_car_t* cfg, const bsx_ca
   int rc = mountain_car_make(cfg, call, action, state, steps, out, info, &a);
   if (rc != 0) return rc;
   if (call->n_lanes == 0) return 0;
-  return launch_small_obs<mountain_car_env>(a, 3, bsx_n_steps(call), call->hip_stream);
+  return launch_small_obs<mountain_car_env>(a, bsx_n_steps(call), call->hip_stream);
 }
 
 extern "C" int bsx_group_set_mountain_car(bsx_group_t* g, int32_t index, const bsx_mountain_car_t* cfg, const bsx_call_t* call,
@@ -786,11 +872,10 @@ extern "C" int bsx_group_set_mountain_car(bsx_group_t* g, int32_t index, const b
   mountain_car_env::args a;
   int rc = mountain_car_make(cfg, call, action, state, steps, out, info, &a);
   if (rc != 0) return rc;
-  return small_obs_group_put<mountain_car_env>(g, BSX_FAM_MOUNTAIN_CAR, index, call, a, 3);
+  return small_obs_group_put<mountain_car_env>(g, BSX_FAM_MOUNTAIN_CAR, index, call, a);
 }
 
 // ------------------------------------------------------------------------------ mixed-family group
-template <int LPB>
 __global__ void __launch_bounds__(BSX_BLOCK) small_obs_mixed_group_kernel(const uint8_t* __restrict__ table,
                                                                           const int32_t* __restrict__ family,
                                                                           const bsx_group_index gi) {
@@ -801,7 +886,7 @@ __global__ void __launch_bounds__(BSX_BLOCK) small_obs_mixed_group_kernel(const 
   const uint32_t blk = w.block;
   const uint8_t* slot = table + (size_t)seg * SMALL_MIXED_STRIDE;
 #define SMALL_MIXED_CASE(FAM, ENV) \
-  case FAM: small_obs_body<ENV, LPB, false, -1, -1, -1>(*reinterpret_cast<const ENV::args*>(slot), 1, blk, s_obs, s_cnt); break;
+  case FAM: small_obs_group_body<ENV>(*reinterpret_cast<const ENV::args*>(slot), blk, s_obs, s_cnt); break;
   switch (family[seg]) {                           // uniform per workgroup
     SMALL_MIXED_CASE(BSX_FAM_BANDIT, bandit_env)
     SMALL_MIXED_CASE(BSX_FAM_MEMORY_CHAIN, memory_chain_env)
@@ -817,10 +902,7 @@ __global__ void __launch_bounds__(BSX_BLOCK) small_obs_mixed_group_kernel(const 
 static int small_obs_mixed_launch(bsx_group* g, int phase, hipStream_t st) {
   if (phase == 1) return 0;
   const dim3 grid((unsigned)g->total_blocks), block(BSX_BLOCK);
-  const uint8_t* table = (const uint8_t*)g->d_args;
-  const int32_t* family = (const int32_t*)g->d_args2;
-  if (g->klass == 256) small_obs_mixed_group_kernel<256><<<grid, block, g->lds_bytes, st>>>(table, family, g->index1());
-  else small_obs_mixed_group_kernel<64><<<grid, block, g->lds_bytes, st>>>(table, family, g->index1());
+  small_obs_mixed_group_kernel<<<grid, block, g->lds_bytes, st>>>((const uint8_t*)g->d_args, (const int32_t*)g->d_args2, g->index1());
   return (int)hipGetLastError();
 }
 
@@ -833,7 +915,7 @@ static int small_obs_mixed_launch(bsx_group* g, int phase, hipStream_t st) {
 // streams (cross-queue waits cost ~10 us each; kernels sharing the machine with the store stream
 // stretch it: profiles/r02/ab_sweep_*.log, sweep_*_timeline*.txt).  The last workgroup to retire bumps
 // the call counter the segments share, so no other kernel has to.
-__global__ void __launch_bounds__(BSX_BLOCK) sweep_phase0_kernel(const uint8_t* __restrict__ table,
+__global__ void __launch_bounds__(BSX_BLOCK) __attribute__((amdgpu_waves_per_eu(8))) sweep_phase0_kernel(const uint8_t* __restrict__ table,
                                                                  const int32_t* __restrict__ tags,
                                                                  const bsx_group_index gi,
                                                                  uint64_t* counter, uint32_t* ticket) {
@@ -845,12 +927,9 @@ __global__ void __launch_bounds__(BSX_BLOCK) sweep_phase0_kernel(const uint8_t* 
   const int tag = tags[w.seg];                       // uniform per workgroup
   const uint32_t blk = w.block;
   const uint8_t* slot = table + (size_t)w.seg * BSX_MIXED_ADV_STRIDE;
-#define SWEEP_SMALL_CASE(FAM, ENV)                                                                              \
-  case FAM:                                                                                                     \
-    if (tag & BSX_MIXED_TAG_LPB64) small_obs_body<ENV, 64, false, -1, -1, -1>(*reinterpret_cast<const ENV::args*>(slot), 1, blk, s_obs, s_cnt); \
-    else small_obs_body<ENV, 256, false, -1, -1, -1>(*reinterpret_cast<const ENV::args*>(slot), 1, blk, s_obs, s_cnt);                          \
-    break;
-  switch (tag & 0xFF) {
+#define SWEEP_SMALL_CASE(FAM, ENV) \
+  case FAM: small_obs_group_body<ENV>(*reinterpret_cast<const ENV::args*>(slot), blk, s_obs, s_cnt); break;
+  switch (tag) {
     case BSX_FAM_DEEP_SEA: bsx_advance_body<deep_sea_fam>(*reinterpret_cast<const deep_sea_fam::args*>(slot), blk, s_ds, s_cnt); break;
     case BSX_FAM_CATCH: bsx_advance_body<catch_fam>(*reinterpret_cast<const catch_fam::args*>(slot), blk, s_ca, s_cnt); break;
     case BSX_FAM_MNIST: mnist_advance_body(*reinterpret_cast<const mnist_args*>(slot), blk, s_cnt); break;

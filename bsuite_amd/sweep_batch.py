@@ -164,9 +164,8 @@ class SweepBatch:
     families — and `step_grouped()` needs nothing else.  Otherwise (A/B, and what the ABI offers
     piecewise): with `mix_pairs` ONE mixed group for the two-kernel families
     deep_sea, catch and mnist together (BSX_FAM_PAIR_MIXED: one advance launch + one observation-stream
-    launch for all their segments), else one group per family; with `mix_small` ONE mixed group per
-    tile class for all small-observation families together (BSX_FAM_SMALL_MIXED), else one per
-    (family, class).  Records every local segment with its static `actions` tensor and uploads the
+    launch for all their segments), else one group per family; with `mix_small` ONE mixed group for
+    all small-observation families together (BSX_FAM_SMALL_MIXED), else one per family.  Records every local segment with its static `actions` tensor and uploads the
     argument tables.  Returns the per-segment output TimeSteps (tensors that every `step_grouped()`
     overwrites)."""
     import ctypes  # pylint: disable=import-outside-toplevel

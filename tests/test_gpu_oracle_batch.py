@@ -32,6 +32,15 @@ CASES = [
     ('umbrella_chain', dict(chain_length=4, n_distractor=20), None),
     ('umbrella_chain', dict(chain_length=2, n_distractor=253), None),
     ('umbrella_chain', dict(chain_length=6, n_distractor=64), ('noise', 0.1)),
+    # row shapes either side of the per-thread-store / packed-record split and of the 32-bit word boundaries
+    ('umbrella_chain', dict(chain_length=3, n_distractor=0), None),     # 3 floats: one 12-byte store
+    ('umbrella_chain', dict(chain_length=3, n_distractor=2), None),     # 5 floats: packed, rows not 16-byte aligned
+    ('umbrella_chain', dict(chain_length=3, n_distractor=5), None),     # 8 floats: four 8-byte stores
+    ('umbrella_chain', dict(chain_length=3, n_distractor=32), None),    # exactly one bit word
+    ('umbrella_chain', dict(chain_length=3, n_distractor=33), None),
+    ('memory_chain', dict(memory_length=2, num_bits=2), None),          # 4 floats: per-thread stores
+    ('memory_chain', dict(memory_length=2, num_bits=32), None),
+    ('memory_chain', dict(memory_length=2, num_bits=33), None),
     ('discounting_chain', dict(mapping_seed=2), None),
 ]
 

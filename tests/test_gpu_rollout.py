@@ -15,7 +15,7 @@ CASES = [
     ('bandit', dict(mapping_seed=2), None, 11),
     ('bandit', dict(mapping_seed=2), ('noise', 0.5), 11),
     ('memory_chain', dict(memory_length=3, num_bits=3), None, 2),      # numel 5: unaligned slices
-    ('memory_chain', dict(memory_length=2, num_bits=40), None, 2),     # 64-lane tiles
+    ('memory_chain', dict(memory_length=2, num_bits=40), None, 2),     # packed records, 42-float rows
     ('umbrella_chain', dict(chain_length=4, n_distractor=20), ('scale', 3.0), 2),
     ('discounting_chain', dict(mapping_seed=1), None, 5),
     ('cartpole', dict(), None, 3),

@@ -94,11 +94,11 @@ def test_grouped_sweep_equals_standalone_envs(tmp_path, mode):
   if mode.startswith('whole_sweep'):
     assert len(batch._groups) == 1               # ONE group: two launches per sweep step, nothing else
   elif mode == 'per_family':
-    assert 9 <= len(batch._groups) <= 12         # families (+ wide-row classes), not segments
+    assert len(batch._groups) == 9               # families, not segments
   elif mode == 'pairs_per_family':
-    assert len(batch._groups) == 5               # deep_sea, catch, mnist + two mixed tile classes
+    assert len(batch._groups) == 4               # deep_sea, catch, mnist + one mixed small-observation group
   else:
-    assert len(batch._groups) == 3               # one mixed two-kernel group + two mixed tile classes
+    assert len(batch._groups) == 2               # one mixed two-kernel group + one mixed small-observation group
   if mode in ('graph', 'graph_phased', 'pairs_per_family', 'whole_sweep_graph'):
     # runs sweep step 0 eagerly, captures one step; phased: advance kernels + small groups on one
     # branch, every observation stream kernel on another as soon as its advance kernel is done
