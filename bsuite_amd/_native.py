@@ -88,7 +88,8 @@ class Call(ctypes.Structure):
   _fields_ = [('n_lanes', ctypes.c_int64), ('force_reset', ctypes.c_int32), ('n_steps', ctypes.c_int32),
               ('stream', Stream), ('wrap', RewardWrap), ('counters', ctypes.c_void_p),
               ('hip_stream', ctypes.c_void_p), ('logging', ctypes.POINTER(Logging)),
-              ('obs_paint', ctypes.c_void_p), ('reward_f64', ctypes.c_void_p)]
+              ('obs_paint', ctypes.c_void_p), ('reward_f64', ctypes.c_void_p),
+              ('state_alt', ctypes.c_void_p)]
 
 
 class DeepSeaCfg(ctypes.Structure):
@@ -210,7 +211,7 @@ for _name, (_args, _res) in _SIGS.items():
   _fn.restype = _res
 if MISSING:
   raise NativeLibraryError(f'{SO_PATH} does not export {MISSING}; rebuild with `python -m bsuite_amd.build --force`')
-ABI_VERSION = 8
+ABI_VERSION = 9
 if lib.bsx_abi_version() != ABI_VERSION:
   raise NativeLibraryError('ABI version mismatch between bsuite_amd/_native.py and libbsuite_amd.so')
 

@@ -39,6 +39,7 @@ struct bsx_ctl {
   double* wrap_mt_gauss;
   int32_t* wrap_mt_has_gauss;
   double* reward_f64;       // optional f64 copy of the reward column (scalar dm_env view), else nullptr
+  const int32_t* state_in;  // two-kernel families: the packed state column the advance READS (nullptr: `state`)
   bsx_logging_t log;        // log.steps == nullptr: logging off
 };
 
@@ -273,7 +274,8 @@ __device__ __forceinline__ void bsx_advance_body(const typename Fam::args& a, ui
     const uint64_t step = bsx_step_of(a.ctl);
     int32_t nst; double reward;
     const int act = a.ctl.force_reset ? 0 : a.action[i];
-    type = Fam::template advance<LEAN>(a, s_fam, i, lane, step, a.state[i], act, nst, reward);
+    const int32_t st = a.ctl.state_in != nullptr ? a.ctl.state_in[i] : a.state[i];
+    type = Fam::template advance<LEAN>(a, s_fam, i, lane, step, st, act, nst, reward);
     a.state[i] = nst;
     if (LEAN) bsx_emit_at<0, 0>(a.ctl, a.out, i, i, lane, step, type, reward);
     else bsx_emit(a.ctl, a.out, i, lane, step, type, reward);
@@ -408,6 +410,26 @@ __global__ void __launch_bounds__(BS) bsx_hot_stream_kernel(float* __restrict__ 
                                                                    uint32_t cells_magic, bsx_div64 dv,
                                                                    HotFn fn, int wave_contig) {
   bsx_hot_stream_body<HotFn, K, BS>(obs, state, n_lanes, cells, cells_magic, dv, fn, blockIdx.x, wave_contig);
+}
+
+// Software-pipelined rollout step of a two-kernel family: ONE launch runs the observation stream of
+// step t beside the lane advance of step t+1.  Nothing inside the launch depends on anything else inside
+// it — both halves read the packed state column W(t) that the previous launch wrote, the advance writes
+// the OTHER column (bsx_call_t.state_alt) — so, unlike a fused {advance, stream} of the same step
+// (profiles/r02/ab_step1_fused_single_launch.log), no workgroup ever waits for another.  The first
+// `adv_blocks` workgroups (or the last, adv_last) advance lanes; the rest are the store stream.
+template <class Fam, bool LEAN, class HotFn, int K>
+__global__ void __launch_bounds__(BSX_BLOCK) bsx_pipelined_kernel(const typename Fam::args a, const uint32_t adv_blocks,
+                                                                  const uint32_t adv_last,
+                                                                  float* __restrict__ obs, const int32_t* __restrict__ hot_state,
+                                                                  uint32_t cells, uint32_t cells_magic, bsx_div64 dv, HotFn fn) {
+  __shared__ typename Fam::shared s_fam;
+  __shared__ unsigned int s_cnt[2];
+  const uint32_t stream_blocks = gridDim.x - adv_blocks;
+  const bool adv = adv_last ? blockIdx.x >= stream_blocks : blockIdx.x < adv_blocks;     // uniform per workgroup
+  if (adv) bsx_advance_body<Fam, LEAN>(a, adv_last ? blockIdx.x - stream_blocks : blockIdx.x, s_fam, s_cnt);
+  else bsx_hot_stream_body<HotFn, K, BSX_BLOCK>(obs, hot_state, a.ctl.n_lanes, cells, cells_magic, dv, fn,
+                                                adv_last ? blockIdx.x : blockIdx.x - adv_blocks);
 }
 
 template <class HotFn, int K>

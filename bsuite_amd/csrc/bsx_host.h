@@ -63,6 +63,7 @@ static inline bsx_ctl bsx_make_ctl(const bsx_call_t* call) {
   c.wrap_mt_gauss = wrap_mt ? call->wrap.mt_gauss : nullptr;
   c.wrap_mt_has_gauss = wrap_mt ? call->wrap.mt_has_gauss : nullptr;
   c.reward_f64 = call->reward_f64;
+  c.state_in = nullptr;
   if (call->logging != nullptr) c.log = *call->logging;
   else c.log = bsx_logging_t{};
   return c;
@@ -227,5 +228,73 @@ static inline int bsx_group_check_set(bsx_group* g, int32_t family, int32_t inde
 }
 
 static inline int bsx_launch_status() { return (int)hipGetLastError(); }
+
+// One call of a two-kernel family (deep_sea, catch): step() / reset() / a rollout of T steps with outputs
+// [T,B,...].  `a` comes from the family's make(); K = stores per thread of its observation stream.
+//   delta mode (obs_paint)          one launch per step: advance + in-place patch
+//   dense                           advance + observation stream per step
+//   dense rollout with state_alt    software-pipelined: advance(0); {stream(t), advance(t+1)} for t < T-1;
+//                                   stream(T-1) — T+1 launches.  The advances alternate between `state`
+//                                   and `state_alt` so that the column stream(t) reads is not the one
+//                                   advance(t+1) writes; the parity is chosen so that the last advance
+//                                   writes `state`.  BSX_ROLLOUT_PIPELINED=0: A/B.
+template <class Fam, class HotFn, int K>
+static int bsx_pair_call(const typename Fam::args& a0, const bsx_call_t* call, const int32_t* action, int32_t* state,
+                         bsx_timestep_t out, uint32_t cells, const HotFn& fn) {
+  hipStream_t st = (hipStream_t)call->hip_stream;
+  const int T = bsx_n_steps(call);
+  const int64_t B = call->n_lanes;
+  auto at = [&](int t) {                      // the arguments of step t: slice [t] of every [T,B,...] array
+    typename Fam::args s = a0;
+    const int64_t off = (int64_t)t * B;
+    s.ctl.step_index = call->stream.step_index + (uint64_t)t;
+    s.ctl.reward_f64 = call->reward_f64 ? call->reward_f64 + off : nullptr;
+    s.action = action ? action + off : action;
+    s.out.reward = out.reward + off; s.out.discount = out.discount + off; s.out.step_type = out.step_type + off;
+    s.out.observation = out.observation + off * (int64_t)cells;
+    return s;
+  };
+  const uint32_t magic = bsx_div_magic(cells);
+  static const int pipe_env = bsx_env_int("BSX_ROLLOUT_PIPELINED", 1);
+  static const int adv_last = bsx_env_int("BSX_PIPELINED_ADV_LAST", 0);
+  // the fused launch uses the 16-byte store stream: every [t] slice must start on a 16-byte boundary
+  const bool pipelined = pipe_env != 0 && T > 1 && call->state_alt != nullptr && call->obs_paint == nullptr &&
+                         cells >= 4u && (((uint64_t)B * cells) & 3ull) == 0;
+  int rc = 0;
+  if (!pipelined) {
+    for (int t = 0; t < T && rc == 0; ++t) {
+      const typename Fam::args s = at(t);
+      if (call->obs_paint != nullptr) {
+        rc = bsx_launch_advance_delta<Fam, HotFn>(s, fn, call->obs_paint, cells, st);
+      } else {
+        rc = bsx_launch_advance<Fam>(s, st);
+        // stores/thread x 256 threads: a sharp optimum per family (profiles/r01/sweep_stream_*.log)
+        if (rc == 0) rc = bsx_launch_hot_stream(s.out.observation, state, B, cells, magic, fn, st, K);
+      }
+    }
+    return rc != 0 ? rc : bsx_launch_status();
+  }
+  int32_t* const col[2] = {state, call->state_alt};
+  auto W = [&](int t) { return col[(T - 1 - t) & 1]; };      // the column advance(t) writes; W(T-1) = state
+  const uint64_t adv_blocks = (uint64_t)(B + BSX_BLOCK - 1) / BSX_BLOCK;
+  const uint64_t str_blocks = ((uint64_t)B * cells + (uint64_t)K * 4 * BSX_BLOCK - 1) / ((uint64_t)K * 4 * BSX_BLOCK);
+  if (adv_blocks + str_blocks > 0x7FFFFFFFull) return BSX_EINVAL;
+  const bsx_div64 dv = bsx_make_div64(cells);
+  const bool lean = a0.ctl.log.steps == nullptr && a0.ctl.wrap_kind < BSX_WRAP_NOISE && a0.ctl.mt_state == nullptr;
+  typename Fam::args s = at(0);
+  s.ctl.state_in = state; s.state = W(0);
+  rc = bsx_launch_advance<Fam>(s, st);
+  for (int t = 0; t + 1 < T && rc == 0; ++t) {
+    s = at(t + 1);
+    s.ctl.state_in = W(t); s.state = W(t + 1);
+    float* obs_t = out.observation + (int64_t)t * B * (int64_t)cells;
+    const dim3 grid((unsigned)(adv_blocks + str_blocks)), block(BSX_BLOCK);
+    if (lean) bsx_pipelined_kernel<Fam, true, HotFn, K><<<grid, block, 0, st>>>(s, (uint32_t)adv_blocks, (uint32_t)adv_last, obs_t, W(t), cells, magic, dv, fn);
+    else bsx_pipelined_kernel<Fam, false, HotFn, K><<<grid, block, 0, st>>>(s, (uint32_t)adv_blocks, (uint32_t)adv_last, obs_t, W(t), cells, magic, dv, fn);
+  }
+  if (rc == 0) rc = bsx_launch_hot_stream(out.observation + (int64_t)(T - 1) * B * (int64_t)cells, state, B, cells, magic, fn, st, K);
+  return rc != 0 ? rc : bsx_launch_status();
+}
+
 
 #endif  // BSX_HOST_H_

@@ -45,28 +45,7 @@ extern "C" int bsx_deep_sea_step(const bsx_deep_sea_t* cfg, const bsx_call_t* ca
   if (rc != 0) return rc;
   if (call->n_lanes == 0) return 0;
   const uint32_t cells = (uint32_t)(cfg->size * cfg->size);
-  hipStream_t st = (hipStream_t)call->hip_stream;
-
-  deep_sea_hot fn{cfg->size};
-  const int n_steps = bsx_n_steps(call);
-  for (int t = 0; t < n_steps; ++t) {       // rollout: the kernel pair once per step, outputs [T,B,...]
-    const int64_t off = (int64_t)t * call->n_lanes;
-    a.ctl.step_index = call->stream.step_index + (uint64_t)t;
-    a.ctl.reward_f64 = call->reward_f64 ? call->reward_f64 + off : nullptr;
-    a.action = action ? action + off : action;
-    a.out.reward = out.reward + off; a.out.discount = out.discount + off; a.out.step_type = out.step_type + off;
-    a.out.observation = out.observation + off * (int64_t)cells;
-    if (call->obs_paint != nullptr) {           // delta mode: advance + in-place patch in one launch
-      rc = bsx_launch_advance_delta<deep_sea_fam, deep_sea_hot>(a, fn, call->obs_paint, cells, st);
-    } else {
-      rc = bsx_launch_advance<deep_sea_fam>(a, st);
-      if (rc != 0) return rc;
-      // stores/thread x 256 threads: a sharp optimum per family (profiles/r01/sweep_stream_*.log)
-      rc = bsx_launch_hot_stream(a.out.observation, state, call->n_lanes, cells, bsx_div_magic(cells), fn, st, 4);
-    }
-    if (rc != 0) return rc;
-  }
-  return bsx_launch_status();
+  return bsx_pair_call<deep_sea_fam, deep_sea_hot, 4>(a, call, action, state, out, cells, deep_sea_hot{cfg->size});
 }
 
 extern "C" int bsx_group_set_deep_sea(bsx_group_t* g, int32_t index, const bsx_deep_sea_t* cfg,

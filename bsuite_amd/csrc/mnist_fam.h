@@ -29,7 +29,7 @@ __device__ __forceinline__ void mnist_advance_body(const mnist_args& a, uint32_t
   if (i < a.ctl.n_lanes) {
     const uint64_t lane = a.ctl.lane_offset + (uint64_t)i;
     const uint64_t step = bsx_step_of(a.ctl);
-    const int32_t st = a.state[i];
+    const int32_t st = a.ctl.state_in != nullptr ? a.ctl.state_in[i] : a.state[i];
     double reward = 0.0;
     int32_t nst;
     if (a.ctl.force_reset || (st & MN_RESET_BIT)) {             // mnist.py:61-67

@@ -34,13 +34,31 @@
 //           itself — no LDS, no barrier.  Every family with a fixed short row (bandit, discounting_chain,
 //           cartpole, mountain_car) always takes it.
 //   PACKED  the families whose row length is a parameter (memory_chain: nb+2, umbrella_chain: 3+nd, up to
-//           256 floats) and whose row is a few floats followed by BITS: the thread leaves a packed record
-//           (Env::rec_words() words: the leading floats verbatim, then the bits 32 to a word) in LDS and,
-//           after one barrier, the block streams the [256 x numel] tile to HBM as consecutive 16-byte
-//           chunks, expanding bits to floats on the way (a lane-per-row store would be a stride-(4*numel)
-//           scatter).  A record is at most 11 words where the f32 row was up to 256: the workgroup's LDS
-//           is <= 11 KiB (was 26-32 KiB with f32 tiles of 64 or 256 lanes), so LDS no longer caps the
-//           resident workgroups per CU — which is what the one-launch sweep phase 0 is bound by.
+//           256 floats) and whose row is a few floats (HEAD) followed by values that one or two BITS
+//           encode.  The block keeps the tile [256 x numel] as flat bit planes in LDS — bit (l*numel + j) of
+//           a plane belongs to element j of lane l — which each lane ORs its bits into; after a barrier
+//           the block streams the tile to HBM as consecutive 16-byte chunks: chunk c is the nibble at bit
+//           4c of each plane, four v_bfe/v_cvt away from a float4 (a lane-per-row store would be a
+//           stride-(4*numel) scatter; an f32 tile costs 32x the LDS — up to 32 KiB per workgroup, which
+//           capped the resident workgroups per CU — and per-element records cost ~80 VALU instructions
+//           per chunk: profiles/r02/ab_packed_records_v*.log).  The HEAD floats stay in the lane's
+//           registers and overwrite their (zero) places in the tile after a second barrier.
+//           LDS per workgroup: 32*numel bytes per plane (<= 8 KiB).
+// A lane's handle on the tile's bit planes.
+struct bsx_bit_sink {
+  uint32_t* planes;        // LDS: PLANES x `stride` words
+  int stride;              // words per plane = 8 * numel
+  uint32_t base;           // flat bit index of the lane's element HEAD
+  // ORs bits [32k, 32k+n) of the lane's bit string (n in 1..32, the low n bits of w) into plane p
+  __device__ __forceinline__ void put(int p, int k, uint32_t w, int n) const {
+    if (n < 32) w &= (1u << n) - 1u;
+    const uint32_t pos = base + 32u * (uint32_t)k, sh = pos & 31u;
+    uint32_t* word = planes + p * stride + (pos >> 5);
+    atomicOr(word, w << sh);
+    if (sh + (uint32_t)n > 32u) atomicOr(word + 1, w >> (32u - sh));
+  }
+};
+
 __host__ __device__ static inline bool bsx_small_direct_shape(int numel) {
   return numel <= 8 && (numel == 1 || numel == 3 || (numel & 1) == 0);
 }
@@ -109,50 +127,52 @@ __device__ __forceinline__ void small_obs_body(const typename Env::args& a, cons
       }
       bsx_count_types(a.ctl, type, s_cnt);
     } else {
-      const int cw = Env::rec_words(a);
+      constexpr int HEAD = Env::HEAD, PLANES = Env::PLANES;
+      uint32_t* __restrict__ planes = reinterpret_cast<uint32_t*>(s_obs);
+      const int stride = numel * (BSX_BLOCK / 32);                       // words per plane
+      for (int w = threadIdx.x; w < PLANES * stride; w += BSX_BLOCK) planes[w] = 0u;
+      __syncthreads();
+      float head[HEAD];
       if (mine) {
         double reward = 0.0;
-        type = Env::template step<LOG, MT, true>(a, i, oi, lane, step0 + (uint64_t)t, s_obs + (int)threadIdx.x * cw, reward);
+        const bsx_bit_sink sink{planes, stride, (uint32_t)((int)threadIdx.x * numel + HEAD)};
+        type = Env::template step<LOG, MT, true>(a, i, oi, lane, step0 + (uint64_t)t, head, reward, &sink);
         bsx_emit_at<LOG, NOISE>(a.ctl, a.out, i, oi, lane, step0 + (uint64_t)t, type, reward);
       }
       bsx_count_types(a.ctl, type, s_cnt);
       __syncthreads();
 
-      // stream the tile: [lanes_here x numel] floats, contiguous in HBM, 16-byte aligned start.  Thread
-      // k owns floats [4k, 4k+4) + multiples of 4*BSX_BLOCK; their (lane, element) split advances by a
-      // constant, so there is one division per thread, not one per chunk.
-      const uint32_t* __restrict__ rec = reinterpret_cast<const uint32_t*>(s_obs);
+      // stream the tile: [lanes_here x numel] floats, contiguous in HBM, 16-byte aligned start
       float* __restrict__ tile = a.out.observation + ((int64_t)t * B + lane0) * (int64_t)numel;
       const int total = lanes_here * numel;
       const bool vec = ((((int64_t)t * B * numel) & 3) == 0);            // [t] slice 16-byte aligned?
       const int n_chunks = vec ? total >> 2 : 0;
       bsx_f4* __restrict__ t4 = reinterpret_cast<bsx_f4*>(tile);
-      const int l0 = (4 * (int)threadIdx.x) / numel;
-      int j = 4 * (int)threadIdx.x - l0 * numel, ro = l0 * cw;          // element in the row, record offset
-      const int dl = (4 * BSX_BLOCK) / numel, dj = 4 * BSX_BLOCK - dl * numel, dro = dl * cw;
       for (int ch = threadIdx.x; ch < n_chunks; ch += BSX_BLOCK) {
-        // Env::expand is branch-free: the four LDS reads of a chunk are issued together, one wait
-        float v[4];
-        int rr = ro, jj = j;
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-          v[k] = Env::expand(a, rec + rr, jj);
-          const bool wrap = ++jj == numel;
-          jj = wrap ? 0 : jj;
-          rr = wrap ? rr + cw : rr;
-        }
-        bsx_f4 q; q.x = v[0]; q.y = v[1]; q.z = v[2]; q.w = v[3];
+        const uint32_t n0 = planes[ch >> 3] >> ((ch & 7) << 2);
+        const uint32_t n1 = PLANES > 1 ? planes[stride + (ch >> 3)] >> ((ch & 7) << 2) : 0u;
+        bsx_f4 q;
+        q.x = Env::decode(n0 & 1u, n1 & 1u);
+        q.y = Env::decode((n0 >> 1) & 1u, (n1 >> 1) & 1u);
+        q.z = Env::decode((n0 >> 2) & 1u, (n1 >> 2) & 1u);
+        q.w = Env::decode((n0 >> 3) & 1u, (n1 >> 3) & 1u);
         t4[ch] = q;
-        j += dj; ro += dro;
-        const bool wrap = j >= numel;
-        j = wrap ? j - numel : j;
-        ro = wrap ? ro + cw : ro;
       }
       for (int f = (n_chunks << 2) + (int)threadIdx.x; f < total; f += BSX_BLOCK) {
-        const int fl = f / numel;
-        tile[f] = Env::expand(a, rec + fl * cw, f - fl * numel);
+        const uint32_t b0 = (planes[f >> 5] >> (f & 31)) & 1u;
+        const uint32_t b1 = PLANES > 1 ? (planes[stride + (f >> 5)] >> (f & 31)) & 1u : 0u;
+        tile[f] = Env::decode(b0, b1);
       }
-      if (t + 1 < n_steps) __syncthreads();                              // records are rewritten next step
+      // The barrier orders every tile store of the block before the HEAD floats that overwrite their
+      // places (and the plane reads above before the next step's zeroing).
+      __syncthreads();
+      if (mine) {
+        struct __attribute__((packed, aligned(4))) head_row { float v[HEAD]; };
+        head_row h;
+#pragma unroll
+        for (int k = 0; k < HEAD; ++k) h.v[k] = head[k];
+        *reinterpret_cast<head_row*>(a.out.observation + oi * (int64_t)numel) = h;
+      }
     }
   }
   if constexpr (REGS) {
@@ -172,7 +192,7 @@ __global__ void __launch_bounds__(BSX_BLOCK) small_obs_kernel(const typename Env
 // Dynamic LDS of one workgroup stepping `a`.
 template <class Env>
 static size_t small_obs_lds(const typename Env::args& a) {
-  if constexpr (Env::PACKED) return bsx_small_direct_shape(a.obs_numel) ? 0 : (size_t)BSX_BLOCK * Env::rec_words(a) * 4;
+  if constexpr (Env::PACKED) return bsx_small_direct_shape(a.obs_numel) ? 0 : (size_t)Env::PLANES * a.obs_numel * (BSX_BLOCK / 32) * 4;
   else return 0;
 }
 
@@ -343,35 +363,35 @@ struct memory_chain_env {
     bsx_ctl ctl; const int32_t* action; int32_t* state; uint64_t* context; bsx_timestep_t out;
     double* info; int32_t obs_numel; int32_t L; int32_t nb;
   };
-  // Packed record: [time f32, query f32, (t == 0), context bits 0-31, context bits 32-63].
-  __host__ __device__ static int rec_words(const args&) { return 5; }
-  // Branch-free on purpose (integer selects): the four LDS reads of a chunk in small_obs_body are then
-  // issued together and waited for once; with `?:` on floats the compiler branches and waits four times.
-  __device__ static float expand(const args&, const uint32_t* rec, int j) {
-    const int b = j - 2;
-    const uint32_t head = (uint32_t)(b >> 31);                          // all ones for the two leading floats
-    const uint32_t w = rec[(head & (uint32_t)j) | (~head & (uint32_t)(3 + (b >> 5)))];
-    const uint32_t first = 0u - (rec[2] != 0u ? 1u : 0u);
-    const uint32_t pm1 = 0xBF800000u ^ (((w >> (b & 31)) & 1u) << 31);  // bit ? 1.0f : -1.0f
-    return __uint_as_float((head & w) | (~head & first & pm1));
+  // Packed rows: HEAD = [time, query]; element 2+b is 0 unless t == 0, then +-1 by context bit b: plane 0 says
+  // "non-zero", plane 1 carries the context bit.
+  static constexpr int HEAD = 2, PLANES = 2;
+  __device__ static float decode(uint32_t nonzero, uint32_t bit) {       // integer selects: no branches
+    return __uint_as_float((0u - nonzero) & (0xBF800000u ^ (bit << 31)));
   }
   template <bool PACK>
-  __device__ static void observe(const args& a, float* o, int t, int query, uint64_t ctx) {
+  __device__ static void observe(const args& a, float* o, int t, int query, uint64_t ctx, const bsx_bit_sink* sink) {
     BSX_NO_CONTRACT
     o[0] = (float)(1.0 - (double)t / (double)a.L);              // memory_chain.py:64
     o[1] = (t == a.L - 1) ? (float)query : 0.0f;                // :66-67
     if constexpr (PACK) {
-      uint32_t* w = reinterpret_cast<uint32_t*>(o);
-      w[2] = (t == 0) ? 1u : 0u;
-      w[3] = (uint32_t)ctx;
-      w[4] = (uint32_t)(ctx >> 32);
+      if (t == 0) {                                             // :69-70
+        const int n0 = a.nb < 32 ? a.nb : 32;
+        sink->put(0, 0, 0xFFFFFFFFu, n0);
+        sink->put(1, 0, (uint32_t)ctx, n0);
+        if (a.nb > 32) {
+          sink->put(0, 1, 0xFFFFFFFFu, a.nb - 32);
+          sink->put(1, 1, (uint32_t)(ctx >> 32), a.nb - 32);
+        }
+      }
     } else {
       for (int b = 0; b < a.nb; ++b)                            // :69-70
         o[2 + b] = (t == 0) ? (float)(2 * (int)((ctx >> b) & 1ull) - 1) : 0.0f;
     }
   }
   template <int LOG, int MT, bool PACK = false>
-  __device__ static int step(const args& a, int64_t i, int64_t oi, uint64_t lane, uint64_t step, float* o, double& reward) {
+  __device__ static int step(const args& a, int64_t i, int64_t oi, uint64_t lane, uint64_t step, float* o, double& reward,
+                             const bsx_bit_sink* sink = nullptr) {
     int32_t st = a.state[i];
     int t = st & 0xFFFFF, query = (st >> 20) & 0xFF;
     uint64_t ctx = a.context[i];
@@ -386,10 +406,10 @@ struct memory_chain_env {
       t = 0;
       a.context[i] = ctx;
       a.state[i] = t | (query << 20);
-      observe<PACK>(a, o, t, query, ctx);
+      observe<PACK>(a, o, t, query, ctx, sink);
       return BSX_FIRST;
     }
-    observe<PACK>(a, o, t, query, ctx);                         // :74 — before the increment
+    observe<PACK>(a, o, t, query, ctx, sink);                   // :74 — before the increment
     t += 1;                                                     // :75
     if (t - 1 < a.L) { a.state[i] = t | (query << 20); return BSX_MID; }   // :77-79
     if (a.action[oi] == (int)((ctx >> query) & 1ull)) { reward = 1.0; a.info[i] += 1.0; }   // :83-85
@@ -437,36 +457,29 @@ struct umbrella_chain_env {
     bsx_ctl ctl; const int32_t* action; int32_t* state; bsx_timestep_t out; double* info;
     int32_t obs_numel; int32_t L; int32_t nd;
   };
-  // Packed record: [need f32, has f32, time f32, distractor bits 32 to a word].
-  __host__ __device__ static int rec_words(const args& a) { return 3 + ((a.nd + 31) >> 5); }
-  // Branch-free on purpose (see memory_chain_env::expand).
-  __device__ static float expand(const args&, const uint32_t* rec, int j) {
-    const int b = j - 3;
-    const uint32_t head = (uint32_t)(b >> 31);                          // all ones for the three leading floats
-    const uint32_t w = rec[(head & (uint32_t)j) | (~head & (uint32_t)(3 + (b >> 5)))];
-    const uint32_t one = (0u - ((w >> (b & 31)) & 1u)) & 0x3F800000u;   // bit ? 1.0f : 0.0f
-    return __uint_as_float((head & w) | (~head & one));
-  }
+  // Packed rows: HEAD = [need, has, time]; element 3+b is distractor bit b as 0.0 / 1.0 (one plane).
+  static constexpr int HEAD = 3, PLANES = 1;
+  __device__ static float decode(uint32_t bit, uint32_t) { return __uint_as_float((0u - bit) & 0x3F800000u); }
   template <bool PACK>
-  __device__ static void observe(const args& a, float* o, int t, int need, int has, bsx_draws* d) {
+  __device__ static void observe(const args& a, float* o, int t, int need, int has, bsx_draws* d, const bsx_bit_sink* sink) {
     BSX_NO_CONTRACT
     o[0] = (float)need;                                         // umbrella_chain.py:62
     o[1] = (float)has;                                          // :63
     o[2] = (float)(1.0 - (double)t / (double)a.L);              // :64
     uint32_t w = 0;
     if constexpr (PACK) {
-      uint32_t* bits = reinterpret_cast<uint32_t*>(o + 3);
       uint32_t acc = 0;
       for (int b = 0; b < a.nd; ++b) {                          // :65 BernVec(nd)
         acc |= bsx_bern_vec_bit(d, b, &w) << (b & 31);
-        if ((b & 31) == 31 || b == a.nd - 1) { bits[b >> 5] = acc; acc = 0; }
+        if ((b & 31) == 31 || b == a.nd - 1) { sink->put(0, b >> 5, acc, (b & 31) + 1); acc = 0; }
       }
     } else {
       for (int b = 0; b < a.nd; ++b) o[3 + b] = (float)bsx_bern_vec_bit(d, b, &w);   // :65 BernVec(nd)
     }
   }
   template <int LOG, int MT, bool PACK = false>
-  __device__ static int step(const args& a, int64_t i, int64_t oi, uint64_t lane, uint64_t step, float* o, double& reward) {
+  __device__ static int step(const args& a, int64_t i, int64_t oi, uint64_t lane, uint64_t step, float* o, double& reward,
+                             const bsx_bit_sink* sink = nullptr) {
     BSX_NO_CONTRACT
     int32_t st = a.state[i];
     int t = st & 0xFFFFF, need = (st >> 20) & 1, has = (st >> 21) & 1;
@@ -476,7 +489,7 @@ struct umbrella_chain_env {
       t = 0;
       need = (int)bsx_bern(&d);
       has = (int)bsx_bern(&d);
-      observe<PACK>(a, o, t, need, has, &d);
+      observe<PACK>(a, o, t, need, has, &d, sink);
       bsx_draws_end<MT>(&d, a.ctl, i);
       a.state[i] = t | (need << 20) | (has << 21);
       return BSX_FIRST;
@@ -487,11 +500,11 @@ struct umbrella_chain_env {
     if (t == a.L) {                                             // :74-81
       if (has == need) reward = 1.0;
       else { reward = -1.0; a.info[i] += 2.0; }
-      observe<PACK>(a, o, t, need, has, &d);
+      observe<PACK>(a, o, t, need, has, &d, sink);
       type = BSX_LAST;
     } else {                                                    // :83-85
       reward = 2.0 * (double)bsx_bern(&d) - 1.0;
-      observe<PACK>(a, o, t, need, has, &d);
+      observe<PACK>(a, o, t, need, has, &d, sink);
       type = BSX_MID;
     }
     bsx_draws_end<MT>(&d, a.ctl, i);

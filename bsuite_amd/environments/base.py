@@ -52,6 +52,8 @@ class Environment(dm_env.EnvironmentBase):
 
   # Subclass constants.
   _supports_delta = False  # families whose observation is a board with <= 2 hot cells
+  _pipelined_rollout = False  # two-kernel families whose rollouts are software-pipelined (state_alt)
+  _state_alt = None
   _info_keys = ()          # names of the f64 info columns, in native column order
   _info_int_keys = ()      # keys the reference reports as Python ints
 
@@ -488,6 +490,12 @@ class Environment(dm_env.EnvironmentBase):
     call = self._call_desc
     call.force_reset = 0
     call.n_steps = T
+    if self._pipelined_rollout and T > 1:
+      # deep_sea / catch: a scratch state column lets every launch after the first carry the observation
+      # stream of step t beside the lane advance of step t+1 (bsx_call_t.state_alt)
+      if self._state_alt is None:
+        self._state_alt = torch.empty_like(self._state['state'])
+      call.state_alt = self._state_alt.data_ptr()
     kind, param, wseed, param2 = self._wrap
     call.wrap.kind, call.wrap.param, call.wrap.seed, call.wrap.param2 = kind, param, wseed, param2
     hip_stream = torch.cuda.current_stream(self._device).cuda_stream
@@ -502,6 +510,7 @@ class Environment(dm_env.EnvironmentBase):
         rc = self._launch(call, actions.data_ptr(), ptrs)
     finally:
       call.n_steps = 0
+      call.state_alt = None
     if rc != 0:
       _native.check(rc, f'{type(self).__name__} rollout')
     self._step_index += T

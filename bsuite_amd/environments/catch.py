@@ -33,6 +33,7 @@ class Catch(base.Environment):
 
   _abi_name = 'catch'
   _supports_delta = True
+  _pipelined_rollout = True
 
   def _native_args(self, call, action_ptr, out):
     return (ctypes.byref(self._cfg), ctypes.byref(call), action_ptr, self._state['state'].data_ptr(), out, self._info.data_ptr())

@@ -69,6 +69,7 @@ class DeepSea(base.Environment):
 
   _abi_name = 'deep_sea'
   _supports_delta = True
+  _pipelined_rollout = True
 
   def _native_args(self, call, action_ptr, out):
     return (ctypes.byref(self._cfg), ctypes.byref(call), action_ptr, self._state['state'].data_ptr(), out, self._info.data_ptr())

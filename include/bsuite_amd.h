@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define BSX_ABI_VERSION 8
+#define BSX_ABI_VERSION 9
 
 #define BSX_FIRST 0
 #define BSX_MID 1
@@ -163,6 +163,20 @@ typedef struct {
                                cast to f32 — the f64 value the reference's step() returns (e.g.
                                deep_sea's -0.01/N move cost, RewardScale's 0.001*r); 0.0 on FIRST.
                                The scalar dm_env view reads its TimeStep.reward from here.       */
+  int32_t* state_alt;       /* device [B] int32 or NULL (ABI v9): a second packed-state column for the
+                               two-kernel families (deep_sea, catch, mnist), whose observation stream
+                               reads the state column their lane advance wrote.  It lets the advance of
+                               step t+1 share ONE launch with the observation stream of step t (the
+                               stream keeps reading the column the advance no longer writes):
+                               - in a rollout (n_steps > 1; deep_sea, catch) it is scratch: after the
+                                 first advance, every launch is {stream of step t, advance of step
+                                 t+1}, the advances alternating between `state` and `state_alt`;
+                                 T + 1 launches instead of 2T, the final state ends up in `state`;
+                               - in a segment of a BSX_FAM_SWEEP_MIXED group the lane advance READS
+                                 `state_alt` and writes `state` (which the segment's stream reads): two
+                                 groups with the columns swapped step alternately, see
+                                 bsx_group_step_pipelined.
+                               Ignored by step()/reset() calls and by the other families.          */
 } bsx_call_t;
 
 /* ---- deep_sea : bsuite/environments/deep_sea.py:51-155 ------------------------------------ */

@@ -59,3 +59,38 @@ def test_rollout_equals_steps(family, kwargs, wrap, na, batch):
   torch.testing.assert_close(la.num_rows(), lb.num_rows(), rtol=0, atol=0)
   torch.testing.assert_close(eu.raw(a).episode_counters(), eu.raw(b).episode_counters(), rtol=0, atol=0)
   assert eu.raw(a).step_index == eu.raw(b).step_index == 5 + T + 1
+
+
+@pytest.mark.parametrize('family,kwargs,na', [('deep_sea', dict(size=6, deterministic=False, mapping_seed=1), 2),
+                                               ('deep_sea', dict(size=10, mapping_seed=42), 2),
+                                               ('catch', dict(), 3)])
+@pytest.mark.parametrize('T', [2, 3, 8])
+@pytest.mark.parametrize('logging', [False, True])
+def test_pipelined_rollout_equals_steps(family, kwargs, na, T, logging):
+  """deep_sea / catch rollouts are software-pipelined (bsx_call_t.state_alt): after the first advance every
+  launch is {observation stream of step t, lane advance of step t+1}, the advances alternating between two
+  state columns.  Even and odd T (the parity decides which column the first advance writes), with and without
+  the Logging wrapper (lean / full advance kernel); the outputs, the state left behind and the counters are
+  those of T step() calls."""
+  batch, seed = 1024, 5                      # B*cells % 4 == 0: the pipelined path (else it falls back)
+  g = torch.Generator(device='cuda'); g.manual_seed(T)
+  acts = torch.randint(na, (3 * T + 1, batch), generator=g, device='cuda', dtype=torch.int32)
+  a = eu.make_env(family, kwargs, batch=batch, lane_offset=3, seed=seed)
+  b = eu.make_env(family, kwargs, batch=batch, lane_offset=3, seed=seed)
+  if logging:
+    a, b = wrappers.Logging(a, None), wrappers.Logging(b, None)
+  assert eu.raw(a)._pipelined_rollout
+  for r in range(3):                          # consecutive rollouts: the state column handed over is the right one
+    ro = a.rollout(acts[r * T:(r + 1) * T])
+    for t in range(T):
+      ts = b.step(acts[r * T + t])
+      for x, y in zip((ro.step_type[t], ro.reward[t], ro.discount[t], ro.observation[t]),
+                      (ts.step_type, ts.reward, ts.discount, ts.observation)):
+        np.testing.assert_array_equal(x.cpu().numpy(), y.cpu().numpy(), err_msg=f'{family} rollout {r} t={t}')
+  assert eu.raw(a)._state_alt is not None
+  np.testing.assert_array_equal(eu.raw(a).state_dict()['state'].cpu().numpy(), eu.raw(b).state_dict()['state'].cpu().numpy())
+  ta, tb = a.step(acts[-1]), b.step(acts[-1])
+  np.testing.assert_array_equal(ta.observation.cpu().numpy(), tb.observation.cpu().numpy())
+  for k, v in eu.raw(a).bsuite_info().items():
+    torch.testing.assert_close(v, eu.raw(b).bsuite_info()[k], rtol=0, atol=0)
+  torch.testing.assert_close(eu.raw(a).episode_counters(), eu.raw(b).episode_counters(), rtol=0, atol=0)
