@@ -444,10 +444,15 @@ class Rank:
     acts = batch.random_actions(seed=1)          # keyed by segment: independent of the rank assignment
     mode = os.environ.get('BSX_SWEEP_MODE', 'grouped')
     grouped = mode in ('grouped', 'grouped_graph', 'grouped_streams')
+    # the sweep's actions are static tensors: step s+1 does not need the observations of step s, so one launch
+    # per step carries the store stream of step s beside the lane advance of step s+1
+    pipelined = (mode == 'grouped' and os.environ.get('BSX_SWEEP_MIX_ALL', '1') != '0'
+                 and os.environ.get('BSX_SWEEP_PIPELINED', '1') != '0')
     if grouped:
       batch.prepare_groups(acts, mix_small=os.environ.get('BSX_SWEEP_MIX_SMALL', '1') != '0',
                            mix_pairs=os.environ.get('BSX_SWEEP_MIX_PAIRS', '1') != '0',
-                           mix_all=os.environ.get('BSX_SWEEP_MIX_ALL', '1') != '0')
+                           mix_all=os.environ.get('BSX_SWEEP_MIX_ALL', '1') != '0',
+                           pipelined=pipelined)
       if mode == 'grouped_graph':              # group launches as concurrent branches of one HIP graph
         batch.capture_grouped(int(os.environ.get('BSX_SWEEP_STREAMS', '2')),
                               phased=os.environ.get('BSX_SWEEP_PHASED', '1') != '0')
@@ -489,7 +494,10 @@ class Rank:
                      'frac': achieved / HBM_PEAK_GBPS, 'traffic': None, 'kernel_ms': step_ms,
                      'algorithmic_bytes_per_launch': max_rank_bytes,
                      'algorithmic_bytes_all_ranks': total_bytes},
-        'launch': ((f'2 launches per sweep step ({len(batch.envs)} segments on rank 0 in one whole-sweep group: phase 0 '
+        'launch': ((f'1 launch per sweep step ({len(batch.envs)} segments on rank 0 in two alternating whole-sweep groups: '
+                    'the observation store stream of step s beside the lane advance of step s+1; the actions are static)'
+                    if pipelined else
+                    f'2 launches per sweep step ({len(batch.envs)} segments on rank 0 in one whole-sweep group: phase 0 '
                     'advances every lane and bumps the call counter, phase 1 is the observation store stream)'
                     if len(batch._groups) == 1 else
                     f'{len(batch._groups)} grouped launches per sweep step ({len(batch.envs)} segments on rank 0)')

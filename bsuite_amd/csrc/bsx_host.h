@@ -157,6 +157,7 @@ struct bsx_group {
   uint64_t* shared_counter = nullptr;   // BSX_FAM_SWEEP_MIXED: the call counter every segment reads; phase 0 bumps it
   uint32_t* d_ticket = nullptr;         //   ... when its last workgroup retires (device word, zero between launches)
   size_t lds_bytes = 0;                 // max dynamic LDS over segments (kernel 1)
+  uint64_t* trace = nullptr;            // diagnostics (bsx_group_trace): per-workgroup [start, end, tag] of phase 0
   void* d_args = nullptr;
   void* d_args2 = nullptr;
   int32_t* d_start = nullptr;           // [n+1] exclusive prefix of blocks
@@ -256,7 +257,7 @@ static int bsx_pair_call(const typename Fam::args& a0, const bsx_call_t* call, c
   };
   const uint32_t magic = bsx_div_magic(cells);
   static const int pipe_env = bsx_env_int("BSX_ROLLOUT_PIPELINED", 1);
-  static const int adv_last = bsx_env_int("BSX_PIPELINED_ADV_LAST", 0);
+  static const int place = bsx_env_int("BSX_PIPELINED_PLACE", 0);     // bsx_pipe_role_of: first (measured best)
   // the fused launch uses the 16-byte store stream: every [t] slice must start on a 16-byte boundary
   const bool pipelined = pipe_env != 0 && T > 1 && call->state_alt != nullptr && call->obs_paint == nullptr &&
                          cells >= 4u && (((uint64_t)B * cells) & 3ull) == 0;
@@ -289,8 +290,8 @@ static int bsx_pair_call(const typename Fam::args& a0, const bsx_call_t* call, c
     s.ctl.state_in = W(t); s.state = W(t + 1);
     float* obs_t = out.observation + (int64_t)t * B * (int64_t)cells;
     const dim3 grid((unsigned)(adv_blocks + str_blocks)), block(BSX_BLOCK);
-    if (lean) bsx_pipelined_kernel<Fam, true, HotFn, K><<<grid, block, 0, st>>>(s, (uint32_t)adv_blocks, (uint32_t)adv_last, obs_t, W(t), cells, magic, dv, fn);
-    else bsx_pipelined_kernel<Fam, false, HotFn, K><<<grid, block, 0, st>>>(s, (uint32_t)adv_blocks, (uint32_t)adv_last, obs_t, W(t), cells, magic, dv, fn);
+    if (lean) bsx_pipelined_kernel<Fam, true, HotFn, K><<<grid, block, 0, st>>>(s, (uint32_t)adv_blocks, (uint32_t)place, obs_t, W(t), cells, magic, dv, fn);
+    else bsx_pipelined_kernel<Fam, false, HotFn, K><<<grid, block, 0, st>>>(s, (uint32_t)adv_blocks, (uint32_t)place, obs_t, W(t), cells, magic, dv, fn);
   }
   if (rc == 0) rc = bsx_launch_hot_stream(out.observation + (int64_t)(T - 1) * B * (int64_t)cells, state, B, cells, magic, fn, st, K);
   return rc != 0 ? rc : bsx_launch_status();

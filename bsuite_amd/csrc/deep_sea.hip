@@ -57,6 +57,7 @@ extern "C" int bsx_group_set_deep_sea(bsx_group_t* g, int32_t index, const bsx_d
   if (bsx_is_mixed_pair_group(g)) {            // one segment of the mixed two-kernel group
     rc = deep_sea_make(cfg, call, action, state, out, info, &a);
     if (rc != 0) return rc;
+    a.ctl.state_in = call->state_alt;            // pipelined sweeps: the advance reads the other column
     const uint32_t cells = (uint32_t)(cfg->size * cfg->size);
     if (cells < 4u) return BSX_ERANGE;
     bsx_stream_seg<deep_sea_hot> sg;

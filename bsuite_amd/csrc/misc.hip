@@ -1,6 +1,7 @@
 // misc.hip — ABI version / error strings, the pure-store calibration kernel and the draw-stream
 // dump used by the tests to pin the device Philox / normal transform against the oracle.
 #include "bsx_host.h"
+#include "pair_mixed.h"
 
 extern "C" int bsx_abi_version(void) { return BSX_ABI_VERSION; }
 
@@ -174,6 +175,22 @@ extern "C" int bsx_group_step_phase(bsx_group_t* g, int32_t phase, void* hip_str
   if (g == nullptr) return BSX_ENULL;
   if (!g->committed || phase < 0 || phase >= g->n_phases) return BSX_EINVAL;
   return g->launch(g, phase, (hipStream_t)hip_stream);
+}
+
+extern "C" int bsx_group_step_pipelined(bsx_group_t* streams_of, bsx_group_t* advances_of, void* hip_stream) {
+  if (streams_of == nullptr || advances_of == nullptr) return BSX_ENULL;
+  if (!streams_of->committed || !advances_of->committed || streams_of->family != BSX_FAM_SWEEP_MIXED ||
+      advances_of->family != BSX_FAM_SWEEP_MIXED || streams_of->n != advances_of->n ||
+      streams_of->shared_counter != advances_of->shared_counter)
+    return BSX_EINVAL;
+  return bsx_sweep_launch_pipelined(streams_of, advances_of, (hipStream_t)hip_stream);
+}
+
+extern "C" int bsx_group_trace(bsx_group_t* g, uint64_t* buf) {
+  if (g == nullptr) return BSX_ENULL;
+  if (g->family != BSX_FAM_SWEEP_MIXED) return BSX_EMODE;
+  g->trace = buf;
+  return 0;
 }
 
 extern "C" int bsx_group_destroy(bsx_group_t* g) {

@@ -129,6 +129,7 @@ extern "C" int bsx_group_set_mnist(bsx_group_t* g, int32_t index, const bsx_mnis
   if (bsx_is_mixed_pair_group(g)) {            // one segment of the mixed two-kernel group (8 x 4 KiB runs)
     rc = mnist_make(cfg, call, action, state, out, info, &a, &o);
     if (rc != 0) return rc;
+    a.ctl.state_in = call->state_alt;            // pipelined sweeps: the advance reads the other column
     return bsx_mixed_put(g, BSX_FAM_MNIST, index, call, &a, sizeof(a), &o, sizeof(o),
                               (uint64_t)(call->n_lanes + BSX_BLOCK - 1) / BSX_BLOCK,
                               bsx_flat_blocks((uint64_t)call->n_lanes * o.cells, 8), 0);

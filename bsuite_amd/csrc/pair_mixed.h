@@ -6,6 +6,9 @@
 #define BSX_PAIR_MIXED_H_
 
 #include "bsx_host.h"
+#include "catch_fam.h"
+#include "deep_sea_fam.h"
+#include "mnist_fam.h"
 
 #define BSX_MIXED_ADV_STRIDE 1024      // phase-0 argument slot (advance args of a pair family, or a small family's args)
 #define BSX_MIXED_STR_STRIDE 1280      // phase-1 argument slot (observation stream args of a pair family)
@@ -22,6 +25,33 @@ int bsx_mixed_put(bsx_group* g, int32_t family, int32_t index, const bsx_call_t*
 int bsx_mixed_launch_stream(bsx_group* g, hipStream_t st);
 // phase 0 of a BSX_FAM_SWEEP_MIXED group (small_obs.hip)
 int bsx_sweep_launch_phase0(bsx_group* g, hipStream_t st);
+// one launch: the phase-1 store stream of `streams_of` beside phase 0 of `advances_of` (small_obs.hip)
+int bsx_sweep_launch_pipelined(bsx_group* streams_of, bsx_group* advances_of, hipStream_t st);
+
+// One workgroup of the mixed observation store stream: `block` of the phase-1 grid runs its segment's
+// family stream body (deep_sea 4 x 4 KiB, catch 2 x 4 KiB, mnist 8 x 4 KiB runs per workgroup).
+#define PAIR_MNIST_K 8
+__device__ __forceinline__ void pair_mixed_stream_body(const uint8_t* __restrict__ table, const int32_t* __restrict__ family,
+                                                       const bsx_group_index& gi, uint32_t block, float* s_lut) {
+  const bsx_group_slot w = bsx_group_find(gi, (int)block);
+  const uint8_t* slot = table + (size_t)w.seg * BSX_MIXED_STR_STRIDE;
+  switch (family[w.seg] & 0xFF) {                   // uniform per workgroup
+    case BSX_FAM_DEEP_SEA: {
+      const bsx_stream_seg<deep_sea_hot>& g = *reinterpret_cast<const bsx_stream_seg<deep_sea_hot>*>(slot);
+      bsx_hot_stream_body<deep_sea_hot, 4, BSX_BLOCK>(g.obs, g.state, g.n_lanes, g.cells, g.cells_magic, g.dv, g.fn, w.block);
+      break;
+    }
+    case BSX_FAM_CATCH: {
+      const bsx_stream_seg<catch_hot>& g = *reinterpret_cast<const bsx_stream_seg<catch_hot>*>(slot);
+      bsx_hot_stream_body<catch_hot, 2, BSX_BLOCK>(g.obs, g.state, g.n_lanes, g.cells, g.cells_magic, g.dv, g.fn, w.block);
+      break;
+    }
+    case BSX_FAM_MNIST:
+      mnist_observe_body<PAIR_MNIST_K, 3>(*reinterpret_cast<const mnist_observe_args*>(slot), w.block, s_lut);
+      break;
+    default: break;
+  }
+}
 
 static inline bool bsx_is_mixed_pair_group(const bsx_group* g) {
   return g->family == BSX_FAM_PAIR_MIXED || g->family == BSX_FAM_SWEEP_MIXED;

@@ -18,7 +18,6 @@
 
 #define PAIR_ADV_STRIDE BSX_MIXED_ADV_STRIDE
 #define PAIR_STR_STRIDE BSX_MIXED_STR_STRIDE
-#define PAIR_MNIST_K 8
 
 static_assert(sizeof(deep_sea_fam::args) <= PAIR_ADV_STRIDE && sizeof(catch_fam::args) <= PAIR_ADV_STRIDE &&
               sizeof(mnist_args) <= PAIR_ADV_STRIDE, "advance argument struct exceeds the mixed-group slot");
@@ -45,24 +44,7 @@ __global__ void __launch_bounds__(BSX_BLOCK) pair_mixed_stream_kernel(const uint
                                                                       const int32_t* __restrict__ family,
                                                                       const bsx_group_index gi) {
   __shared__ float s_lut[256];
-  const bsx_group_slot w = bsx_group_find(gi, (int)blockIdx.x);
-  const uint8_t* slot = table + (size_t)w.seg * PAIR_STR_STRIDE;
-  switch (family[w.seg] & 0xFF) {
-    case BSX_FAM_DEEP_SEA: {
-      const bsx_stream_seg<deep_sea_hot>& g = *reinterpret_cast<const bsx_stream_seg<deep_sea_hot>*>(slot);
-      bsx_hot_stream_body<deep_sea_hot, 4, BSX_BLOCK>(g.obs, g.state, g.n_lanes, g.cells, g.cells_magic, g.dv, g.fn, w.block);
-      break;
-    }
-    case BSX_FAM_CATCH: {
-      const bsx_stream_seg<catch_hot>& g = *reinterpret_cast<const bsx_stream_seg<catch_hot>*>(slot);
-      bsx_hot_stream_body<catch_hot, 2, BSX_BLOCK>(g.obs, g.state, g.n_lanes, g.cells, g.cells_magic, g.dv, g.fn, w.block);
-      break;
-    }
-    case BSX_FAM_MNIST:
-      mnist_observe_body<PAIR_MNIST_K, 3>(*reinterpret_cast<const mnist_observe_args*>(slot), w.block, s_lut);
-      break;
-    default: break;
-  }
+  pair_mixed_stream_body(table, family, gi, blockIdx.x, s_lut);
 }
 
 int bsx_mixed_launch_stream(bsx_group* g, hipStream_t st) {

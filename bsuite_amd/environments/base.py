@@ -179,10 +179,13 @@ class Environment(dm_env.EnvironmentBase):
     """Calls the family's C-ABI entry point."""
     return getattr(_native.lib, f'bsx_{self._abi_name}_step')(*self._native_args(call, action_ptr, out))
 
-  def _group_set(self, group, index: int, action: torch.Tensor) -> int:
+  def _group_set(self, group, index: int, action: torch.Tensor, *, out=None, state_alt=None,
+                 swap_state: bool = False) -> int:
     """Records this environment as segment `index` of a grouped launch (bsx_group_set_<family>):
-    static arguments — `action` is read in place every group step, outputs go to buffer 0, the call
-    index comes from the (shared) device step counter."""
+    static arguments — `action` is read in place every group step, outputs go to buffer 0 (or to `out`, a
+    dict of reward / discount / step_type / observation tensors), the call index comes from the (shared)
+    device step counter.  `state_alt` (two-kernel families, pipelined sweeps): the lane advance reads that
+    column and writes the environment's own; with `swap_state` the roles are exchanged."""
     self._ensure_allocated()
     if (not torch.is_tensor(action) or action.dtype != torch.int32 or action.device != self._device
         or tuple(action.shape) != (self._batch,) or not action.is_contiguous()):
@@ -198,8 +201,21 @@ class Environment(dm_env.EnvironmentBase):
     call.wrap.kind, call.wrap.param, call.wrap.seed, call.wrap.param2 = kind, param, wseed, param2
     call.stream.step_index = 0
     self._buf = 1 % self._num_buffers
-    return getattr(_native.lib, f'bsx_group_set_{self._abi_name}')(
-        group, index, *self._native_args(call, action.data_ptr(), self._out_ptrs[0]))
+    ptrs = self._out_ptrs[0] if out is None else _native.TimeStepPtrs(
+        out['reward'].data_ptr(), out['discount'].data_ptr(), out['step_type'].data_ptr(), out['observation'].data_ptr())
+    own = self._state.get('state')
+    try:
+      if state_alt is not None:
+        if swap_state:
+          self._state['state'], call.state_alt = state_alt, own.data_ptr()
+        else:
+          call.state_alt = state_alt.data_ptr()
+      return getattr(_native.lib, f'bsx_group_set_{self._abi_name}')(
+          group, index, *self._native_args(call, action.data_ptr(), ptrs))
+    finally:
+      call.state_alt = None
+      if state_alt is not None:
+        self._state['state'] = own
 
   def _set_wrap_mt_seeds(self, seeds):
     """rng='mt19937': RewardNoise's own np.random.RandomState(seed) per lane (wrappers.py:267)."""

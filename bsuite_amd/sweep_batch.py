@@ -157,7 +157,7 @@ class SweepBatch:
 
   # -- grouped launches --------------------------------------------------------------------
   def prepare_groups(self, actions: Sequence[torch.Tensor], mix_small: bool = True, mix_pairs: bool = True,
-                     mix_all: bool = True):
+                     mix_all: bool = True, pipelined: bool = False):
     """Builds the launch groups.  With `mix_all` (default) ONE group for the whole sweep
     (BSX_FAM_SWEEP_MIXED): a sweep step is two launches — phase 0 advances every lane of every family
     and bumps the shared call counter, phase 1 is the observation store stream of the two-kernel
@@ -167,7 +167,17 @@ class SweepBatch:
     launch for all their segments), else one group per family; with `mix_small` ONE mixed group for
     all small-observation families together (BSX_FAM_SMALL_MIXED), else one per family.  Records every local segment with its static `actions` tensor and uploads the
     argument tables.  Returns the per-segment output TimeSteps (tensors that every `step_grouped()`
-    overwrites)."""
+    overwrites).
+
+    `pipelined` (with `mix_all`): the sweep's actions are static, so sweep step s+1 does not need the
+    observations of step s — ONE launch per step then carries the observation store stream of step s
+    beside the lane advance of step s+1 (bsx_group_step_pipelined).  Two whole-sweep groups over the same
+    segments alternate: their two-kernel segments have the state columns swapped (the stream of step s
+    keeps reading the column the advance of step s+1 does not write) and each has its own reward /
+    discount / step_type buffers (and observation buffers of the small families, which the advance
+    writes).  `step_grouped()` then returns the TimeSteps of the step whose stream it launched — the lanes
+    (state, info, episode counters) are one advance ahead of them; `release_groups()` leaves the state in
+    the environments' own columns."""
     import ctypes  # pylint: disable=import-outside-toplevel
     from bsuite_amd import _native  # pylint: disable=import-outside-toplevel
     from bsuite_amd import dm_env_compat as dm_env  # pylint: disable=import-outside-toplevel
@@ -185,7 +195,11 @@ class SweepBatch:
       if mix_all:
         klass = 0
       buckets.setdefault((group_family, klass), []).append(k)
+    if pipelined and not mix_all:
+      raise ValueError('pipelined sweep steps need the whole-sweep group (mix_all)')
     outs = [None] * len(self.envs)
+    outs_of = [outs, [None] * len(self.envs)]
+    self._state_alt = {}
     costs = []
     import os  # pylint: disable=import-outside-toplevel
     heavy_first = os.environ.get('BSX_SWEEP_HEAVY_FIRST', '1') != '0'
@@ -199,17 +213,33 @@ class SweepBatch:
           small_k = raw_k._abi_name not in ('deep_sea', 'catch', 'mnist')  # pylint: disable=protected-access
           return -int(np.prod(raw_k.observation_spec().shape)) if small_k else 1
         members = sorted(members, key=weight)
-      handle = ctypes.c_void_p()
-      _native.check(_native.lib.bsx_group_create(_native.FAMILY_IDS[name], len(members), ctypes.byref(handle)),
-                    'bsx_group_create')
-      self._groups.append(handle)
-      for idx, k in enumerate(members):
-        raw = self.envs[k].raw_env if hasattr(self.envs[k], 'raw_env') else self.envs[k]
-        _native.check(raw._group_set(handle, idx, actions[k]), f'bsx_group_set_{raw._abi_name}')  # pylint: disable=protected-access
-        o = raw._out[0]  # pylint: disable=protected-access
-        outs[k] = dm_env.TimeStep(step_type=o['step_type'], reward=o['reward'], discount=o['discount'],
-                                  observation=o['observation'])
-      _native.check(_native.lib.bsx_group_commit(handle), 'bsx_group_commit')
+      def build(parity):
+        handle = ctypes.c_void_p()
+        _native.check(_native.lib.bsx_group_create(_native.FAMILY_IDS[name], len(members), ctypes.byref(handle)),
+                      'bsx_group_create')
+        self._groups.append(handle)
+        for idx, k in enumerate(members):
+          raw = self.envs[k].raw_env if hasattr(self.envs[k], 'raw_env') else self.envs[k]
+          extra = {}
+          o = raw._out[0]  # pylint: disable=protected-access
+          if pipelined:
+            pair = raw._abi_name in ('deep_sea', 'catch', 'mnist')  # pylint: disable=protected-access
+            if pair:
+              if k not in self._state_alt:
+                self._state_alt[k] = raw._state['state'].clone()  # pylint: disable=protected-access
+              extra = dict(state_alt=self._state_alt[k], swap_state=(parity == 1))
+            if parity == 1:
+              o = dict(reward=torch.empty_like(o['reward']), discount=torch.empty_like(o['discount']),
+                       step_type=torch.empty_like(o['step_type']),
+                       observation=o['observation'] if pair else torch.empty_like(o['observation']))
+              extra['out'] = o
+          _native.check(raw._group_set(handle, idx, actions[k], **extra), f'bsx_group_set_{raw._abi_name}')  # pylint: disable=protected-access
+          outs_of[parity][k] = dm_env.TimeStep(step_type=o['step_type'], reward=o['reward'], discount=o['discount'],
+                                               observation=o['observation'])
+        _native.check(_native.lib.bsx_group_commit(handle), 'bsx_group_commit')
+      build(0)
+      if pipelined:
+        build(1)
       costs.append(sum(self.segments[k][2] * bytes_per_step(int(np.prod(self.envs[k].observation_spec().shape)))
                        for k in members))
     order = sorted(range(len(costs)), key=lambda j: -costs[j])
@@ -217,12 +247,27 @@ class SweepBatch:
     self._self_bump = mix_all                 # a whole-sweep group moves the call counter on by itself
     self._group_actions = list(actions)      # keep the static action tensors alive
     self._group_outs = outs
-    return outs
+    self._pipelined = bool(pipelined)
+    self._pipelined_outs = outs_of
+    self._pipelined_step = 0
+    return outs_of if pipelined else outs
 
   def step_grouped(self):
     """One sweep step = one grouped launch per (family, class) + one call-counter bump."""
     from bsuite_amd import _native  # pylint: disable=import-outside-toplevel
     stream = torch.cuda.current_stream(self.device).cuda_stream
+    if getattr(self, '_pipelined', False):
+      # one launch: observation stream of sweep step s (group s & 1) | lane advance of step s + 1 (the other)
+      s = self._pipelined_step
+      if s == 0:                               # prologue: the lane advance of step 0 on its own
+        _native.check(_native.lib.bsx_group_step_phase(self._groups[0], 0, stream), 'bsx_group_step_phase')
+        self._pending_steps += 1
+      rc = _native.lib.bsx_group_step_pipelined(self._groups[s & 1], self._groups[(s + 1) & 1], stream)
+      if rc != 0:
+        _native.check(rc, 'bsx_group_step_pipelined')
+      self._pipelined_step = s + 1
+      self._pending_steps += 1
+      return self._pipelined_outs[s & 1]
     for handle in self._groups:
       rc = _native.lib.bsx_group_step(handle, stream)
       if rc != 0:
@@ -402,6 +447,14 @@ class SweepBatch:
       self.join_streams()
       torch.cuda.synchronize(self.device)
       self._pipe = self._small = None
+    if getattr(self, '_pipelined', False) and self._groups:
+      # advances of odd steps wrote the alternate state columns: hand the lanes back in the environments' own
+      if self._pipelined_step % 2 == 1:
+        for k, alt in self._state_alt.items():
+          raw = self.envs[k].raw_env if hasattr(self.envs[k], 'raw_env') else self.envs[k]
+          raw._state['state'].copy_(alt)  # pylint: disable=protected-access
+      torch.cuda.synchronize(self.device)
+      self._pipelined, self._state_alt = False, {}
     for handle in self._groups:
       _native.lib.bsx_group_destroy(handle)
     self._groups = []

@@ -366,8 +366,9 @@ int bsx_group_set_mountain_car(bsx_group_t* g, int32_t index, const bsx_mountain
                                bsx_timestep_t out, double* info);
 int bsx_group_set_mnist(bsx_group_t* g, int32_t index, const bsx_mnist_t* cfg, const bsx_call_t* call,
                         const int32_t* action, int32_t* state, bsx_timestep_t out, double* info);
-/* Tile class (lanes per workgroup: 256 or 64) a small-observation segment with `numel` observation
- * floats gets inside a group; segments of one group must share it (BSX_EINVAL otherwise). */
+/* Tile class (lanes per workgroup) a small-observation segment with `numel` observation floats gets
+ * inside a group; segments of one group must share it.  Since ABI v9 always 256: the wide rows are
+ * staged as bit planes (bsuite_amd/csrc/small_obs.hip), the 64-lane class is gone. */
 int bsx_group_small_class(int32_t numel);
 int bsx_group_commit(bsx_group_t* g);
 int bsx_group_step(bsx_group_t* g, void* hip_stream);
@@ -377,6 +378,24 @@ int bsx_group_step(bsx_group_t* g, void* hip_stream);
  * the small-observation groups have 1.  bsx_group_step == all phases in order on one stream. */
 int bsx_group_phases(const bsx_group_t* g);
 int bsx_group_step_phase(bsx_group_t* g, int32_t phase, void* hip_stream);
+/* Software-pipelined sweep step (ABI v9), for callers whose actions do not depend on the observations
+ * (a rollout with given actions, BASELINE config 5): ONE launch runs phase 1 — the observation stream —
+ * of `streams_of` beside phase 0 — every lane's advance — of `advances_of`.  Both are committed
+ * BSX_FAM_SWEEP_MIXED groups over the same segments; their two-kernel segments were set with the state
+ * columns swapped (group E: state = A, state_alt = B; group O: state = B, state_alt = A; B starts as a
+ * copy of A) and each group has its own reward / discount / step_type buffers (and observation buffers
+ * for the small-observation segments, which phase 0 writes).  Schedule:
+ *     bsx_group_step_phase(E, 0)                       lane advance of sweep step 0
+ *     bsx_group_step_pipelined(E, O)                   stream of step 0 | advance of step 1
+ *     bsx_group_step_pipelined(O, E)                   stream of step 1 | advance of step 2 ...
+ * After launch s the TimeStep of step s is complete in the buffers of group (s even ? E : O); the lanes
+ * are one advance ahead of it. */
+int bsx_group_step_pipelined(bsx_group_t* streams_of, bsx_group_t* advances_of, void* hip_stream);
+/* Diagnostics (ABI v9): with a device buffer of 3 * (phase-0 workgroups) uint64, every phase-0 workgroup of a
+ * BSX_FAM_SWEEP_MIXED group records buf[3b] = start, buf[3b+1] = end (wall_clock64(): 100 MHz), buf[3b+2] =
+ * its segment's family id on every bsx_group_step / step_phase(0) that follows; NULL switches it off.  Where
+ * the latency-bound phase 0 of a sweep step spends its time (tools/sweep_phase0_trace.py). */
+int bsx_group_trace(bsx_group_t* g, uint64_t* buf);
 int bsx_group_destroy(bsx_group_t* g);
 
 /* ---- observation adapter ------------------------------------------------------

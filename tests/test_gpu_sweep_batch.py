@@ -73,7 +73,7 @@ def test_sweep_rank_assignment_is_a_partition():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize('mode', ['whole_sweep', 'whole_sweep_graph', 'eager', 'streams', 'graph', 'graph_phased', 'per_family',
+@pytest.mark.parametrize('mode', ['whole_sweep', 'whole_sweep_pipelined', 'whole_sweep_graph', 'eager', 'streams', 'graph', 'graph_phased', 'per_family',
                                   'pairs_per_family'])
 def test_grouped_sweep_equals_standalone_envs(tmp_path, mode):
   """One grouped launch per family advances every segment exactly like its standalone environment
@@ -90,8 +90,14 @@ def test_grouped_sweep_equals_standalone_envs(tmp_path, mode):
   batch = sb.SweepBatch(ids, total, seed=seed, env_kwargs=kw)
   acts = batch.random_actions(seed=2)
   outs = batch.prepare_groups(acts, mix_small=(mode != 'per_family'), mix_pairs=(mode not in ('per_family', 'pairs_per_family')),
-                              mix_all=mode.startswith('whole_sweep'))
-  if mode.startswith('whole_sweep'):
+                              mix_all=mode.startswith('whole_sweep'), pipelined=(mode == 'whole_sweep_pipelined'))
+  ahead = 0
+  if mode == 'whole_sweep_pipelined':
+    # two groups (state columns swapped, own TimeStep buffers) alternate: ONE launch per sweep step carries
+    # the store stream of step s beside the lane advance of step s+1, so the lanes run one advance ahead
+    assert len(batch._groups) == 2
+    ahead = 1
+  elif mode.startswith('whole_sweep'):
     assert len(batch._groups) == 1               # ONE group: two launches per sweep step, nothing else
   elif mode == 'per_family':
     assert len(batch._groups) == 9               # families, not segments
@@ -111,9 +117,11 @@ def test_grouped_sweep_equals_standalone_envs(tmp_path, mode):
     batch.join_streams()
   else:
     for _ in range(reps):
-      batch.step_grouped()
+      last = batch.step_grouped()
+    if ahead:
+      outs = last                                # the TimeSteps of the step whose stream ran last
   batch.sync()
-  assert all(eu.raw(e).step_index == reps for e in batch.envs)
+  assert all(eu.raw(e).step_index == reps + ahead for e in batch.envs)
   for (bid, begin, lanes), a, out, env in zip(batch.segments, acts, outs, batch.envs):
     name = bid.split('/')[0]
     ekw = dict(kw.get(name, {}))
@@ -124,10 +132,25 @@ def test_grouped_sweep_equals_standalone_envs(tmp_path, mode):
       ts = ref.step(a)
     for x, y in zip(eu.to_np(out), eu.to_np(ts)):
       np.testing.assert_array_equal(x, y, err_msg=bid)
+    for _ in range(ahead):
+      ref.step(a)
     for k, v in ref.bsuite_info().items():
       torch.testing.assert_close(env.bsuite_info()[k], v, rtol=0, atol=0)
     torch.testing.assert_close(eu.raw(env).episode_counters(), eu.raw(ref).episode_counters(), rtol=0, atol=0)
   batch.release_groups()
+  if ahead:                                      # the lanes come back in the environments' own state columns
+    for (bid, begin, lanes), a, env in zip(batch.segments, acts, batch.envs):
+      if bid.split('/')[0] not in ('deep_sea', 'catch', 'catch_noise', 'mnist'):
+        continue
+      name = bid.split('/')[0]
+      ekw = dict(kw.get(name, {}))
+      if sweep.SETTINGS[bid].get('seed', 0) is None or 'seed' not in sweep.SETTINGS[bid]:
+        ekw['seed'] = seed
+      ref = bsuite_amd.load_from_id(bid, batch=lanes, lane_offset=begin, num_buffers=1, **ekw)
+      for _ in range(reps + 1):
+        ref.step(a)
+      np.testing.assert_array_equal(eu.raw(env).state_dict()['state'].cpu().numpy(),
+                                    eu.raw(ref).state_dict()['state'].cpu().numpy(), err_msg=bid)
 
 
 @pytest.mark.gpu

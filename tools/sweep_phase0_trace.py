@@ -1,0 +1,76 @@
+"""Where phase 0 of a config-5 sweep step (one launch: every lane's advance) spends its time: per-workgroup
+start / end stamps (bsx_group_trace, 100 MHz wall clock) of one step, summarised per family.
+
+  python tools/sweep_phase0_trace.py [--lanes 1048576] [--out gpurun_out/sweep_phase0_trace.json]
+"""
+import argparse
+import collections
+import json
+import os
+import sys
+import tempfile
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from bsuite_amd import _native  # noqa: E402
+from bsuite_amd import sweep_batch as sb  # noqa: E402
+from bsuite_amd.utils import datasets  # noqa: E402
+
+
+def main():
+  ap = argparse.ArgumentParser()
+  ap.add_argument('--lanes', type=int, default=1 << 20)
+  ap.add_argument('--out', default=os.path.join(ROOT, 'gpurun_out', 'sweep_phase0_trace.json'))
+  args = ap.parse_args()
+  d = np.load(os.path.join(ROOT, 'tests', 'golden', 'mnist_synthetic_dataset.npz'))
+  tmp = tempfile.mkdtemp(prefix='bsx_mnist_')
+  datasets.write_idx_files(tmp, d['images_u8'], d['labels'])
+  mn = dict(data_dir=tmp)
+  batch = sb.SweepBatch(None, args.lanes, seed=42, env_kwargs=dict(mnist=mn, mnist_noise=mn, mnist_scale=mn))
+  acts = batch.random_actions(seed=1)
+  batch.prepare_groups(acts)
+  for _ in range(30):
+    batch.step_grouped()
+  torch.cuda.synchronize()
+  n_blocks = sum((lanes + 255) // 256 for _, _, lanes in batch.segments)
+  buf = torch.zeros(3 * n_blocks, dtype=torch.int64, device='cuda')
+  _native.check(_native.lib.bsx_group_trace(batch._groups[0], buf.data_ptr()), 'bsx_group_trace')
+  names = {v: k for k, v in _native.FAMILY_IDS.items()}
+  summary = []
+  for rep in range(3):
+    batch.step_grouped()
+    torch.cuda.synchronize()
+    t = buf.cpu().numpy().reshape(-1, 3)
+    t0 = t[:, 0].min()
+    start, end, tag = (t[:, 0] - t0) / 100.0, (t[:, 1] - t0) / 100.0, t[:, 2]      # us
+    rec = {'rep': rep, 'workgroups': int(n_blocks), 'span_us': float(end.max()),
+           'last_start_us': float(start.max()), 'families': {}}
+    for fam in sorted(set(tag.tolist())):
+      m = tag == fam
+      life = end[m] - start[m]
+      rec['families'][names.get(int(fam), str(fam))] = {
+          'workgroups': int(m.sum()), 'life_us_median': float(np.median(life)), 'life_us_p95': float(np.percentile(life, 95)),
+          'life_us_max': float(life.max()), 'first_start_us': float(start[m].min()), 'last_end_us': float(end[m].max())}
+    # how many workgroups are resident over time
+    ev = sorted([(s, 1) for s in start] + [(e, -1) for e in end])
+    cur, peak = 0, 0
+    for _, dlt in ev:
+      cur += dlt
+      peak = max(peak, cur)
+    rec['peak_resident_workgroups'] = peak
+    hist = collections.Counter(int(s) for s in start)
+    rec['starts_per_us'] = [hist.get(u, 0) for u in range(int(end.max()) + 1)]
+    summary.append(rec)
+    print(json.dumps({k: v for k, v in rec.items() if k != 'starts_per_us'}))
+    print('starts per us:', rec['starts_per_us'])
+  _native.check(_native.lib.bsx_group_trace(batch._groups[0], None), 'bsx_group_trace')
+  os.makedirs(os.path.dirname(args.out), exist_ok=True)
+  json.dump(summary, open(args.out, 'w'), indent=1)
+  batch.release_groups()
+
+
+if __name__ == '__main__':
+  main()
