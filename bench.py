@@ -418,6 +418,9 @@ class Rank:
     launch = ('eager step()' if r['mode'] == 'eager' else
               f"hipGraph of {r['chunk']} step() launches" if r['mode'] == 'graph' else
               f"rollout(T={r['chunk']}) per call")
+    if r['mode'] == 'rollout' and r['family'] in ('deep_sea', 'catch'):
+      launch += (' — software-pipelined: T+1 launches, each observation store stream beside the next step\'s '
+                 'lane advance (bsx_call_t.state_alt)')
     return {'value': r['value'], 'unit': 'env-steps/s', 'steps': r['steps'], 'ms_per_step': r['wall'] / r['steps'] * 1e3,
             'workload': f"{r['bsuite_id']} ({r['family']}) random-action rollout, dense TimeStep, "
                         f"{r['lanes']} lanes per GPU x {self.world} GPU(s)",
@@ -559,6 +562,12 @@ class Rank:
         return self.guarded(workload, lambda: self.sub_record(self.measure(workload, n_lanes, k, w, md, ch)))
 
       also['catch/0'] = sub('catch', lanes)                      # the other half of BASELINE.json's metric
+      if world == 1:
+        # rollout(actions[T,B]) of the two-kernel families: the open-loop form of the same metric, pipelined
+        K32 = (K + 31) // 32 * 32
+        if 'error' not in also['catch/0']:
+          also['catch/0']['rollout32'] = sub('catch', lanes, 'rollout', 32, K32, 32)
+        also['deep_sea/10 rollout16'] = sub('deep_sea', lanes, 'rollout', 16, 48, 16)
       if world == 1:
         for w_ in ('cartpole', 'mountain_car'):                  # BASELINE configs[3]
           bid = WORKLOADS[w_][0]

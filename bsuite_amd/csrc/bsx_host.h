@@ -147,7 +147,7 @@ static inline int bsx_launch_hot_stream(float* obs, const int32_t* state, int64_
 struct bsx_group {
   int32_t family = -1;
   int32_t n = 0;
-  int32_t klass = -1;                   // family-specific launch class (e.g. LPB of small_obs), -1 unset
+  int32_t klass = -1;                   // family-specific launch class (lanes per workgroup of small_obs), -1 unset
   size_t arg_size = 0, arg2_size = 0;
   std::vector<uint8_t> args, args2;     // n * arg_size  /  n * arg2_size (second kernel of a pair)
   std::vector<int32_t> blocks, blocks2; // workgroups of each segment in kernel 1 / kernel 2

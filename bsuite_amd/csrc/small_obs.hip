@@ -8,12 +8,12 @@
 //   mountain_car      bsuite/environments/mountain_car.py:62-90
 // each with the auto-reset of bsuite/environments/base.py:54-65.
 //
-// One kernel shape for all of them: thread t advances lane (block*LPB + t) from coalesced SoA
-// column loads, writes its observation row into an LDS tile [LPB x numel], and after one barrier
-// the whole block streams that tile to HBM as consecutive 16-byte chunks (a lane-per-row global
-// store would be a stride-(4*numel) scatter).  Physics state is f32 on the device (the reference
-// holds Python floats); rewards and the time-fraction observation are formed in f64 exactly as the
-// reference forms them and cast once.
+// One kernel shape for all of them: thread t advances lane (block*256 + t) from coalesced SoA column
+// loads and either stores its short observation row itself or — the wide rows of memory_chain /
+// umbrella_chain — leaves it as bits in an LDS tile that the whole block streams to HBM as consecutive
+// 16-byte chunks (small_obs_body, below).  Physics state is f32 on the device (the reference holds
+// Python floats); rewards and the time-fraction observation are formed in f64 exactly as the reference
+// forms them and cast once.
 #include "bsx_host.h"
 #include "bsx_math.h"
 #include "catch_fam.h"
@@ -237,7 +237,7 @@ static int small_obs_group_launch(bsx_group* g, int phase, hipStream_t st) {
 static int small_obs_mixed_launch(bsx_group* g, int phase, hipStream_t st);
 
 // Tile class of a segment inside a grouped launch (segments of one group must share it).  Always 256 since
-// the packed records: the 64-lane class for rows wider than 32 floats is gone (kept in the ABI so that a
+// the bit-plane tiles: the 64-lane class for rows wider than 32 floats is gone (kept in the ABI so that a
 // caller that buckets segments by class keeps working).
 extern "C" int bsx_group_small_class(int32_t numel) { (void)numel; return BSX_BLOCK; }
 
@@ -923,8 +923,8 @@ static int small_obs_mixed_launch(bsx_group* g, int phase, hipStream_t st) {
 // BSX_FAM_SWEEP_MIXED: ONE launch advances every lane of a heterogeneous sweep — the lane-advance of
 // deep_sea / catch / mnist segments (whose observation stream follows as phase 1, pair_mixed.hip) and the
 // complete step of every small-observation segment.  All of this is latency-bound work that moves a
-// few percent of the sweep's bytes; as separate launches (advance, 256-lane small groups, 64-lane small
-// groups, counter bump) it cost ~45 us of a ~185 us sweep step whether serialised or spread over HIP
+// few percent of the sweep's bytes; as separate launches (advance, two small-family groups, counter
+// bump) it cost ~45 us of a ~185 us sweep step whether serialised or spread over HIP
 // streams (cross-queue waits cost ~10 us each; kernels sharing the machine with the store stream
 // stretch it: profiles/r02/ab_sweep_*.log, sweep_*_timeline*.txt).  The last workgroup to retire bumps
 // the call counter the segments share, so no other kernel has to.

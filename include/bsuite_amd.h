@@ -330,8 +330,7 @@ typedef struct bsx_group bsx_group_t;
 #define BSX_FAM_MOUNTAIN_CAR 7
 #define BSX_FAM_MNIST 8
 /* A group of this family accepts bsx_group_set_<family> of bandit, memory_chain, umbrella_chain,
- * discounting_chain, cartpole and mountain_car segments alike (all of one tile class: observation
- * rows of <= 32 floats, or all wider) and advances them with ONE launch. */
+ * discounting_chain, cartpole and mountain_car segments alike and advances them with ONE launch. */
 #define BSX_FAM_SMALL_MIXED 9
 #define BSX_FAM_PAIR_MIXED 10  /* segments of deep_sea, catch and mnist together: ONE advance launch + ONE
                                   observation-stream launch for all of them (bsx_group_set_deep_sea /

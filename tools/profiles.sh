@@ -18,20 +18,22 @@ f=$(find /tmp/prof_sweep -name "*kernel_trace.csv" | head -1)
 python - "$f" > $out/sweep_whole_group_timeline.txt <<'PY'
 import csv, sys
 rows=list(csv.DictReader(open(sys.argv[1])))
-rows=[r for r in rows if 'group_kernel' in r['Kernel_Name'] or 'counter_add' in r['Kernel_Name'] or 'pair_mixed' in r['Kernel_Name'] or 'sweep_phase0' in r['Kernel_Name']]
+rows=[r for r in rows if any(k in r['Kernel_Name'] for k in ('group_kernel', 'counter_add', 'pair_mixed', 'sweep_phase0', 'sweep_pipelined'))]
 rows.sort(key=lambda r:int(r['Start_Timestamp']))
-idx=[i for i,r in enumerate(rows) if 'sweep_phase0' in r['Kernel_Name']]
+idx=[i for i,r in enumerate(rows) if 'sweep_phase0' in r['Kernel_Name'] or 'sweep_pipelined' in r['Kernel_Name']]
 for s in (-4,-3,-2):
     a,b=idx[s], idx[s+1]
     t0=int(rows[a]['Start_Timestamp'])
-    print('--- sweep step (whole-sweep group: two launches)')
+    print('--- sweep step')
     for r in rows[a:b]:
         n=r['Kernel_Name'].split('(')[0][-60:]
         print(f"{(int(r['Start_Timestamp'])-t0)/1e3:8.1f} -> {(int(r['End_Timestamp'])-t0)/1e3:8.1f} us  {n}")
 PY
 cd $repo
 timeout 200 python bench.py --workload sweep --no-cpu-baseline > $out/bench_sweep_config5.json 2>/dev/null
-for w in bandit discounting_chain memory_len umbrella_length cartpole mountain_car catch deep_sea mnist; do
+BSX_SWEEP_PIPELINED=0 timeout 200 python bench.py --workload sweep --no-cpu-baseline > $out/bench_sweep_config5_two_launches.json 2>/dev/null
+timeout 200 python tools/sweep_phase0_trace.py --out $out/sweep_phase0_trace.json > $out/sweep_phase0_trace.log 2>&1
+for w in bandit discounting_chain memory_len umbrella_length umbrella_distract memory_size cartpole mountain_car catch deep_sea mnist; do
   timeout 100 python bench.py --workload $w --no-cpu-baseline --no-also 2>/dev/null | tail -1 | python -c "
 import sys,json; d=json.loads(sys.stdin.read()); r=d['roofline']; print('%-18s eager  %.3e env-steps/s  %.2f us/step  %.0f GB/s  frac %.3f' % ('$w', d['value'], r['kernel_ms']*1e3, r['achieved'], r['frac']))"
 done > $out/bench_all_workloads_eager.log
