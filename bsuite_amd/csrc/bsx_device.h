@@ -11,6 +11,7 @@
 
 #include "../../include/bsuite_amd.h"
 #include "../../include/bsx_stream.h"
+#include "bsx_index.h"
 
 #define BSX_BLOCK 256
 #define BSX_WAVE 64
@@ -418,26 +419,6 @@ __global__ void __launch_bounds__(BS) bsx_hot_stream_kernel(float* __restrict__ 
 // the OTHER column (bsx_call_t.state_alt) — so, unlike a fused {advance, stream} of the same step
 // (profiles/r02/ab_step1_fused_single_launch.log), no workgroup ever waits for another.  The first
 // adv_blocks of the workgroups advance lanes (bsx_pipe_role_of); the rest are the store stream.
-// Which workgroups of a pipelined launch advance lanes: `place` 0 = the first adv_blocks of the grid (default),
-// 1 = the last, 2 = spread evenly through the grid (one every grid/adv_blocks workgroups).  Measured
-// (profiles/r02/ab_pipelined_rollout.log, ab_sweep_pipelined.log): first is best; last leaves the latency-bound
-// advance alone at the end of the launch; spread is far worse than no pipelining at all (catch 54 us against 43.5,
-// deep_sea 625 against 594) — anything that interrupts the address-ordered store stream costs more than it hides.
-struct bsx_pipe_role { bool adv; uint32_t index; };
-__device__ __forceinline__ bsx_pipe_role bsx_pipe_role_of(uint32_t b, uint32_t grid, uint32_t adv_blocks, uint32_t place) {
-  bsx_pipe_role r;
-  if (place == 0u) { r.adv = b < adv_blocks; r.index = r.adv ? b : b - adv_blocks; return r; }
-  const uint32_t str_blocks = grid - adv_blocks;
-  if (place == 1u) { r.adv = b >= str_blocks; r.index = r.adv ? b - str_blocks : b; return r; }
-  const uint32_t every = grid / (adv_blocks > 0u ? adv_blocks : 1u);     // >= 1; uniform
-  const uint32_t j = b / every;
-  r.adv = j < adv_blocks && b == j * every;
-  uint32_t before = (b + every - 1u) / every;                            // advance workgroups in front of b
-  before = before < adv_blocks ? before : adv_blocks;
-  r.index = r.adv ? j : b - before;
-  return r;
-}
-
 template <class Fam, bool LEAN, class HotFn, int K>
 __global__ void __launch_bounds__(BSX_BLOCK) bsx_pipelined_kernel(const typename Fam::args a, const uint32_t adv_blocks,
                                                                   const uint32_t place,

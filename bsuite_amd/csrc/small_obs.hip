@@ -51,17 +51,14 @@ struct bsx_bit_sink {
   uint32_t base;           // flat bit index of the lane's element HEAD
   // ORs bits [32k, 32k+n) of the lane's bit string (n in 1..32, the low n bits of w) into plane p
   __device__ __forceinline__ void put(int p, int k, uint32_t w, int n) const {
-    if (n < 32) w &= (1u << n) - 1u;
-    const uint32_t pos = base + 32u * (uint32_t)k, sh = pos & 31u;
-    uint32_t* word = planes + p * stride + (pos >> 5);
-    atomicOr(word, w << sh);
-    if (sh + (uint32_t)n > 32u) atomicOr(word + 1, w >> (32u - sh));
+    uint32_t word, lo, hi;
+    int has_hi;
+    bsx_plane_split(base + 32u * (uint32_t)k, w, n, &word, &lo, &hi, &has_hi);
+    uint32_t* dst = planes + p * stride + word;
+    atomicOr(dst, lo);
+    if (has_hi) atomicOr(dst + 1, hi);
   }
 };
-
-__host__ __device__ static inline bool bsx_small_direct_shape(int numel) {
-  return numel <= 8 && (numel == 1 || numel == 3 || (numel & 1) == 0);
-}
 
 template <class Env, bool ROLLOUT, int LOG, int NOISE, int MT, bool DIRECT_ARG>
 __device__ __forceinline__ void small_obs_body(const typename Env::args& a, const int n_steps_arg,
