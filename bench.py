@@ -263,6 +263,21 @@ class Rank:
     torch.cuda.set_device(local_rank)
     self.dev = torch.device('cuda', local_rank)
     self._ceiling = None
+    self.warm_runtime()
+
+  def warm_runtime(self, launches=2048):
+    """The first time a process has more than ~256 launches in flight on a stream, the HIP runtime stalls once
+    for ~37 ms (it grows a pool; tools/step_loop_gpu_vs_host.py shows the one-off).  The host enqueues a step
+    in ~5.5 us, the kernels run 6.6-18 us, so a timed region of a few hundred steps would otherwise pay that
+    stall once, at a random step.  Take it here, before anything is timed."""
+    torch = self.torch
+    from bsuite_amd import _native
+    with torch.cuda.device(self.dev):
+      scratch = torch.zeros(1, dtype=torch.int64, device=self.dev)
+      stream_h = torch.cuda.current_stream(self.dev).cuda_stream
+      for _ in range(launches):
+        _native.lib.bsx_counter_add(scratch.data_ptr(), 0, stream_h)
+      torch.cuda.synchronize(self.dev)
 
   def sync_all(self):
     self.torch.cuda.synchronize(self.dev)

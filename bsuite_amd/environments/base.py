@@ -37,6 +37,15 @@ from bsuite_amd.dm_env_compat import specs
 _MASK63 = (1 << 63) - 1
 
 
+# torch.cuda.current_stream(dev).cuda_stream / torch.cuda.current_device() through their Python wrappers cost
+# 1.9 us / 0.4 us per call — a fifth of a step() of the tiny families; the C getters behind them ~0.1 us.
+_current_raw_stream = getattr(torch._C, '_cuda_getCurrentRawStream', None)   # pylint: disable=protected-access
+if _current_raw_stream is None:
+  def _current_raw_stream(index):
+    return torch.cuda.current_stream(index).cuda_stream
+_current_device = getattr(torch._C, '_cuda_getDevice', None) or torch.cuda.current_device   # pylint: disable=protected-access
+
+
 def _resolve_seed(seed: Optional[int]) -> int:
   """seed=None means fresh OS entropy, as np.random.RandomState(None) does in the reference."""
   if seed is None:
@@ -199,6 +208,7 @@ class Environment(dm_env.EnvironmentBase):
     call.force_reset, call.n_steps = 0, 0
     kind, param, wseed, param2 = self._wrap
     call.wrap.kind, call.wrap.param, call.wrap.seed, call.wrap.param2 = kind, param, wseed, param2
+    self._wrap_applied = self._wrap
     call.stream.step_index = 0
     self._buf = 1 % self._num_buffers
     ptrs = self._out_ptrs[0] if out is None else _native.TimeStepPtrs(
@@ -315,44 +325,62 @@ class Environment(dm_env.EnvironmentBase):
       self._call_desc.reward_f64 = self._reward_f64.data_ptr()
     if self._wrap_mt_seeds is not None:
       self._upload_wrap_mt()
+    # The host side of a step() call is part of the hot path: the tiny families' kernels run 5-7 us at 2^20
+    # lanes and a slower host leaves the GPU idle between launches (tools/host_overhead.py).  Everything that
+    # does not change between calls is resolved once: the entry point, its argument list per output buffer
+    # (state / info pointers never move: load_state_dict copies in place), the nested structs of the call
+    # descriptor, and the TimeStep tuples the batched view returns.
+    self._fn = getattr(_native.lib, f'bsx_{self._abi_name}_step')
+    self._argv = [list(self._native_args(self._call_desc, 0, p)) for p in self._out_ptrs]
+    self._call_stream, self._call_wrap = self._call_desc.stream, self._call_desc.wrap     # views of the same memory
+    self._wrap_applied = None
+    self._dev_index = self._device.index
+    self._timesteps = None if self._scalar else [
+        dm_env.TimeStep(step_type=o['step_type'], reward=o['reward'], discount=o['discount'], observation=o['observation'])
+        for o in self._out]
     self._allocated = True
 
   # ----------------------------------------------------------------------------------------
   # the hot path
-  def _call(self, action_ptr: int, force_reset: bool):
-    if torch.cuda.current_device() != self._device.index:
+  def _call(self, action_ptr: int, force_reset: bool) -> int:
+    """One reset()/step() launch; returns the index of the output buffer it wrote."""
+    if _current_device() != self._dev_index:
       # kernels launch in the current device's context: step an environment that lives elsewhere
       # (several GPUs driven from one process) under its own device
       with torch.cuda.device(self._device):
         return self._call(action_ptr, force_reset)
-    out_ptrs = self._out_ptrs[self._buf]
-    out = self._out[self._buf]
-    if self._delta:
-      self._call_desc.obs_paint = self._paint[self._buf].data_ptr()
-    self._buf = (self._buf + 1) % self._num_buffers
+    b = self._buf
+    self._buf = b + 1 if b + 1 < self._num_buffers else 0
     call = self._call_desc
+    if self._delta:
+      call.obs_paint = self._paint[b].data_ptr()
     call.force_reset = 1 if force_reset else 0
-    kind, param, wseed, param2 = self._wrap
-    call.wrap.kind, call.wrap.param, call.wrap.seed, call.wrap.param2 = kind, param, wseed, param2
-    hip_stream = torch.cuda.current_stream(self._device).cuda_stream
+    if self._wrap is not self._wrap_applied:       # the wrappers install a NEW tuple when they change it
+      w = self._call_wrap
+      w.kind, w.param, w.seed, w.param2 = self._wrap
+      self._wrap_applied = self._wrap
+    hip_stream = _current_raw_stream(self._dev_index)
     call.hip_stream = hip_stream
-    if self._device_step_counter and self._deferred_steps is not None:
-      # inside `step_counter_deferred()`: call index = device counter + position in the block
-      call.stream.step_index = self._deferred_steps
-      rc = self._launch(call, action_ptr, out_ptrs)
-      call.stream.step_index = 0
-      self._deferred_steps += 1
-    elif self._device_step_counter:
-      rc = self._launch(call, action_ptr, out_ptrs)
-      if rc == 0 and self._shared_step_counter is None:
-        rc = _native.lib.bsx_counter_add(self._step_base.data_ptr(), 1, hip_stream)
+    argv = self._argv[b]
+    argv[2] = action_ptr
+    if self._device_step_counter:
+      if self._deferred_steps is not None:
+        # inside `step_counter_deferred()`: call index = device counter + position in the block
+        self._call_stream.step_index = self._deferred_steps
+        rc = self._fn(*argv)
+        self._call_stream.step_index = 0
+        self._deferred_steps += 1
+      else:
+        rc = self._fn(*argv)
+        if rc == 0 and self._shared_step_counter is None:
+          rc = _native.lib.bsx_counter_add(self._step_base.data_ptr(), 1, hip_stream)
     else:
-      call.stream.step_index = self._step_index
-      rc = self._launch(call, action_ptr, out_ptrs)
+      self._call_stream.step_index = self._step_index
+      rc = self._fn(*argv)
     if rc != 0:
       _native.check(rc, f'{type(self).__name__} step')
     self._step_index += 1
-    return out
+    return b
 
   # ----------------------------------------------------------------------------------------
   # batched `Logging` bookkeeping (bsuite/utils/wrappers.py:34-147), fused into the kernels
@@ -437,13 +465,13 @@ class Environment(dm_env.EnvironmentBase):
   def _check_scalar_action(self, action: int):
     """Scalar view only: subclasses raise what the reference raises for an invalid action."""
 
-  def _wrap_output(self, out):
+  def _wrap_output(self, b: int):
     if not self._scalar:
-      return dm_env.TimeStep(step_type=out['step_type'], reward=out['reward'],
-                             discount=out['discount'], observation=out['observation'])
+      return self._timesteps[b]
+    out = self._out[b]
     if self._host_out:
       torch.cuda.current_stream(self._device).synchronize()     # the TimeStep is now in host memory
-      o = next(n for n, t in zip(self._out_np, self._out) if t is out)
+      o = self._out_np[b]
       st, reward, discount = int(o['step_type'][0]), float(self._reward_f64.numpy()[0]), float(o['discount'][0])
       obs = o['observation'][0].copy()                          # fresh array per step, like the reference
     else:
@@ -459,14 +487,22 @@ class Environment(dm_env.EnvironmentBase):
   def reset(self) -> dm_env.TimeStep:
     """Resets every lane (base.py:54-57) and returns the FIRST TimeStep."""
     self._reset_next_step = False
-    self._ensure_allocated()
+    if not self._allocated:
+      self._ensure_allocated()
     return self._wrap_output(self._call(0, force_reset=True))
 
   def step(self, action) -> dm_env.TimeStep:
     """Steps every lane; lanes whose previous step was LAST (or that are fresh) reset instead and
     ignore their action (base.py:59-65)."""
-    self._ensure_allocated()
-    return self._wrap_output(self._call(self._coerce_actions(action).data_ptr(), force_reset=False))
+    if not self._allocated:
+      self._ensure_allocated()
+    if (type(action) is torch.Tensor and action.dtype is torch.int32 and action.is_cuda and action.dim() == 1
+        and action.size(0) == self._batch and action.is_contiguous() and action.get_device() == self._dev_index
+        and not self._scalar):
+      ptr = action.data_ptr()                  # the common call: nothing to convert
+    else:
+      ptr = self._coerce_actions(action).data_ptr()
+    return self._wrap_output(self._call(ptr, force_reset=False))
 
   def rollout(self, actions) -> dm_env.TimeStep:
     """T consecutive step() calls in one entry-point call (batched view only).
@@ -514,6 +550,7 @@ class Environment(dm_env.EnvironmentBase):
       call.state_alt = self._state_alt.data_ptr()
     kind, param, wseed, param2 = self._wrap
     call.wrap.kind, call.wrap.param, call.wrap.seed, call.wrap.param2 = kind, param, wseed, param2
+    self._wrap_applied = self._wrap
     hip_stream = torch.cuda.current_stream(self._device).cuda_stream
     call.hip_stream = hip_stream
     try:
