@@ -34,7 +34,7 @@ timeout 200 python bench.py --workload sweep --no-cpu-baseline > $out/bench_swee
 BSX_SWEEP_PIPELINED=0 timeout 200 python bench.py --workload sweep --no-cpu-baseline > $out/bench_sweep_config5_two_launches.json 2>/dev/null
 timeout 200 python tools/sweep_phase0_trace.py --out $out/sweep_phase0_trace.json > $out/sweep_phase0_trace.log 2>&1
 for w in bandit discounting_chain memory_len umbrella_length umbrella_distract memory_size cartpole mountain_car catch deep_sea mnist; do
-  timeout 100 python bench.py --workload $w --no-cpu-baseline --no-also 2>/dev/null | tail -1 | python -c "
+  timeout 100 python bench.py --workload $w --steps 200 --warmup 40 --no-cpu-baseline --no-also 2>/dev/null | tail -1 | python -c "
 import sys,json; d=json.loads(sys.stdin.read()); r=d['roofline']; print('%-18s eager  %.3e env-steps/s  %.2f us/step  %.0f GB/s  frac %.3f' % ('$w', d['value'], r['kernel_ms']*1e3, r['achieved'], r['frac']))"
 done > $out/bench_all_workloads_eager.log
 timeout 600 python tools/pmc_traffic.py deep_sea $out/deep_sea_pmc_traffic.json $((3621*B)) "bsx_advance_kernel<deep_sea_fam>" "bsx_hot_stream_kernel<deep_sea_hot" -- --steps 20 --warmup 4 --no-cpu-baseline --no-also --workload deep_sea > $out/pmc_deep_sea.log 2>&1
