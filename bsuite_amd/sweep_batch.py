@@ -289,6 +289,8 @@ class SweepBatch:
     graph starts dependent nodes 6-14 us apart and consecutive replays ~20 us apart,
     profiles/r02/sweep_graph_timeline_*.txt.)  Call `join_streams()` before reading the outputs on
     the current stream."""
+    if getattr(self, '_pipelined', False):
+      raise RuntimeError('pipelined groups alternate inside step_grouped(); prepare_groups(pipelined=False) for this schedule')
     from bsuite_amd import _native  # pylint: disable=import-outside-toplevel
     if self._pipe is None:
       cur = torch.cuda.current_stream(self.device)
@@ -381,6 +383,8 @@ class SweepBatch:
     phased=False: whole groups as `num_streams` round-robin branches (the r01 topology).
     Groups are independent (disjoint segments); the shared call counter is bumped after the join.
     Call prepare_groups() first; then `replay_grouped()` per sweep step."""
+    if getattr(self, '_pipelined', False):
+      raise RuntimeError('pipelined groups alternate inside step_grouped(); prepare_groups(pipelined=False) for this schedule')
     from bsuite_amd import _native  # pylint: disable=import-outside-toplevel
     if not self._groups:
       raise RuntimeError('capture_grouped() needs prepare_groups() first')

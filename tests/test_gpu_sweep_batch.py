@@ -168,3 +168,21 @@ def test_group_set_rejects_actions_it_would_misread():
   batch.prepare_groups(acts)                                   # and the right ones are accepted
   batch.step_grouped()
   batch.sync()
+
+
+@pytest.mark.gpu
+def test_pipelined_groups_refuse_the_other_schedules():
+  batch = sb.SweepBatch(['catch/0', 'bandit/0', 'deep_sea/0'], 900, seed=1)
+  acts = batch.random_actions(seed=0)
+  with pytest.raises(ValueError):
+    batch.prepare_groups(acts, mix_all=False, pipelined=True)      # needs the whole-sweep group
+  outs = batch.prepare_groups(acts, pipelined=True)
+  assert len(outs) == 2 and len(batch._groups) == 2
+  with pytest.raises(RuntimeError):
+    batch.capture_grouped()
+  with pytest.raises(RuntimeError):
+    batch.step_grouped_streams()
+  first = batch.step_grouped()
+  assert first is outs[0] and batch.step_grouped() is outs[1] and batch.step_grouped() is outs[0]
+  batch.sync()
+  batch.release_groups()
