@@ -94,3 +94,36 @@ def test_pipelined_rollout_equals_steps(family, kwargs, na, T, logging):
   for k, v in eu.raw(a).bsuite_info().items():
     torch.testing.assert_close(v, eu.raw(b).bsuite_info()[k], rtol=0, atol=0)
   torch.testing.assert_close(eu.raw(a).episode_counters(), eu.raw(b).episode_counters(), rtol=0, atol=0)
+
+
+@pytest.mark.parametrize('place', ['1', '2'])
+def test_pipelined_rollout_other_placements(place):
+  """BSX_PIPELINED_PLACE (read once per process) = where the advance workgroups sit in the fused grid: the last
+  workgroups, or spread evenly.  The default (first) is what every other test runs; the A/B placements must
+  produce the same TimeSteps (catch at a batch whose stream has fewer / more workgroups than its advance)."""
+  import subprocess
+  import sys
+  import os
+  code = r'''
+import numpy as np, torch
+from tests import engine_util as eu
+for family, kwargs, na, batch in (('catch', dict(), 3, 1024), ('catch', dict(rows=40, columns=40), 3, 2048),
+                                  ('deep_sea', dict(size=9, mapping_seed=3), 2, 4096)):
+  g = torch.Generator(device='cuda'); g.manual_seed(1)
+  acts = torch.randint(na, (7, batch), generator=g, device='cuda', dtype=torch.int32)
+  a = eu.make_env(family, kwargs, batch=batch, lane_offset=5, seed=11)
+  b = eu.make_env(family, kwargs, batch=batch, lane_offset=5, seed=11)
+  ro = a.rollout(acts)
+  for t in range(7):
+    ts = b.step(acts[t])
+    for x, y in zip((ro.step_type[t], ro.reward[t], ro.discount[t], ro.observation[t]),
+                    (ts.step_type, ts.reward, ts.discount, ts.observation)):
+      np.testing.assert_array_equal(x.cpu().numpy(), y.cpu().numpy(), err_msg=f'{family} t={t}')
+  np.testing.assert_array_equal(eu.raw(a).state_dict()['state'].cpu().numpy(), eu.raw(b).state_dict()['state'].cpu().numpy())
+print('placements ok')
+'''
+  root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+  env = dict(os.environ, BSX_PIPELINED_PLACE=place, PYTHONPATH=root)
+  p = subprocess.run([sys.executable, '-c', code], cwd=root, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT,
+                     text=True, timeout=300)
+  assert p.returncode == 0 and 'placements ok' in p.stdout, p.stdout[-2000:]
