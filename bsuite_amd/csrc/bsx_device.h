@@ -44,6 +44,11 @@ struct bsx_ctl {
   bsx_logging_t log;        // log.steps == nullptr: logging off
 };
 
+// No Logging wrapper, no RewardNoise, counter-based draws: the call the lean instantiations serve.
+__host__ __device__ __forceinline__ bool bsx_ctl_lean(const bsx_ctl& c) {
+  return c.log.steps == nullptr && c.wrap_kind < BSX_WRAP_NOISE && c.mt_state == nullptr;
+}
+
 __device__ __forceinline__ uint64_t bsx_step_of(const bsx_ctl& c) {
   return c.step_index + (c.step_base ? *c.step_base : 0ull);
 }

@@ -193,17 +193,26 @@ static size_t small_obs_lds(const typename Env::args& a) {
   else return 0;
 }
 
-// One workgroup of a grouped launch: the single-step body with everything decided at run time.
+// One workgroup of a grouped launch: the single-step body.  A segment without Logging wrapper, RewardNoise and
+// MT19937 draws (uniform per workgroup) runs the lean instantiation, like a stand-alone call does: a cartpole
+// workgroup then issues a third fewer instructions, and the heavy workgroups are what a sweep's lane advance
+// waits for (profiles/r02/sweep_phase0_trace.json).
+template <class Env, bool D>
+__device__ __forceinline__ void small_obs_group_body_d(const typename Env::args& a, const uint32_t blk, float* s_obs,
+                                                       unsigned int* s_cnt) {
+  if (bsx_ctl_lean(a.ctl)) small_obs_body<Env, false, 0, 0, 0, D>(a, 1, blk, s_obs, s_cnt);
+  else small_obs_body<Env, false, -1, -1, -1, D>(a, 1, blk, s_obs, s_cnt);
+}
 template <class Env>
 __device__ __forceinline__ void small_obs_group_body(const typename Env::args& a, const uint32_t blk, float* s_obs,
                                                      unsigned int* s_cnt) {
   if constexpr (Env::PACKED) {
     if (!bsx_small_direct_shape(a.obs_numel)) {                 // uniform per workgroup
-      small_obs_body<Env, false, -1, -1, -1, false>(a, 1, blk, s_obs, s_cnt);
+      small_obs_group_body_d<Env, false>(a, blk, s_obs, s_cnt);
       return;
     }
   }
-  small_obs_body<Env, false, -1, -1, -1, true>(a, 1, blk, s_obs, s_cnt);
+  small_obs_group_body_d<Env, true>(a, blk, s_obs, s_cnt);
 }
 
 // Grouped launch: every workgroup looks up its segment and runs the single-step body on that
@@ -936,8 +945,18 @@ __device__ __forceinline__ void sweep_phase0_body(const uint8_t* __restrict__ ta
 #define SWEEP_SMALL_CASE(FAM, ENV) \
   case FAM: small_obs_group_body<ENV>(*reinterpret_cast<const ENV::args*>(slot), blk, s_obs, s_cnt); break;
   switch (tag) {
-    case BSX_FAM_DEEP_SEA: bsx_advance_body<deep_sea_fam>(*reinterpret_cast<const deep_sea_fam::args*>(slot), blk, s_ds, s_cnt); break;
-    case BSX_FAM_CATCH: bsx_advance_body<catch_fam>(*reinterpret_cast<const catch_fam::args*>(slot), blk, s_ca, s_cnt); break;
+    case BSX_FAM_DEEP_SEA: {
+      const deep_sea_fam::args& a = *reinterpret_cast<const deep_sea_fam::args*>(slot);
+      if (bsx_ctl_lean(a.ctl)) bsx_advance_body<deep_sea_fam, true>(a, blk, s_ds, s_cnt);
+      else bsx_advance_body<deep_sea_fam, false>(a, blk, s_ds, s_cnt);
+      break;
+    }
+    case BSX_FAM_CATCH: {
+      const catch_fam::args& a = *reinterpret_cast<const catch_fam::args*>(slot);
+      if (bsx_ctl_lean(a.ctl)) bsx_advance_body<catch_fam, true>(a, blk, s_ca, s_cnt);
+      else bsx_advance_body<catch_fam, false>(a, blk, s_ca, s_cnt);
+      break;
+    }
     case BSX_FAM_MNIST: mnist_advance_body(*reinterpret_cast<const mnist_args*>(slot), blk, s_cnt); break;
     SWEEP_SMALL_CASE(BSX_FAM_BANDIT, bandit_env)
     SWEEP_SMALL_CASE(BSX_FAM_MEMORY_CHAIN, memory_chain_env)
