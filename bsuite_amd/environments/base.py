@@ -510,8 +510,9 @@ class Environment(dm_env.EnvironmentBase):
     actions: int32 device tensor [T, B].  Returns a TimeStep whose fields carry a leading T
     dimension (step_type/reward/discount [T,B], observation [T,B,*obs_shape]) — exactly what T
     step() calls would have returned, in order.  The small-observation families run the T steps
-    inside ONE kernel launch (state stays in L2, HBM sees only actions in / TimeSteps out); deep_sea,
-    catch and mnist issue their kernel pair T times.  Output buffers are cached per T and
+    inside ONE kernel launch (state stays in L2, HBM sees only actions in / TimeSteps out); mnist issues
+    its kernel pair T times; deep_sea and catch are software-pipelined — after the first lane advance every
+    launch carries the observation stream of step t beside the advance of step t+1 (T+1 launches).  Output buffers are cached per T and
     overwritten by the next rollout of the same length."""
     if self._scalar:
       raise TypeError('rollout() needs the batched view (batch=B)')

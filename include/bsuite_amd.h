@@ -133,7 +133,9 @@ typedef struct {
                                array gains a leading T dimension (observation [T,B,obs_numel]), call
                                index of step t is step_index + t.  The small-observation families
                                fuse the T steps into one kernel; deep_sea / catch / mnist launch
-                               their kernel pair T times.  Not combinable with force_reset.      */
+                               their kernel pair T times — or, deep_sea / catch with `state_alt`,
+                               T + 1 launches (software-pipelined, below).  Not combinable with
+                               force_reset.                                                      */
   bsx_stream_t stream;
   bsx_reward_wrap_t wrap;
   uint64_t* counters;       /* device, nullable: BSX_COUNTER_SHARDS x BSX_COUNTER_STRIDE uint64.
