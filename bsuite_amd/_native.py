@@ -192,7 +192,7 @@ _SIGS.update({
     'bsx_group_small_class': ([ctypes.c_int32], ctypes.c_int),
     'bsx_group_step_phase': ([_G, ctypes.c_int32, _P], ctypes.c_int),
     'bsx_group_step_pipelined': ([_G, _G, _P], ctypes.c_int),
-    'bsx_group_trace': ([_G, _P], ctypes.c_int),
+    'bsx_group_trace': ([_G, _P, ctypes.c_int64], ctypes.c_int),
     'bsx_group_destroy': ([_G], ctypes.c_int),
 })
 for _fam in ('deep_sea', 'catch', 'bandit', 'memory_chain', 'umbrella_chain', 'discounting_chain',

@@ -186,9 +186,10 @@ extern "C" int bsx_group_step_pipelined(bsx_group_t* streams_of, bsx_group_t* ad
   return bsx_sweep_launch_pipelined(streams_of, advances_of, (hipStream_t)hip_stream);
 }
 
-extern "C" int bsx_group_trace(bsx_group_t* g, uint64_t* buf) {
+extern "C" int bsx_group_trace(bsx_group_t* g, uint64_t* buf, int64_t capacity) {
   if (g == nullptr) return BSX_ENULL;
   if (g->family != BSX_FAM_SWEEP_MIXED) return BSX_EMODE;
+  if (buf != nullptr && (!g->committed || capacity < 3 * g->total_blocks)) return BSX_EINVAL;
   g->trace = buf;
   return 0;
 }

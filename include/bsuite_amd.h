@@ -392,11 +392,12 @@ int bsx_group_step_phase(bsx_group_t* g, int32_t phase, void* hip_stream);
  * After launch s the TimeStep of step s is complete in the buffers of group (s even ? E : O); the lanes
  * are one advance ahead of it. */
 int bsx_group_step_pipelined(bsx_group_t* streams_of, bsx_group_t* advances_of, void* hip_stream);
-/* Diagnostics (ABI v9): with a device buffer of 3 * (phase-0 workgroups) uint64, every phase-0 workgroup of a
- * BSX_FAM_SWEEP_MIXED group records buf[3b] = start, buf[3b+1] = end (wall_clock64(): 100 MHz), buf[3b+2] =
- * its segment's family id on every bsx_group_step / step_phase(0) that follows; NULL switches it off.  Where
- * the latency-bound phase 0 of a sweep step spends its time (tools/sweep_phase0_trace.py). */
-int bsx_group_trace(bsx_group_t* g, uint64_t* buf);
+/* Diagnostics (ABI v9): with a device buffer of `capacity` >= 3 * (phase-0 workgroups) uint64 (BSX_EINVAL if
+ * smaller; the group must be committed), every phase-0 workgroup of a BSX_FAM_SWEEP_MIXED group records
+ * buf[3b] = start, buf[3b+1] = end (wall_clock64(): 100 MHz), buf[3b+2] = its segment's family id on every
+ * bsx_group_step / step_phase(0) that follows; NULL switches it off.  Where the latency-bound phase 0 of a
+ * sweep step spends its time (tools/sweep_phase0_trace.py). */
+int bsx_group_trace(bsx_group_t* g, uint64_t* buf, int64_t capacity);
 int bsx_group_destroy(bsx_group_t* g);
 
 /* ---- observation adapter ------------------------------------------------------

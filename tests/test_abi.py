@@ -85,10 +85,14 @@ def test_argument_errors_without_touching_the_gpu():
   assert b'NULL' in lib.bsx_strerror(-2)
   # ABI v9: pipelined group step / phase-0 trace refuse what they cannot run (host-side checks only)
   assert lib.bsx_group_step_pipelined(None, None, None) == -2
-  assert lib.bsx_group_trace(None, None) == -2
+  assert lib.bsx_group_trace(None, None, 0) == -2
   g = ctypes.c_void_p()
   assert lib.bsx_group_create(_native.FAMILY_IDS['bandit'], 1, ctypes.byref(g)) == 0
-  assert lib.bsx_group_trace(g, None) == -5                          # BSX_EMODE: whole-sweep groups only
+  assert lib.bsx_group_trace(g, None, 0) == -5                       # BSX_EMODE: whole-sweep groups only
+  sw = ctypes.c_void_p()
+  assert lib.bsx_group_create(_native.FAMILY_IDS['sweep_mixed'], 1, ctypes.byref(sw)) == 0
+  assert lib.bsx_group_trace(sw, 16, 1 << 20) == -1                  # not committed yet: its size is unknown
+  lib.bsx_group_destroy(sw)
   assert lib.bsx_group_step_pipelined(g, g, None) == -1              # not committed, not a whole-sweep group
   assert lib.bsx_group_small_class(3) == lib.bsx_group_small_class(200) == 256
   lib.bsx_group_destroy(g)

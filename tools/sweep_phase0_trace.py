@@ -37,7 +37,7 @@ def main():
   torch.cuda.synchronize()
   n_blocks = sum((lanes + 255) // 256 for _, _, lanes in batch.segments)
   buf = torch.zeros(3 * n_blocks, dtype=torch.int64, device='cuda')
-  _native.check(_native.lib.bsx_group_trace(batch._groups[0], buf.data_ptr()), 'bsx_group_trace')
+  _native.check(_native.lib.bsx_group_trace(batch._groups[0], buf.data_ptr(), buf.numel()), 'bsx_group_trace')
   names = {v: k for k, v in _native.FAMILY_IDS.items()}
   summary = []
   for rep in range(3):
@@ -66,7 +66,7 @@ def main():
     summary.append(rec)
     print(json.dumps({k: v for k, v in rec.items() if k != 'starts_per_us'}))
     print('starts per us:', rec['starts_per_us'])
-  _native.check(_native.lib.bsx_group_trace(batch._groups[0], None), 'bsx_group_trace')
+  _native.check(_native.lib.bsx_group_trace(batch._groups[0], None, 0), 'bsx_group_trace')
   os.makedirs(os.path.dirname(args.out), exist_ok=True)
   json.dump(summary, open(args.out, 'w'), indent=1)
   batch.release_groups()
