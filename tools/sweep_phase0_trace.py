@@ -24,6 +24,8 @@ def main():
   ap = argparse.ArgumentParser()
   ap.add_argument('--lanes', type=int, default=1 << 20)
   ap.add_argument('--out', default=os.path.join(ROOT, 'gpurun_out', 'sweep_phase0_trace.json'))
+  ap.add_argument('--phase0-only', action='store_true',
+                  help='step only the lane-advance launch, back to back: no store stream in between to sweep the caches')
   args = ap.parse_args()
   d = np.load(os.path.join(ROOT, 'tests', 'golden', 'mnist_synthetic_dataset.npz'))
   tmp = tempfile.mkdtemp(prefix='bsx_mnist_')
@@ -32,8 +34,15 @@ def main():
   batch = sb.SweepBatch(None, args.lanes, seed=42, env_kwargs=dict(mnist=mn, mnist_noise=mn, mnist_scale=mn))
   acts = batch.random_actions(seed=1)
   batch.prepare_groups(acts)
+  stream = torch.cuda.current_stream().cuda_stream
+
+  def one_step():
+    if args.phase0_only:
+      _native.check(_native.lib.bsx_group_step_phase(batch._groups[0], 0, stream), 'bsx_group_step_phase')
+    else:
+      batch.step_grouped()
   for _ in range(30):
-    batch.step_grouped()
+    one_step()
   torch.cuda.synchronize()
   n_blocks = sum((lanes + 255) // 256 for _, _, lanes in batch.segments)
   buf = torch.zeros(3 * n_blocks, dtype=torch.int64, device='cuda')
@@ -41,7 +50,7 @@ def main():
   names = {v: k for k, v in _native.FAMILY_IDS.items()}
   summary = []
   for rep in range(3):
-    batch.step_grouped()
+    one_step()
     torch.cuda.synchronize()
     t = buf.cpu().numpy().reshape(-1, 3)
     t0 = t[:, 0].min()
