@@ -1,25 +1,29 @@
 """bench.py — env-steps/sec of the batched bsuite step() path on MI355X.
 
-  python bench.py [--gpus N] [--steps K] [--warmup W] [--workload deep_sea|catch|...|sweep] [--lanes B]
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--workload deep_sea|catch|...|sweep] [--lanes B] [--weak]
 
 One "step" = one env.step(actions) call on every lane of the batch (auto-reset calls included,
 they are real API calls: bsuite/environments/base.py:61-62).  Default workload is BASELINE.json
-configs[1]: deep_sea size=30 (bsuite_id deep_sea/10), 2^20 lanes per GPU, uniform random actions
+configs[1]: deep_sea size=30 (bsuite_id deep_sea/10), 2^20 lanes, uniform random actions
 pre-generated on the device (the batched analogue of bsuite/baselines/random/agent.py:35-37).
 Every TimeStep field is materialised in HBM on every step (dense contract).  Before the warm-up the
 lanes are put at staggered episode phases, so that every timed call carries the steady-state mix of
 FIRST / MID / LAST lanes whatever K is.
 
-The default line also carries the other BASELINE configs as sub-records under "also": catch/0
-(configs[2]), cartpole/0 and mountain_car/0 (configs[3]; eager step(), a HIP graph of 16 step()
-launches, and the fused rollout(T=16)), and the 468-id sweep (configs[4]).
+The default line also carries the other BASELINE configs as sub-records under "also" — catch/0
+(configs[2]) first, then cartpole/0 and mountain_car/0 (configs[3]; eager step(), a HIP graph of 16
+step() launches, the fused rollout(T=16)) and the 468-id sweep (configs[4]) — in a compact form: 5
+significant digits, short codes instead of prose (legend: DESIGN.md §6), so that the whole line stays
+well under 8000 characters.
 
 Multi-GPU: one process per GPU (torch.distributed, backend nccl = RCCL); lanes shard with no
 data-path collective; the only collective is the end-of-rollout all-gather of per-rank summaries.
 Either launch the ranks yourself (`python -m torch.distributed.run --nproc-per-node N bench.py
 --gpus N`), or run `python bench.py --gpus N` and this script spawns them itself (the reference's
-own parallel entry is self-launching too: bsuite/baselines/utils/pool.py:28-54).  With N > 1 the
-main record is weak scaling (2^20 lanes per GPU); "strong" sub-records split 2^20 lanes over the ranks.
+own parallel entry is self-launching too: bsuite/baselines/utils/pool.py:28-54).  `--lanes` is the
+GLOBAL batch (BASELINE.json: "batch=2^20 ... at 1, 2, 4 and 8 GPUs"): with N > 1 the main
+record is STRONG scaling — 2^20 / N lanes per GPU — and the weak-scaling figure (2^20 lanes per GPU) is
+information under "also" (`--weak` makes it the main record).
 Prints ONE JSON line on rank 0.
 """
 import argparse
@@ -63,19 +67,74 @@ def algorithmic_bytes_per_step(obs_numel, state_bytes):
   return 4 + 4 + 4 + 1 + 4 * obs_numel + state_bytes
 
 
-def pmc_traffic(workload, lanes):
-  """HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/rNN/<w>_pmc_traffic.json:
-  WRITE_SIZE and FETCH_SIZE collected in separate runs, gfx950 corrections applied there)."""
+def _latest_profile(name):
   import glob
-  hits = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*', f'{workload}_pmc_traffic.json')))
-  if not hits or lanes != (1 << 20):
+  hits = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*', name)))
+  if not hits:
     return None, None
   with open(hits[-1]) as f:
-    d = json.load(f)
-  return d['per_launch']['hbm_bytes'], os.path.relpath(hits[-1], ROOT)
+    return json.load(f), os.path.relpath(hits[-1], ROOT)
+
+
+def pmc_traffic(workload, lanes):
+  """HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/rNN/<w>_pmc_traffic.json:
+  WRITE_SIZE and FETCH_SIZE collected in separate runs over the timed launches, gfx950 corrections applied
+  there: tools/pmc.py)."""
+  d, src = _latest_profile(f'{workload}_pmc_traffic.json')
+  if d is None or lanes != d.get('lanes', 1 << 20) or not d['per_launch'].get('fetch_bytes_x2'):
+    return None, None                      # (a pass that recorded no FETCH bytes is not evidence)
+  return d['per_launch']['hbm_bytes'], src
+
+
+# VALU issue peak of the chip: 256 CUs x 4 SIMDs, one wave64 instruction per 2 cycles at 2.4 GHz
+# (/opt/skills/guides/MI355X_MICROARCH.md: "issues each VALU instruction over 2 cycles"), in 10^9 wave-instr/s
+VALU_PEAK_GINSTR = 256 * 4 * 2.4 / 2
+
+
+def pmc_valu(workload, mode, lanes):
+  """VALU wave-instructions per launch (and the measured VALU-busy share of the SIMD cycles) of a fused rollout
+  kernel, from the committed SQ counter pass (profiles/rNN/<w>_<mode>_pmc_sq.json, tools/pmc.py)."""
+  d, src = _latest_profile(f'{workload}_{mode}_pmc_sq.json')
+  if d is None or lanes != d.get('lanes', 1 << 20):
+    return None
+  return dict(insts=d['per_launch']['SQ_INSTS_VALU'], busy=d['per_launch'].get('valu_busy_frac'), src=src)
+
+
+def sig(x, n=5):
+  """The JSON line in n significant digits (the driver keeps an 8000-character tail of it)."""
+  if isinstance(x, float):
+    return float(f'{x:.{n}g}') if x == x and abs(x) != float('inf') else None
+  if isinstance(x, dict):
+    return {k: sig(v, n) for k, v in x.items()}
+  if isinstance(x, (list, tuple)):
+    return [sig(v, n) for v in x]
+  return x
 
 
 # ------------------------------------------------------------------------------------ CPU baselines
+def _reference_loop(bsuite_id, seconds, seed=0):
+  """The UNMODIFIED reference stepped on this box: `bsuite.load_from_id(id)` driven by the loop of
+  bsuite/baselines/experiment.py:43-57 with the random agent of bsuite/baselines/random/agent.py:35-37 inlined.
+  env-steps count every environment call, reset() included (base.py:54-65).  The package is imported from
+  /root/reference where that exists, else from the byte-code `__graft_entry__.build()` staged under oracle/_ref
+  (oracle/stage_reference.py) — it is the checker's copy, never the product's."""
+  import numpy as np
+  from oracle import replay
+  bs = replay.import_reference()
+  env = bs.load_from_id(bsuite_id)
+  num_actions = env.action_spec().num_values
+  rng = np.random.RandomState(seed)
+  calls = 0
+  t0 = time.perf_counter()
+  while time.perf_counter() - t0 < seconds:
+    timestep = env.reset()
+    calls += 1
+    while not timestep.last():
+      timestep = env.step(rng.randint(num_actions))
+      calls += 1
+  return calls, time.perf_counter() - t0
+
+
 def _oracle_loop(family, kwargs, num_actions, lanes, lane0, budget_s):
   """Steps one OracleEnv (its own lanes) for budget_s seconds; returns (env-steps, seconds)."""
   import numpy as np
@@ -97,69 +156,60 @@ def _oracle_loop(family, kwargs, num_actions, lanes, lane0, budget_s):
   return lanes * n, time.perf_counter() - t0
 
 
-def cpu_port_baseline(family, kwargs, num_actions, budget_s=12.0, all_cores_budget_s=4.0):
-  """The oracle (C restatement of the reference's numpy step) on ONE host core of THIS box, bounded
-  sample; plus the same loop on every host core at once (one process per core, each with its own
-  OracleEnv) — the analogue of the reference's one-process-per-bsuite_id pool (pool.py:48)."""
+def _host_cores():
+  return len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
+
+
+def _fan_out(code, argv, n_procs):
+  """One PROCESS per core, like the reference's own fan-out (bsuite/baselines/utils/pool.py:35,48; threads would
+  serialise on the interpreter lock); each prints "<env-steps> <seconds>"."""
+  import subprocess
+  t0 = time.perf_counter()
+  procs = [subprocess.Popen([sys.executable, '-c', code] + [str(a) for a in argv] + [str(j)], stdout=subprocess.PIPE,
+                            stderr=subprocess.DEVNULL, text=True) for j in range(n_procs)]
+  res = []
+  for pr in procs:
+    o, _ = pr.communicate()
+    try:
+      x, y = o.split()[-2:]
+      res.append((float(x), float(y)))
+    except ValueError:
+      pass
+  return res, time.perf_counter() - t0
+
+
+def cpu_port_baseline(family, kwargs, num_actions, budget_s=2.5):
+  """The oracle (C restatement of the reference's numpy step) on ONE host core of THIS box, a bounded sample:
+  context for the reference number below, neither the target nor the reference."""
   lanes = 4096
   steps, dt = _oracle_loop(family, kwargs, num_actions, lanes, 0, budget_s)
-  out = dict(value=steps / dt, unit='env-steps/s', cores=1, kind='port',
-             sample=f'{lanes} lanes x {steps // lanes} step() calls of {family} {kwargs} through '
-                    f'oracle/oracle.c (gcc -O2, single thread, {dt:.1f} s) on this box')
-  cores = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
-  if cores > 1 and all_cores_budget_s > 0:
-    # one PROCESS per core (threads would serialise on the interpreter lock between the short C calls)
-    import subprocess
-    code = ('import sys, json; sys.path.insert(0, %r); import bench; '
-            'f, kw, na, lanes, lane0, b = sys.argv[1], json.loads(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4]), '
-            'int(sys.argv[5]), float(sys.argv[6]); print(*bench._oracle_loop(f, kw, na, lanes, lane0, b))' % ROOT)
-    t0 = time.perf_counter()
-    procs = [subprocess.Popen([sys.executable, '-c', code, family, json.dumps(kwargs), str(num_actions), str(lanes),
-                               str((j + 1) * lanes), str(all_cores_budget_s)],
-                              stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True) for j in range(cores)]
-    res = []
-    for pr in procs:
-      o, _ = pr.communicate()
-      try:
-        a, b = o.split()
-        res.append((float(a), float(b)))
-      except ValueError:
-        pass
-    wall = time.perf_counter() - t0
+  return dict(value=steps / dt, cores=1, kind='port', sample=f'oracle.c, {lanes} lanes x {steps // lanes} calls, {dt:.1f} s')
+
+
+def cpu_baseline(bsuite_id, family, kwargs, num_actions, single_s=8.0, all_s=5.0):
+  """`cpu_baseline` of the JSON line: the reference's own numpy path timed LIVE on this box's host cores in this
+  very run (`kind: "reference"`; BASELINE.json north_star) — one core, then one process per core — with the C
+  port beside it.  Falls back to the port alone (and says so) where no reference can be imported."""
+  from oracle import replay
+  port = cpu_port_baseline(family, kwargs, num_actions)
+  origin = replay.reference_origin()
+  if origin is None:
+    port.update(unit='env-steps/s', note='no reference on this box (oracle/_ref not staged): C port only')
+    return port
+  calls, dt = _reference_loop(bsuite_id, single_s)
+  cores = _host_cores()
+  out = dict(value=calls / dt, unit='env-steps/s', cores=1, kind='reference',
+             sample=f"unmodified bsuite.load_from_id('{bsuite_id}') + random agent, {calls} reset()/step() calls in "
+                    f"{dt:.1f} s on one core of this box ({origin}: {'/root/reference' if origin == 'source' else 'oracle/_ref byte-code'})")
+  if cores > 1 and all_s > 0:
+    code = ('import sys; sys.path.insert(0, %r); import bench; '
+            'print(*bench._reference_loop(sys.argv[1], float(sys.argv[2]), 1 + int(sys.argv[3])))' % ROOT)
+    res, wall = _fan_out(code, [bsuite_id, all_s], cores)
     if res:
       out['all_cores'] = dict(value=sum(r[0] for r in res) / max(r[1] for r in res), cores=len(res),
-                              sample=f'{len(res)} processes x {lanes} lanes x {all_cores_budget_s:.0f} s each, '
-                                     f'{wall:.1f} s wall incl. start-up')
+                              sample=f'{len(res)} processes x {all_s:.0f} s (pool.py:35,48 shape), {wall:.1f} s wall incl. start-up')
+  out['port'] = port
   return out
-
-
-def cpu_baseline(bsuite_id, family, kwargs, num_actions):
-  """`cpu_baseline` of the JSON line.  The reference's own numpy path (`kind: "reference"`) is the
-  unmodified bsuite package timed by tools/cpu_reference_numpy.py in the build container — it cannot
-  travel to the GPU box (no /root/reference there), so its numbers are read from the committed
-  profiles/rNN/cpu_reference_numpy.json with the measuring host stated; the C port of the same step
-  is timed live on this box's cores and reported under "port"."""
-  import glob
-  port = cpu_port_baseline(family, kwargs, num_actions)
-  hits = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*', 'cpu_reference_numpy.json')))
-  if not hits:
-    return port
-  with open(hits[-1]) as f:
-    d = json.load(f)
-  rec = d['results'].get(bsuite_id)
-  if rec is None:
-    return port
-  one, allc = rec['single_core'], rec['all_cores']
-  return dict(
-      value=one['value'], unit='env-steps/s', cores=1, kind='reference',
-      sample=f"unmodified reference bsuite.load_from_id('{bsuite_id}') + inlined random agent, {one['calls']} "
-             f"reset()/step() calls in {one['seconds']:.1f} s on one core",
-      provenance=dict(file=os.path.relpath(hits[-1], ROOT), script=d['script'], host=d['host'],
-                      note='measured in the build container: the reference tree cannot travel to the GPU box; '
-                           'the live same-box CPU number is "port"'),
-      all_cores=dict(value=allc['value'], cores=allc['cores'],
-                     sample=f"{allc['cores']} processes (one reference env each, pool.py:35,48 style), {allc['seconds']:.1f} s"),
-      port=port)
 
 
 # ------------------------------------------------------------------------------------ helpers
@@ -420,110 +470,90 @@ class Rank:
       torch.cuda.empty_cache()
     return self._ceiling
 
-  def roofline(self, r):
-    ceiling = self.store_ceiling()
-    return {'bound': 'hbm', 'achieved': r['achieved'], 'peak': HBM_PEAK_GBPS, 'unit': 'GB/s',
-            'frac': r['achieved'] / HBM_PEAK_GBPS, 'traffic': r['traffic'],
-            'traffic_source': r['traffic_src'],
-            'algorithmic_bytes_per_launch': r['bytes_per_step'] * r['lanes'],
-            'kernel_ms': r['kernel_ms'], 'box_store_ceiling_GBps': ceiling,
-            'frac_of_box_store_ceiling': r['achieved'] / ceiling}
+  def roofline(self, r, full=False):
+    """HBM roofline of a record: algorithmic bytes per launch / launch time by HIP events.  Fused
+    rollouts of the physics families also carry the VALU-issue roofline (`valu`): their state stays in registers
+    for T steps, bytes are not what bounds them."""
+    out = {'bound': 'hbm', 'achieved': r['achieved'], 'peak': HBM_PEAK_GBPS, 'unit': 'GB/s',
+           'frac': r['achieved'] / HBM_PEAK_GBPS, 'traffic': r['traffic']}
+    if full:
+      ceiling = self.store_ceiling()
+      out.update(traffic_src=r['traffic_src'], alg_bytes=r['bytes_per_step'] * r['lanes'], kernel_ms=r['kernel_ms'],
+                 box_fill_GBps=ceiling, frac_of_box_fill=r['achieved'] / ceiling)
+    if r['mode'] == 'rollout' and r['family'] in ('cartpole', 'mountain_car'):
+      v = pmc_valu(r['workload'], f"rollout{r['chunk']}", r['lanes'])
+      if v is not None:
+        ginstr = v['insts'] / (r['kernel_ms'] * r['chunk'] * 1e-3) / 1e9      # the launch runs `chunk` steps
+        out = {'bound': 'valu', 'achieved': ginstr, 'peak': VALU_PEAK_GINSTR, 'unit': 'Gwave-instr/s',
+               'frac': ginstr / VALU_PEAK_GINSTR, 'valu_busy': v['busy'], 'src': v['src'],
+               'hbm': {'achieved': out['achieved'], 'frac': out['frac']}}
+    return out
 
   def sub_record(self, r):
-    launch = ('eager step()' if r['mode'] == 'eager' else
-              f"hipGraph of {r['chunk']} step() launches" if r['mode'] == 'graph' else
-              f"rollout(T={r['chunk']}) per call")
-    if r['mode'] == 'rollout' and r['family'] in ('deep_sea', 'catch'):
-      launch += (' — software-pipelined: T+1 launches, each observation store stream beside the next step\'s '
-                 'lane advance (bsx_call_t.state_alt)')
-    return {'value': r['value'], 'unit': 'env-steps/s', 'steps': r['steps'], 'ms_per_step': r['wall'] / r['steps'] * 1e3,
-            'workload': f"{r['bsuite_id']} ({r['family']}) random-action rollout, dense TimeStep, "
-                        f"{r['lanes']} lanes per GPU x {self.world} GPU(s)",
-            'launch': launch, 'bytes_per_env_step': r['bytes_per_step'], 'timed_mix': r['timed_mix'],
-            'episodes_finished': r['episodes_finished'], 'bsuite_info_sums': r['info_sums'],
-            'roofline': self.roofline(r)}
+    """Compact sub-record.  `mode`: e = eager step() per call; gT = hipGraph of T step() launches; rT = rollout(T)
+    per call — deep_sea / catch: software-pipelined, T+1 launches (bsx_call_t.state_alt); the other families: one
+    fused T-step kernel."""
+    mode = 'e' if r['mode'] == 'eager' else f"g{r['chunk']}" if r['mode'] == 'graph' else f"r{r['chunk']}"
+    return {'value': r['value'], 'ms_per_step': r['wall'] / r['steps'] * 1e3, 'steps': r['steps'], 'mode': mode,
+            'lanes_per_gpu': r['lanes'], 'bytes_per_env_step': r['bytes_per_step'], 'roofline': self.roofline(r),
+            'episodes_finished': r['episodes_finished']}
 
   # -------------------------------------------------------------------------------------------
-  def measure_sweep(self, lanes, steps, warmup):
-    """BASELINE config 5: all 468 bsuite_ids as lane segments (`lanes` in total, split evenly per id,
-    whole segments bin-packed over the ranks), grouped launches, one captured HIP graph per sweep step."""
+  def measure_sweep(self, lanes, steps, warmup, ring=16):
+    """BASELINE config 5: all 468 bsuite_ids as lane segments (`lanes` in total, split evenly per id, whole
+    segments bin-packed over the ranks), the whole sweep as ONE launch group.  Random actions over time: every
+    segment reads row (sweep step mod `ring`) of a pre-generated [ring, lanes] action ring on the device
+    (bsx_call_t.action_ring; SURVEY §8d actions [T,B]).  Two schedules are timed on the same batch:
+      closed-loop (the record's `value`): two launches per sweep step — phase 0 advances every lane and bumps the
+        call counter, phase 1 is the observation store stream; the TimeSteps of step s are complete before the
+        actions of step s+1 are needed;
+      open-loop (`pipelined`): one launch per step — the store stream of step s beside the lane advance of step
+        s+1 — valid because the actions do not depend on the observations; not reachable by a closed-loop agent."""
     import tempfile
     import numpy as np
     torch = self.torch
     from bsuite_amd import sweep_batch as sb
     from bsuite_amd.utils import datasets
+    from bsuite_amd import distributed as bdist
     d = np.load(os.path.join(ROOT, 'tests', 'golden', 'mnist_synthetic_dataset.npz'))
     tmp = tempfile.mkdtemp(prefix='bsx_mnist_')
     datasets.write_idx_files(tmp, d['images_u8'], d['labels'])      # synthetic stand-in (no network)
     mn = dict(data_dir=tmp)
     batch = sb.SweepBatch(None, lanes, device=self.dev, seed=42, rank=self.rank, world_size=self.world,
-                          num_streams=int(os.environ.get('BSX_SWEEP_STREAMS', '32')),
                           env_kwargs=dict(mnist=mn, mnist_noise=mn, mnist_scale=mn))
-    acts = batch.random_actions(seed=1)          # keyed by segment: independent of the rank assignment
-    mode = os.environ.get('BSX_SWEEP_MODE', 'grouped')
-    grouped = mode in ('grouped', 'grouped_graph', 'grouped_streams')
-    # the sweep's actions are static tensors: step s+1 does not need the observations of step s, so one launch
-    # per step carries the store stream of step s beside the lane advance of step s+1 (DESIGN.md §7b)
-    pipelined = (mode == 'grouped' and os.environ.get('BSX_SWEEP_MIX_ALL', '1') != '0'
-                 and os.environ.get('BSX_SWEEP_PIPELINED', '1') != '0')
-    if grouped:
-      batch.prepare_groups(acts, mix_small=os.environ.get('BSX_SWEEP_MIX_SMALL', '1') != '0',
-                           mix_pairs=os.environ.get('BSX_SWEEP_MIX_PAIRS', '1') != '0',
-                           mix_all=os.environ.get('BSX_SWEEP_MIX_ALL', '1') != '0',
-                           pipelined=pipelined)
-      if mode == 'grouped_graph':              # group launches as concurrent branches of one HIP graph
-        batch.capture_grouped(int(os.environ.get('BSX_SWEEP_STREAMS', '2')),
-                              phased=os.environ.get('BSX_SWEEP_PHASED', '1') != '0')
-        replay = batch.replay_grouped
-      elif mode == 'grouped_streams':          # eager, two HIP streams: pipe (advance -> store stream) + small
-        replay = batch.step_grouped_streams
-      else:
-        replay = batch.step_grouped
-    else:
-      batch.capture(acts)
-      replay = batch.replay
-
-    def run(n):
-      for _ in range(n):
-        replay()
-      batch.join_streams()                     # the timing events sit on the current stream
-
-    wall, step_ms = self.timed(run, steps, warmup)
+    acts = batch.random_actions(seed=1, ring=ring)   # keyed by segment: independent of the rank assignment
     local_bytes = float(sum(l * sb.bytes_per_step(int(np.prod(e.observation_spec().shape)))
                             for e, (_, _, l) in zip(batch.envs, batch.segments)))
+    timed = {}
+    for name, pipelined in (('closed', False), ('pipelined', True)):
+      batch.prepare_groups(acts, pipelined=pipelined)
+
+      def run(n):
+        for _ in range(n):
+          batch.step_grouped()
+
+      timed[name] = self.timed(run, steps, warmup)
+      batch.release_groups()
     # the only collective: all-gather of the per-rank summaries (here: bytes + lanes + episode counters)
-    from bsuite_amd import distributed as bdist
     summ = batch.summary()
     vec = torch.tensor([local_bytes, float(batch.lanes()), float(len(batch.envs)),
                         sum(v['episodes_finished'] for v in summ.values())], dtype=torch.float64, device=self.dev)
     g = bdist.all_gather_summary(vec)
-    total_bytes, total_lanes = float(g[:, 0].sum()), float(g[:, 1].sum())
-    max_rank_bytes = float(g[:, 0].max())
-    achieved = max_rank_bytes / (step_ms * 1e-3) / 1e9          # the busiest rank's stream
-    rec = {
-        'value': total_lanes * steps / wall, 'unit': 'env-steps/s', 'steps': steps, 'ms_per_step': wall / steps * 1e3,
-        'workload': 'sweep.SWEEP: 468 bsuite_ids as lane segments (MNIST ids on a synthetic stand-in dataset), '
-                    'random-action rollout, dense TimeStep',
-        'global_lanes': int(total_lanes), 'segments_per_rank': [int(x) for x in g[:, 2].tolist()],
-        'sharding': f'whole segments bin-packed over {self.world} rank(s) by lanes x bytes/step',
-        'scaling': 'strong',
-        'episodes_finished': float(g[:, 3].sum()),
-        'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBPS, 'unit': 'GB/s',
-                     'frac': achieved / HBM_PEAK_GBPS, 'traffic': None, 'kernel_ms': step_ms,
-                     'algorithmic_bytes_per_launch': max_rank_bytes,
-                     'algorithmic_bytes_all_ranks': total_bytes},
-        'launch': ((f'1 launch per sweep step ({len(batch.envs)} segments on rank 0 in two alternating whole-sweep groups: '
-                    'the observation store stream of step s beside the lane advance of step s+1; the actions are static)'
-                    if pipelined else
-                    f'2 launches per sweep step ({len(batch.envs)} segments on rank 0 in one whole-sweep group: phase 0 '
-                    'advances every lane and bumps the call counter, phase 1 is the observation store stream)'
-                    if len(batch._groups) == 1 else
-                    f'{len(batch._groups)} grouped launches per sweep step ({len(batch.envs)} segments on rank 0)')
-                   + (' as concurrent branches of one HIP graph' if mode == 'grouped_graph' else
-                      ' on two HIP streams (advance -> store stream | small groups + counter bump)' if mode == 'grouped_streams'
-                      else '') if grouped else
-                   f'one hipGraph per sweep step ({len(batch.envs)} segments over {batch.num_streams} streams)')}
-    batch.release_groups()
+    total_lanes, max_rank_bytes = float(g[:, 1].sum()), float(g[:, 0].max())
+
+    def roof(step_ms, traffic=None):
+      achieved = max_rank_bytes / (step_ms * 1e-3) / 1e9          # the busiest rank's stream
+      return {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBPS, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBPS,
+              'traffic': traffic}
+
+    tr = {k: (pmc_traffic(k, int(total_lanes))[0] if self.world == 1 else None) for k in ('sweep_closed', 'sweep_pipelined')}
+    (wall, step_ms), (wall_p, step_ms_p) = timed['closed'], timed['pipelined']
+    rec = {'value': total_lanes * steps / wall, 'ms_per_step': wall / steps * 1e3, 'steps': steps, 'mode': 'closed-loop, 2 launches/step',
+           'global_lanes': int(total_lanes), 'segments_per_rank': [int(x) for x in g[:, 2].tolist()], 'action_ring': ring,
+           'alg_bytes_busiest_rank': max_rank_bytes, 'roofline': roof(step_ms, tr['sweep_closed']),
+           'pipelined': {'value': total_lanes * steps / wall_p, 'ms_per_step': wall_p / steps * 1e3, 'open_loop': True,
+                         'mode': '1 launch/step', 'roofline': roof(step_ms_p, tr['sweep_pipelined'])},
+           'episodes_finished': float(g[:, 3].sum())}
     del batch, acts
     torch.cuda.empty_cache()
     return rec
@@ -538,16 +568,10 @@ class Rank:
     except Exception as e:  # pylint: disable=broad-except
       if self.world > 1:
         raise                      # ranks must stay in step: a lone rank skipping a collective would hang
-      return {'error': f'{type(e).__name__}: {e}'}
+      return {'error': f'{type(e).__name__}: {e}'[:300]}
 
   def run(self):
     args, world = self.args, self.world
-    lanes = args.lanes
-    if args.strong and args.workload != 'sweep':
-      if lanes % world:
-        raise SystemExit('--strong needs --lanes divisible by the number of ranks')
-      lanes //= world
-
     if args.workload == 'sweep':
       rec = self.measure_sweep(args.lanes, args.steps, args.warmup)
       if self.rank == 0:
@@ -555,11 +579,21 @@ class Rank:
                 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': rec['ms_per_step'],
                 'higher_is_better': True, 'scaling': 'strong', 'vs_baseline': None, 'dtype': 'int32+f32',
                 'data': 'synthetic (MNIST ids on a synthetic stand-in dataset)',
-                'config': {'workload': rec['workload'], 'global_lanes': rec['global_lanes'],
-                           'segments_per_rank': rec['segments_per_rank'], 'sharding': rec['sharding']},
-                'roofline': rec['roofline'], 'launch': rec['launch'], 'episodes_finished': rec['episodes_finished']}
-        print(json.dumps(line), flush=True)
+                'config': {'workload': 'sweep.SWEEP: 468 bsuite_ids as lane segments, random-action ring, dense TimeStep',
+                           'global_lanes': rec['global_lanes'], 'segments_per_rank': rec['segments_per_rank'],
+                           'sharding': f'whole segments bin-packed over {world} rank(s) by lanes x bytes/step'},
+                'roofline': rec['roofline'], 'launch': rec['mode'], 'pipelined': rec['pipelined'],
+                'episodes_finished': rec['episodes_finished']}
+        print(json.dumps(sig(line)), flush=True)
       return
+
+    # --lanes is the GLOBAL batch (BASELINE.json: batch = 2^20 at 1, 2, 4 and 8 GPUs): strong scaling unless --weak
+    strong = not args.weak
+    lanes = args.lanes
+    if strong:
+      if lanes % world:
+        raise SystemExit('--lanes must be divisible by the number of ranks (strong scaling: the global batch is split evenly)')
+      lanes //= world
 
     mode, chunk = ('graph', args.graph) if args.graph else ('rollout', args.rollout) if args.rollout else ('eager', 0)
     m = self.measure(args.workload, lanes, args.steps, args.warmup, mode, chunk, args.observation_mode, args.logging)
@@ -580,22 +614,17 @@ class Rank:
       if world == 1:
         # rollout(actions[T,B]) of the two-kernel families: the open-loop form of the same metric, pipelined
         K32 = (K + 31) // 32 * 32
-        if 'error' not in also['catch/0']:
-          also['catch/0']['rollout32'] = sub('catch', lanes, 'rollout', 32, K32, 32)
-        also['deep_sea/10 rollout16'] = sub('deep_sea', lanes, 'rollout', 16, 48, 16)
-      if world == 1:
+        also['catch/0 r32'] = sub('catch', lanes, 'rollout', 32, K32, 32)
+        also['deep_sea/10 r16'] = sub('deep_sea', lanes, 'rollout', 16, 48, 16)
         for w_ in ('cartpole', 'mountain_car'):                  # BASELINE configs[3]
           bid = WORKLOADS[w_][0]
           also[bid] = sub(w_, lanes)
-          if 'error' not in also[bid]:
-            also[bid]['graph16'] = sub(w_, lanes, 'graph', 16, K16, W16)
-            also[bid]['rollout16'] = sub(w_, lanes, 'rollout', 16, K16, W16)
-      else:
-        if args.lanes % world == 0 and not args.strong:          # strong scaling: 2^20 lanes over all ranks
-          also['strong'] = {
-              'scaling': 'strong', 'global_lanes': args.lanes,
-              'deep_sea/10': sub('deep_sea', args.lanes // world, k=args.steps, w=args.warmup),
-              'catch/0': sub('catch', args.lanes // world)}
+          also[bid + ' g16'] = sub(w_, lanes, 'graph', 16, K16, W16)
+          also[bid + ' r16'] = sub(w_, lanes, 'rollout', 16, K16, W16)
+      elif strong:
+        # weak scaling as information: the full batch on every GPU
+        also['weak'] = dict(self.guarded('weak', lambda: self.sub_record(
+            self.measure('deep_sea', args.lanes, args.steps, args.warmup))), scaling='weak', global_lanes=args.lanes * world)
       # BASELINE configs[4]: the heterogeneous sweep, sharded over the ranks by whole segments
       also['sweep'] = self.guarded('sweep', lambda: self.measure_sweep(args.lanes, max(100, K // 2), max(10, W // 2)))
 
@@ -605,27 +634,29 @@ class Rank:
           'metric': 'env-steps/sec', 'value': m['value'], 'unit': 'env-steps/s',
           'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
           'ms_per_step': m['wall'] / args.steps * 1e3, 'higher_is_better': True,
-          'scaling': 'strong' if args.strong else 'weak',
+          'scaling': 'strong' if strong else 'weak',
           'vs_baseline': None, 'dtype': 'f32' if m['family'] in ('cartpole', 'mountain_car') else 'int32',
           'data': 'synthetic',
-          'config': {'workload': f"{m['bsuite_id']} ({m['family']} {m['okw']}) random-action rollout, "
+          'config': {'workload': f"{m['bsuite_id']} {m['family']} {m['okw']} random actions, "
                                  + ('dense TimeStep' if args.observation_mode == 'dense' else
-                                    'DELTA observation mode (persistent buffers patched in place; not the dense contract)'),
-                     'observation_mode': args.observation_mode, 'logging_wrapper': bool(args.logging),
-                     'lanes_per_gpu': B, 'global_lanes': B * world, 'sharding': f'lanes x{world}',
-                     'bytes_per_env_step': m['bytes_per_step'],
-                     'episode_phases': 'lock-step' if args.no_stagger else 'staggered (steady-state FIRST/MID/LAST mix)'},
-          'roofline': self.roofline(m),
-          'launch': (f'hipGraph x{args.graph}' if args.graph else
-                     f'rollout x{args.rollout} per call' if args.rollout else 'eager'),
-          'episodes_finished': m['episodes_finished'], 'bsuite_info_sums': m['info_sums'],
-          'timed_mix': m['timed_mix'],
+                                    'DELTA observation mode (persistent buffers patched in place; not the dense contract)')
+                                 + (', Logging wrapper' if args.logging else ''),
+                     'mode': (f'g{args.graph}' if args.graph else f'r{args.rollout}' if args.rollout else 'e'),
+                     'lanes_per_gpu': B, 'global_lanes': B * world, 'bytes_per_env_step': m['bytes_per_step'],
+                     'episode_phases': 'lock-step' if args.no_stagger else 'staggered'},
+          'roofline': self.roofline(m, full=True),
       }
       if also:
         line['also'] = also
+      line.update(episodes_finished=m['episodes_finished'], bsuite_info_sums=m['info_sums'], timed_mix=m['timed_mix'])
       if world == 1 and not args.no_cpu_baseline:
         line['cpu_baseline'] = cpu_baseline(m['bsuite_id'], m['family'], m['okw'], m['num_actions'])
-      print(json.dumps(line), flush=True)
+      text = json.dumps(sig(line))
+      if len(text) >= 7800:                 # the driver keeps an 8000-character tail: never let the line outgrow it
+        for k in ('bsuite_info_sums', 'timed_mix'):
+          line.pop(k, None)
+        text = json.dumps(sig(line, 4))
+      print(text, flush=True)
 
   def close(self):
     if self.collective:
@@ -638,10 +669,10 @@ def main():
   ap.add_argument('--steps', type=int, default=200)
   ap.add_argument('--warmup', type=int, default=20)
   ap.add_argument('--workload', default='deep_sea', choices=sorted(WORKLOADS) + ['sweep'])
-  ap.add_argument('--lanes', type=int, default=1 << 20, help='lanes per GPU (sweep: global lanes)')
-  ap.add_argument('--strong', action='store_true',
-                  help='strong scaling (SURVEY §8d): --lanes is the GLOBAL lane count, split evenly over the ranks '
-                       '(default: weak scaling, --lanes per GPU)')
+  ap.add_argument('--lanes', type=int, default=1 << 20,
+                  help='GLOBAL lane count (BASELINE.json: batch = 2^20), split evenly over the ranks (strong scaling)')
+  ap.add_argument('--weak', action='store_true', help='weak scaling: --lanes per GPU')
+  ap.add_argument('--strong', action='store_true', help='(the default; kept for older command lines)')
   ap.add_argument('--no-cpu-baseline', action='store_true')
   ap.add_argument('--no-also', action='store_true', help='only the main workload (no catch / cartpole / sweep sub-records)')
   ap.add_argument('--no-stagger', action='store_true', help='start all lanes in lock-step (fresh lanes, first call = reset)')

@@ -1,9 +1,14 @@
 """Build bsuite_amd/_lib/libbsuite_amd.so (hand-written HIP for gfx950 + the C ABI) with hipcc.
 
-    python -m bsuite_amd.build [--force]
+    python -m bsuite_amd.build [--force] [--tuning]
 
 hipcc cross-compiles for gfx950 without a GPU.  The .so is built in-tree so that it travels with
 the repository snapshot to the GPU box (it is git-ignored, not gpurun-ignored).
+
+--tuning additionally builds libbsuite_amd_tuning.so: the same sources compiled with -DBSX_TUNING, the
+only build in which the A/B knobs of DESIGN §9 (BSX_STREAM_K, BSX_PIPELINED_PLACE, ...) are read from
+the environment.  The product library reads no environment variable; the A/B scripts under tools/ and the
+tests of the non-default settings load the tuning build through BSX_NATIVE_LIB.
 """
 import concurrent.futures
 import contextlib
@@ -16,6 +21,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, 'csrc')
 LIB_DIR = os.path.join(HERE, '_lib')
 SO_PATH = os.path.join(LIB_DIR, 'libbsuite_amd.so')
+TUNING_SO_PATH = os.path.join(LIB_DIR, 'libbsuite_amd_tuning.so')
 INCLUDE = os.path.join(os.path.dirname(HERE), 'include')
 
 # -ffp-contract=off: rewards / draws are specified as sequences of IEEE ops without fused
@@ -41,9 +47,9 @@ def _stale(target, deps):
   return any(os.path.getmtime(d) > t for d in deps)
 
 
-def _compile(src, obj):
+def _compile(src, obj, extra=()):
   tmp = f'{obj}.{os.getpid()}.tmp'
-  subprocess.check_call(['hipcc'] + FLAGS + ['-c', src, '-o', tmp])
+  subprocess.check_call(['hipcc'] + FLAGS + list(extra) + ['-c', src, '-o', tmp])
   os.replace(tmp, obj)                      # atomic: a concurrent reader never sees a half-written file
   return obj
 
@@ -79,54 +85,65 @@ def source_hashes():
   return {os.path.basename(s)[:-4] + '.o': _digest([s] + hdrs) for s in sources()}
 
 
-def _recorded():
+def _variant(tuning):
+  """(library path, object directory, hash file, extra flags) of the product / the tuning build."""
+  if tuning:
+    return TUNING_SO_PATH, os.path.join(LIB_DIR, 'tuning'), HASH_PATH + '_tuning', ('-DBSX_TUNING',)
+  return SO_PATH, LIB_DIR, HASH_PATH, ()
+
+
+def _recorded(tuning=False):
   import json  # pylint: disable=import-outside-toplevel
   try:
-    with open(HASH_PATH) as f:
+    with open(_variant(tuning)[2]) as f:
       return json.load(f)
   except (OSError, ValueError):
     return {}
 
 
-def needs_build():
+def needs_build(tuning=False):
   """True when the library does not match the sources.  Decided by CONTENT (hashes recorded next to
   the library at build time), not by mtimes: a snapshot copied to another machine may carry any
   timestamps, and must neither rebuild needlessly nor run stale kernels."""
-  return not os.path.exists(SO_PATH) or _recorded() != source_hashes()
+  return not os.path.exists(_variant(tuning)[0]) or _recorded(tuning) != source_hashes()
 
 
-def build(force=False, verbose=False):
-  if not force and not needs_build():        # the common import: nothing to do, no lock traffic
-    return SO_PATH
+def build(force=False, verbose=False, tuning=False):
+  if not force and not needs_build(tuning):  # the common import: nothing to do, no lock traffic
+    return _variant(tuning)[0]
   with _locked():
-    return _build_locked(force, verbose)
+    return _build_locked(force, verbose, tuning)
 
 
-def _build_locked(force, verbose):
+def _build_locked(force, verbose, tuning):
   import json  # pylint: disable=import-outside-toplevel
-  want, have = source_hashes(), _recorded()
-  if not force and os.path.exists(SO_PATH) and want == have:
-    return SO_PATH                           # another process built it while we waited for the lock
+  so_path, obj_dir, hash_path, extra = _variant(tuning)
+  want, have = source_hashes(), _recorded(tuning)
+  if not force and os.path.exists(so_path) and want == have:
+    return so_path                           # another process built it while we waited for the lock
+  os.makedirs(obj_dir, exist_ok=True)
   objs, jobs = [], []
   for s in sources():
     name = os.path.basename(s)[:-4] + '.o'
-    o = os.path.join(LIB_DIR, name)
+    o = os.path.join(obj_dir, name)
     objs.append(o)
     if force or not os.path.exists(o) or have.get(name) != want[name]:
       jobs.append((s, o))
   if jobs:
     if verbose:
-      print('hipcc:', ' '.join(os.path.basename(s) for s, _ in jobs), flush=True)
+      print('hipcc' + (' -DBSX_TUNING:' if tuning else ':'), ' '.join(os.path.basename(s) for s, _ in jobs), flush=True)
     with concurrent.futures.ThreadPoolExecutor(max_workers=min(8, len(jobs))) as ex:
-      list(ex.map(lambda so: _compile(*so), jobs))
-  tmp = f'{SO_PATH}.{os.getpid()}.tmp'
+      list(ex.map(lambda so: _compile(*so, extra=extra), jobs))
+  tmp = f'{so_path}.{os.getpid()}.tmp'
   subprocess.check_call(['hipcc', '--offload-arch=gfx950', '-shared', '-fPIC', '-o', tmp] + objs)
-  os.replace(tmp, SO_PATH)
-  with open(HASH_PATH + '.tmp', 'w') as f:
+  os.replace(tmp, so_path)
+  with open(hash_path + '.tmp', 'w') as f:
     json.dump(want, f)
-  os.replace(HASH_PATH + '.tmp', HASH_PATH)
-  return SO_PATH
+  os.replace(hash_path + '.tmp', hash_path)
+  return so_path
 
 
 if __name__ == '__main__':
   print(build(force='--force' in sys.argv, verbose=True))
+  if '--tuning' in sys.argv:
+    print(build(force='--force' in sys.argv, verbose=True, tuning=True))

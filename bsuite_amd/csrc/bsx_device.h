@@ -31,6 +31,8 @@ struct bsx_ctl {
   uint64_t wrap_seed;
   int32_t wrap_kind;
   int32_t force_reset;
+  uint32_t action_ring_mask; // R - 1 for an action ring of R = 2^k rows [R, n_lanes] (bsx_call_t.action_ring), else 0
+  uint32_t _pad;
   uint32_t* mt_state;       // MT19937-exact mode: [624, n_lanes] generator states, else nullptr
   int32_t* mt_pos;          // [n_lanes]
   double* mt_gauss;         // [n_lanes] cached second normal of the env generator (nullable)
@@ -51,6 +53,13 @@ __host__ __device__ __forceinline__ bool bsx_ctl_lean(const bsx_ctl& c) {
 
 __device__ __forceinline__ uint64_t bsx_step_of(const bsx_ctl& c) {
   return c.step_index + (c.step_base ? *c.step_base : 0ull);
+}
+
+// The action of output element `oi` (lane i of a step() call; t*B + i inside a fused rollout) on call `step`.
+// With an action ring (bsx_call_t.action_ring = R) the call reads row (step mod R) of `action` [R, B] — the
+// offset is uniform per workgroup (scalar unit) and zero without a ring.
+__device__ __forceinline__ int bsx_action(const bsx_ctl& c, const int32_t* __restrict__ action, int64_t oi, uint64_t step) {
+  return action[oi + (int64_t)(step & (uint64_t)c.action_ring_mask) * c.n_lanes];
 }
 
 // Opens lane i's environment draw stream for this call: the counter-based stream, or — in
@@ -269,7 +278,8 @@ __device__ __forceinline__ bsx_group_slot bsx_group_find(const bsx_group_index& 
 // launcher picks it when the call has none of them).
 template <class Fam, bool LEAN = false>
 __device__ __forceinline__ void bsx_advance_body(const typename Fam::args& a, uint32_t block_id,
-                                                 typename Fam::shared& s_fam, unsigned int* s_cnt) {
+                                                 typename Fam::shared& s_fam, unsigned int* s_cnt,
+                                                 int32_t* s_state = nullptr) {
   if (threadIdx.x < 2) s_cnt[threadIdx.x] = 0;
   Fam::stage(a, s_fam);
   __syncthreads();
@@ -279,10 +289,11 @@ __device__ __forceinline__ void bsx_advance_body(const typename Fam::args& a, ui
     const uint64_t lane = a.ctl.lane_offset + (uint64_t)i;
     const uint64_t step = bsx_step_of(a.ctl);
     int32_t nst; double reward;
-    const int act = a.ctl.force_reset ? 0 : a.action[i];
+    const int act = a.ctl.force_reset ? 0 : bsx_action(a.ctl, a.action, i, step);
     const int32_t st = a.ctl.state_in != nullptr ? a.ctl.state_in[i] : a.state[i];
     type = Fam::template advance<LEAN>(a, s_fam, i, lane, step, st, act, nst, reward);
     a.state[i] = nst;
+    if (s_state != nullptr) s_state[threadIdx.x] = nst;     // fused small-batch step: the tile streamer reads it from LDS
     if (LEAN) bsx_emit_at<0, 0>(a.ctl, a.out, i, i, lane, step, type, reward);
     else bsx_emit(a.ctl, a.out, i, lane, step, type, reward);
   }
@@ -418,6 +429,67 @@ __global__ void __launch_bounds__(BS) bsx_hot_stream_kernel(float* __restrict__ 
   bsx_hot_stream_body<HotFn, K, BS>(obs, state, n_lanes, cells, cells_magic, dv, fn, blockIdx.x, wave_contig);
 }
 
+// ---------------------------------------------------------------------------------------------
+// Small batches (a rank's share of a strong-scaled batch: 2^20 / 8 lanes of catch are 26 MB of boards): ONE
+// launch per step.  A workgroup advances its 256 lanes, leaves their new packed states in LDS, and after one
+// barrier streams exactly those 256 boards — [256 x cells] floats, contiguous in HBM — as 16-byte chunks with the
+// hot cells decoded from LDS.  At 2^20 lanes the decoupled pair wins (no store waits behind a barrier: the
+// barrier'd single-kernel designs lost 15-35 % there); when the whole step is a few microseconds
+// the second launch and the state column's round trip through L2 are what is left to remove.
+template <class HotFn>
+__device__ __forceinline__ void bsx_tile_stream(float* __restrict__ tile, const int32_t* s_state, int lanes_here,
+                                                uint32_t cells, uint32_t cells_magic, const HotFn& fn) {
+  const uint32_t total = (uint32_t)lanes_here * cells;                  // <= 256 * 4096 floats
+  const uint32_t n_chunks = total >> 2;
+  const bool aligned = (cells & 3u) == 0;
+  bsx_f4* __restrict__ t4 = reinterpret_cast<bsx_f4*>(tile);
+  for (uint32_t c = threadIdx.x; c < n_chunks; c += BSX_BLOCK) {
+    const uint32_t f = c << 2;
+    const uint32_t dl = bsx_div_cells(f, cells, cells_magic);
+    const int r0 = (int)(f - dl * cells);
+    int ha, hb;
+    fn(s_state[dl], ha, hb);
+    const int a0 = ha < 0 ? -1 : ha - r0, b0 = hb < 0 ? -1 : hb - r0;
+    bsx_f4 v;
+    v.x = (a0 == 0 || b0 == 0) ? 1.0f : 0.0f;
+    v.y = (a0 == 1 || b0 == 1) ? 1.0f : 0.0f;
+    v.z = (a0 == 2 || b0 == 2) ? 1.0f : 0.0f;
+    v.w = (a0 == 3 || b0 == 3) ? 1.0f : 0.0f;
+    const int over = (int)cells - r0;
+    if (!aligned && over < 4) {               // elements j >= over belong to the next lane's row (dl + 1 < lanes_here
+      int na, nb;                             // because the chunk lies inside the tile)
+      fn(s_state[dl + 1], na, nb);
+      const int a1 = na < 0 ? -1 : na + over, b1 = nb < 0 ? -1 : nb + over;
+      if (over <= 1) v.y = (a1 == 1 || b1 == 1) ? 1.0f : 0.0f;
+      if (over <= 2) v.z = (a1 == 2 || b1 == 2) ? 1.0f : 0.0f;
+      v.w = (a1 == 3 || b1 == 3) ? 1.0f : 0.0f;
+    }
+    t4[c] = v;
+  }
+  // ragged tail (< 4 floats): only the last, partial workgroup of an odd-sized array can have one
+  const uint32_t f = (n_chunks << 2) + threadIdx.x;
+  if (threadIdx.x < 3 && f < total) {
+    const uint32_t dl = bsx_div_cells(f, cells, cells_magic);
+    const int r = (int)(f - dl * cells);
+    int ha, hb;
+    fn(s_state[dl], ha, hb);
+    tile[f] = (ha == r || hb == r) ? 1.0f : 0.0f;
+  }
+}
+
+template <class Fam, bool LEAN, class HotFn>
+__global__ void __launch_bounds__(BSX_BLOCK) bsx_fused_tile_kernel(const typename Fam::args a, float* __restrict__ obs,
+                                                                   const uint32_t cells, const uint32_t cells_magic,
+                                                                   const HotFn fn) {
+  __shared__ typename Fam::shared s_fam;
+  __shared__ unsigned int s_cnt[2];
+  __shared__ int32_t s_state[BSX_BLOCK];
+  bsx_advance_body<Fam, LEAN>(a, blockIdx.x, s_fam, s_cnt, s_state);    // ends with a barrier: s_state is complete
+  const int64_t lane0 = (int64_t)blockIdx.x * BSX_BLOCK;
+  const int64_t left = a.ctl.n_lanes - lane0;
+  bsx_tile_stream(obs + lane0 * (int64_t)cells, s_state, left < BSX_BLOCK ? (int)left : BSX_BLOCK, cells, cells_magic, fn);
+}
+
 // Software-pipelined rollout step of a two-kernel family: ONE launch runs the observation stream of
 // step t beside the lane advance of step t+1.  Nothing inside the launch depends on anything else inside
 // it — both halves read the packed state column W(t) that the previous launch wrote, the advance writes
@@ -475,7 +547,7 @@ __global__ void __launch_bounds__(BSX_BLOCK) bsx_advance_delta_kernel(const type
     const uint64_t lane = a.ctl.lane_offset + (uint64_t)i;
     const uint64_t step = bsx_step_of(a.ctl);
     int32_t nst; double reward;
-    const int act = a.ctl.force_reset ? 0 : a.action[i];
+    const int act = a.ctl.force_reset ? 0 : bsx_action(a.ctl, a.action, i, step);
     const int32_t was = paint[i];
     type = Fam::template advance<false>(a, s_fam, i, lane, step, a.state[i], act, nst, reward);
     a.state[i] = nst;

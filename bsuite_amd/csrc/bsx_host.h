@@ -22,6 +22,9 @@ static inline int bsx_check_call(const bsx_call_t* call, const void* action, con
   if ((reinterpret_cast<uintptr_t>(out.observation) & 15u) != 0) return BSX_EALIGN;
   if (call->wrap.kind < BSX_WRAP_NONE || call->wrap.kind > BSX_WRAP_NOISE_SCALE) return BSX_EINVAL;
   if (call->n_steps < 0 || (call->n_steps > 1 && call->force_reset)) return BSX_EINVAL;
+  // action ring: a power of two of rows, for single-step calls only (a rollout already takes [T,B] actions)
+  if (call->action_ring < 0 || (call->action_ring & (call->action_ring - 1)) != 0) return BSX_EINVAL;
+  if (call->action_ring > 1 && (call->n_steps > 1 || call->obs_paint != nullptr)) return BSX_EMODE;
   if ((call->stream.mt_state == nullptr) != (call->stream.mt_pos == nullptr)) return BSX_ENULL;
   if ((call->stream.mt_gauss == nullptr) != (call->stream.mt_has_gauss == nullptr)) return BSX_ENULL;
   if (call->stream.mt_state != nullptr && call->wrap.kind >= BSX_WRAP_NOISE &&
@@ -53,6 +56,8 @@ static inline bsx_ctl bsx_make_ctl(const bsx_call_t* call) {
   c.wrap_seed = call->wrap.seed;
   c.wrap_kind = call->wrap.kind;
   c.force_reset = call->force_reset;
+  c.action_ring_mask = call->action_ring > 1 ? (uint32_t)call->action_ring - 1u : 0u;
+  c._pad = 0;
   c.mt_state = call->stream.mt_state;
   c.mt_pos = call->stream.mt_pos;
   c.mt_gauss = call->stream.mt_gauss;
@@ -74,9 +79,18 @@ static inline int bsx_n_steps(const bsx_call_t* call) { return call->n_steps > 1
 // magic for q = n / d via __umulhi(n, magic): exact for n < 2^20, d <= 4096
 static inline uint32_t bsx_div_magic(uint32_t d) { return (uint32_t)((0x100000000ull / d) + 1ull); }
 
+// A/B knobs.  The product library never reads the environment: the knobs exist only in the
+// tuning build (`python -m bsuite_amd.build --tuning` -> libbsuite_amd_tuning.so, compiled with -DBSX_TUNING and
+// loaded through BSX_NATIVE_LIB by the A/B scripts under tools/ and by the tests that cover the non-default
+// settings); everywhere else every knob is its measured-best default, fixed at compile time.
 static inline int bsx_env_int(const char* name, int dflt) {
+#ifdef BSX_TUNING
   const char* v = getenv(name);
   return (v != nullptr && *v != '\0') ? atoi(v) : dflt;
+#else
+  (void)name;
+  return dflt;
+#endif
 }
 
 // Launches the lane-per-thread advance kernel of a two-kernel family.
@@ -262,11 +276,22 @@ static int bsx_pair_call(const typename Fam::args& a0, const bsx_call_t* call, c
   const bool pipelined = pipe_env != 0 && T > 1 && call->state_alt != nullptr && call->obs_paint == nullptr &&
                          cells >= 4u && (((uint64_t)B * cells) & 3ull) == 0;
   int rc = 0;
-  if (!pipelined) {
+  // small batches: one fused launch per step (bsx_fused_tile_kernel) while the observation array is at most
+  // BSX_FUSED_TILE_MAX_BYTES (measured crossover, profiles/r03/ab_fused_tile.log); the tile start
+  // block*256*cells*4 is always 16-byte aligned when the slice is.
+  static const int64_t fused_max = (int64_t)bsx_env_int("BSX_FUSED_TILE_MAX_BYTES", 64 << 20);
+  const bool fused = call->obs_paint == nullptr && cells >= 4u && cells <= 4096u && B * (int64_t)cells * 4 <= fused_max &&
+                     (((uint64_t)B * cells) & 3ull) == 0 && (reinterpret_cast<uintptr_t>(out.observation) & 15u) == 0;
+  if (!pipelined || fused) {
+    const bool lean_f = a0.ctl.log.steps == nullptr && a0.ctl.wrap_kind < BSX_WRAP_NOISE && a0.ctl.mt_state == nullptr;
     for (int t = 0; t < T && rc == 0; ++t) {
       const typename Fam::args s = at(t);
       if (call->obs_paint != nullptr) {
         rc = bsx_launch_advance_delta<Fam, HotFn>(s, fn, call->obs_paint, cells, st);
+      } else if (fused) {
+        const dim3 grid((unsigned)((B + BSX_BLOCK - 1) / BSX_BLOCK)), block(BSX_BLOCK);
+        if (lean_f) bsx_fused_tile_kernel<Fam, true, HotFn><<<grid, block, 0, st>>>(s, s.out.observation, cells, magic, fn);
+        else bsx_fused_tile_kernel<Fam, false, HotFn><<<grid, block, 0, st>>>(s, s.out.observation, cells, magic, fn);
       } else {
         rc = bsx_launch_advance<Fam>(s, st);
         // stores/thread x 256 threads: a sharp optimum per family (profiles/r01/sweep_stream_*.log)

@@ -41,7 +41,7 @@ __device__ __forceinline__ void mnist_advance_body(const mnist_args& a, uint32_t
       type = BSX_FIRST;
     } else {                                                    // mnist.py:69-75
       const int label = (st >> 24) & 0xF;
-      reward = (a.action[i] == label) ? 1.0 : -1.0;
+      reward = (bsx_action(a.ctl, a.action, i, step) == label) ? 1.0 : -1.0;
       a.info[i] += 1.0 - reward;
       nst = (st & 0x0FFFFFFF) | MN_RESET_BIT;                   // SHOW bit cleared: obs = zeros
       type = BSX_LAST;

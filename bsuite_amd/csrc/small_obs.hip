@@ -1,4 +1,4 @@
-// small_obs.hip — the families whose observation is a short row (1..256 floats per lane):
+// small_obs.hip — C-ABI entry points of the small-observation families (device code: small_obs.h):
 //   bandit            bsuite/environments/bandit.py:54-64
 //   memory_chain      bsuite/environments/memory_chain.py:60-97
 //   umbrella_chain    bsuite/environments/umbrella_chain.py:60-92
@@ -7,330 +7,14 @@
 //                     bsuite/experiments/cartpole_swingup/cartpole_swingup.py:81-150
 //   mountain_car      bsuite/environments/mountain_car.py:62-90
 // each with the auto-reset of bsuite/environments/base.py:54-65.
-//
-// One kernel shape for all of them: thread t advances lane (block*256 + t) from coalesced SoA column
-// loads and either stores its short observation row itself or — the wide rows of memory_chain /
-// umbrella_chain — leaves it as bits in an LDS tile that the whole block streams to HBM as consecutive
-// 16-byte chunks (small_obs_body, below).  Physics state is f32 on the device (the reference holds
-// Python floats); rewards and the time-fraction observation are formed in f64 exactly as the reference
-// forms them and cast once.
-#include "bsx_host.h"
-#include "bsx_math.h"
-#include "catch_fam.h"
-#include "deep_sea_fam.h"
-#include "mnist_fam.h"
-#include "pair_mixed.h"
-
-// n_steps == 1 is env.step()/reset(); n_steps = T > 1 is the fused rollout: the same thread advances
-// its lane T times inside one launch (actions [T,B], outputs [T,B,...]); per-lane state columns are
-// re-read from L2 by the thread that wrote them, so HBM sees only the action/TimeStep streams —
-// the tiny families are otherwise bound by one ~8 us launch per step.
-// LOG / NOISE / MT: -1 = decide at run time, 0 = compiled out, 1 = always on.  The common call (no
-// Logging wrapper, no RewardNoise, counter-based draws) runs the <0,0,0> instantiation: without the
-// MT19937 twist, the f64 normal transform and the row snapshots the kernel is a fifth of the size.
-//
-// Two ways for a row to reach HBM:
-//   DIRECT  rows of 1, 3 or an even number <= 8 floats: the thread that advances a lane stores its row
-//           itself — no LDS, no barrier.  Every family with a fixed short row (bandit, discounting_chain,
-//           cartpole, mountain_car) always takes it.
-//   PACKED  the families whose row length is a parameter (memory_chain: nb+2, umbrella_chain: 3+nd, up to
-//           256 floats) and whose row is a few floats (HEAD) followed by values that one or two BITS
-//           encode.  The block keeps the tile [256 x numel] as flat bit planes in LDS — bit (l*numel + j) of
-//           a plane belongs to element j of lane l — which each lane ORs its bits into; after a barrier
-//           the block streams the tile to HBM as consecutive 16-byte chunks: chunk c is the nibble at bit
-//           4c of each plane, four v_bfe/v_cvt away from a float4 (a lane-per-row store would be a
-//           stride-(4*numel) scatter; an f32 tile costs 32x the LDS — up to 32 KiB per workgroup, which
-//           capped the resident workgroups per CU — and per-element records cost ~80 VALU instructions
-//           per chunk: profiles/r02/ab_packed_records_v*.log).  The HEAD floats stay in the lane's
-//           registers and overwrite their (zero) places in the tile after a second barrier.
-//           LDS per workgroup: 32*numel bytes per plane (<= 8 KiB).
-// A lane's handle on the tile's bit planes.
-struct bsx_bit_sink {
-  uint32_t* planes;        // LDS: PLANES x `stride` words
-  int stride;              // words per plane = 8 * numel
-  uint32_t base;           // flat bit index of the lane's element HEAD
-  // ORs bits [32k, 32k+n) of the lane's bit string (n in 1..32, the low n bits of w) into plane p
-  __device__ __forceinline__ void put(int p, int k, uint32_t w, int n) const {
-    uint32_t word, lo, hi;
-    int has_hi;
-    bsx_plane_split(base + 32u * (uint32_t)k, w, n, &word, &lo, &hi, &has_hi);
-    uint32_t* dst = planes + p * stride + word;
-    atomicOr(dst, lo);
-    if (has_hi) atomicOr(dst + 1, hi);
-  }
-};
-
-template <class Env, bool ROLLOUT, int LOG, int NOISE, int MT, bool DIRECT_ARG>
-__device__ __forceinline__ void small_obs_body(const typename Env::args& a, const int n_steps_arg,
-                                               const uint32_t block_id, float* s_obs, unsigned int* s_cnt) {
-  constexpr bool DIRECT = DIRECT_ARG || !Env::PACKED;
-  const int n_steps = ROLLOUT ? n_steps_arg : 1;   // the single-step instantiation has no loop: keeping
-                                                    // every kernarg live across iterations costs ~120 VGPRs
-  if (threadIdx.x < 2) s_cnt[threadIdx.x] = 0;
-  __syncthreads();
-  const int numel = a.obs_numel;
-  const int64_t B = a.ctl.n_lanes;
-  const int64_t lane0 = (int64_t)block_id * BSX_BLOCK;
-  const int64_t remaining = B - lane0;
-  const int lanes_here = remaining < BSX_BLOCK ? (int)remaining : BSX_BLOCK;
-  const uint64_t step0 = bsx_step_of(a.ctl);
-  // Fused rollout of a family with HAS_REGS: the lane's state lives in registers for the T steps and the
-  // action of step t+1 is in flight while step t computes.
-  constexpr bool REGS = ROLLOUT && Env::HAS_REGS;
-  const bool mine = (int)threadIdx.x < lanes_here;
-  const int64_t i = lane0 + threadIdx.x;
-  const uint64_t lane = a.ctl.lane_offset + (uint64_t)i;
-  typename Env::regs rg;
-  int act_next = 0;
-  if constexpr (REGS) {
-    if (mine) {
-      Env::load(a, i, rg);
-      act_next = a.action[i];
-    }
-  }
-
-#pragma unroll 1
-  for (int t = 0; t < n_steps; ++t) {
-    int act = 0;
-    if constexpr (REGS) {
-      act = act_next;
-      if (mine && t + 1 < n_steps) act_next = a.action[(int64_t)(t + 1) * B + i];
-    }
-    const int64_t oi = (int64_t)t * B + i;
-    int type = -1;
-    if constexpr (DIRECT) {
-      // A wave's 64 rows are one contiguous range, written by back-to-back instructions that the L2 merges
-      // line by line; the waves of a block (and the steps of a fused rollout) never wait for each other.
-      if (mine) {
-        double reward = 0.0;
-        float o[8];
-        if constexpr (REGS) type = Env::template core<LOG, MT>(a, rg, act, i, lane, step0 + (uint64_t)t, o, reward);
-        else type = Env::template step<LOG, MT>(a, i, oi, lane, step0 + (uint64_t)t, o, reward);
-        bsx_emit_at<LOG, NOISE>(a.ctl, a.out, i, oi, lane, step0 + (uint64_t)t, type, reward);
-        float* __restrict__ dst = a.out.observation + oi * (int64_t)numel;
-        if ((numel & 1) == 0) {
-          float2* __restrict__ d2 = reinterpret_cast<float2*>(dst);
-#pragma unroll
-          for (int k = 0; k < 4; ++k)
-            if (2 * k < numel) d2[k] = make_float2(o[2 * k], o[2 * k + 1]);
-        } else if (numel == 3) {
-          // one 12-byte store per lane (global_store_dwordx3): a wave's 64 rows are 768 contiguous bytes
-          struct __attribute__((packed, aligned(4))) row3 { float a, b, c; };
-          row3 v; v.a = o[0]; v.b = o[1]; v.c = o[2];
-          *reinterpret_cast<row3*>(dst) = v;
-        } else {
-          dst[0] = o[0];                                                // numel == 1
-        }
-      }
-      bsx_count_types(a.ctl, type, s_cnt);
-    } else {
-      constexpr int HEAD = Env::HEAD, PLANES = Env::PLANES;
-      uint32_t* __restrict__ planes = reinterpret_cast<uint32_t*>(s_obs);
-      const int stride = numel * (BSX_BLOCK / 32);                       // words per plane
-      for (int w = threadIdx.x; w < PLANES * stride; w += BSX_BLOCK) planes[w] = 0u;
-      __syncthreads();
-      float head[HEAD];
-      if (mine) {
-        double reward = 0.0;
-        const bsx_bit_sink sink{planes, stride, (uint32_t)((int)threadIdx.x * numel + HEAD)};
-        type = Env::template step<LOG, MT, true>(a, i, oi, lane, step0 + (uint64_t)t, head, reward, &sink);
-        bsx_emit_at<LOG, NOISE>(a.ctl, a.out, i, oi, lane, step0 + (uint64_t)t, type, reward);
-      }
-      bsx_count_types(a.ctl, type, s_cnt);
-      __syncthreads();
-
-      // stream the tile: [lanes_here x numel] floats, contiguous in HBM, 16-byte aligned start
-      float* __restrict__ tile = a.out.observation + ((int64_t)t * B + lane0) * (int64_t)numel;
-      const int total = lanes_here * numel;
-      const bool vec = ((((int64_t)t * B * numel) & 3) == 0);            // [t] slice 16-byte aligned?
-      const int n_chunks = vec ? total >> 2 : 0;
-      bsx_f4* __restrict__ t4 = reinterpret_cast<bsx_f4*>(tile);
-      for (int ch = threadIdx.x; ch < n_chunks; ch += BSX_BLOCK) {
-        const uint32_t n0 = planes[ch >> 3] >> ((ch & 7) << 2);
-        const uint32_t n1 = PLANES > 1 ? planes[stride + (ch >> 3)] >> ((ch & 7) << 2) : 0u;
-        bsx_f4 q;
-        q.x = Env::decode(n0 & 1u, n1 & 1u);
-        q.y = Env::decode((n0 >> 1) & 1u, (n1 >> 1) & 1u);
-        q.z = Env::decode((n0 >> 2) & 1u, (n1 >> 2) & 1u);
-        q.w = Env::decode((n0 >> 3) & 1u, (n1 >> 3) & 1u);
-        t4[ch] = q;
-      }
-      for (int f = (n_chunks << 2) + (int)threadIdx.x; f < total; f += BSX_BLOCK) {
-        const uint32_t b0 = (planes[f >> 5] >> (f & 31)) & 1u;
-        const uint32_t b1 = PLANES > 1 ? (planes[stride + (f >> 5)] >> (f & 31)) & 1u : 0u;
-        tile[f] = Env::decode(b0, b1);
-      }
-      // The barrier orders every tile store of the block before the HEAD floats that overwrite their
-      // places (and the plane reads above before the next step's zeroing).
-      __syncthreads();
-      if (mine) {
-        struct __attribute__((packed, aligned(4))) head_row { float v[HEAD]; };
-        head_row h;
-#pragma unroll
-        for (int k = 0; k < HEAD; ++k) h.v[k] = head[k];
-        *reinterpret_cast<head_row*>(a.out.observation + oi * (int64_t)numel) = h;
-      }
-    }
-  }
-  if constexpr (REGS) {
-    if (mine) Env::store(a, i, rg);
-  }
-  __syncthreads();
-  bsx_flush_counts(a.ctl, s_cnt, block_id);
-}
-
-template <class Env, bool ROLLOUT, int LOG, int NOISE, int MT, bool DIRECT>
-__global__ void __launch_bounds__(BSX_BLOCK) small_obs_kernel(const typename Env::args a, const int n_steps) {
-  extern __shared__ __attribute__((aligned(16))) float s_obs[];
-  __shared__ unsigned int s_cnt[2];
-  small_obs_body<Env, ROLLOUT, LOG, NOISE, MT, DIRECT>(a, n_steps, blockIdx.x, s_obs, s_cnt);
-}
-
-// Dynamic LDS of one workgroup stepping `a`.
-template <class Env>
-static size_t small_obs_lds(const typename Env::args& a) {
-  if constexpr (Env::PACKED) return bsx_small_direct_shape(a.obs_numel) ? 0 : (size_t)Env::PLANES * a.obs_numel * (BSX_BLOCK / 32) * 4;
-  else return 0;
-}
-
-// One workgroup of a grouped launch: the single-step body.  A segment without Logging wrapper, RewardNoise and
-// MT19937 draws (uniform per workgroup) runs the lean instantiation, like a stand-alone call does: a cartpole
-// workgroup then issues a third fewer instructions, and the heavy workgroups are what a sweep's lane advance
-// waits for (profiles/r02/sweep_phase0_trace.json).
-template <class Env, bool D>
-__device__ __forceinline__ void small_obs_group_body_d(const typename Env::args& a, const uint32_t blk, float* s_obs,
-                                                       unsigned int* s_cnt) {
-  if (bsx_ctl_lean(a.ctl)) small_obs_body<Env, false, 0, 0, 0, D>(a, 1, blk, s_obs, s_cnt);
-  else small_obs_body<Env, false, -1, -1, -1, D>(a, 1, blk, s_obs, s_cnt);
-}
-template <class Env>
-__device__ __forceinline__ void small_obs_group_body(const typename Env::args& a, const uint32_t blk, float* s_obs,
-                                                     unsigned int* s_cnt) {
-  if constexpr (Env::PACKED) {
-    if (!bsx_small_direct_shape(a.obs_numel)) {                 // uniform per workgroup
-      small_obs_group_body_d<Env, false>(a, blk, s_obs, s_cnt);
-      return;
-    }
-  }
-  small_obs_group_body_d<Env, true>(a, blk, s_obs, s_cnt);
-}
-
-// Grouped launch: every workgroup looks up its segment and runs the single-step body on that
-// segment's argument struct (device memory).
-template <class Env>
-__global__ void __launch_bounds__(BSX_BLOCK) small_obs_group_kernel(const typename Env::args* __restrict__ table,
-                                                                    const bsx_group_index gi) {
-  extern __shared__ __attribute__((aligned(16))) float s_obs[];
-  __shared__ unsigned int s_cnt[2];
-  const bsx_group_slot w = bsx_group_find(gi, (int)blockIdx.x);
-  small_obs_group_body<Env>(table[w.seg], w.block, s_obs, s_cnt);
-}
-
-template <class Env>
-static int small_obs_group_launch(bsx_group* g, int phase, hipStream_t st) {
-  if (phase == 1) return 0;                 // one kernel per step: everything happens in phase 0
-  const dim3 grid((unsigned)g->total_blocks), block(BSX_BLOCK);
-  const typename Env::args* table = (const typename Env::args*)g->d_args;
-  small_obs_group_kernel<Env><<<grid, block, g->lds_bytes, st>>>(table, g->index1());
-  return (int)hipGetLastError();
-}
-
-// A BSX_FAM_SMALL_MIXED group holds segments of ANY of the families in this file: every segment's
-// argument struct sits in a fixed-stride slot next to a family tag, and one launch
-// advances them all (the kernel switches on the tag per workgroup).  Six ~8 us launches of a
-// heterogeneous sweep become one.
-#define SMALL_MIXED_STRIDE 1024
-static int small_obs_mixed_launch(bsx_group* g, int phase, hipStream_t st);
+#include "small_obs.h"
 
 // Tile class of a segment inside a grouped launch (segments of one group must share it).  Always 256 since
 // the bit-plane tiles: the 64-lane class for rows wider than 32 floats is gone (kept in the ABI so that a
 // caller that buckets segments by class keeps working).
 extern "C" int bsx_group_small_class(int32_t numel) { (void)numel; return BSX_BLOCK; }
 
-// Records one segment of a small-observation family in a group (of its own family, or mixed).
-template <class Env>
-static int small_obs_group_put(bsx_group* g, int32_t family, int32_t index, const bsx_call_t* call,
-                               const typename Env::args& a) {
-  static_assert(sizeof(typename Env::args) <= SMALL_MIXED_STRIDE, "argument struct exceeds the mixed-group slot");
-  const uint64_t nb = (uint64_t)(a.ctl.n_lanes + BSX_BLOCK - 1) / BSX_BLOCK;
-  const size_t lds = small_obs_lds<Env>(a);
-  if (g != nullptr && g->family == BSX_FAM_SWEEP_MIXED)       // one segment of the whole-sweep group: phase 0 only
-    return bsx_mixed_put(g, family, index, call, &a, sizeof(a), nullptr, 0, nb, 0, lds);
-  const bool mixed = g != nullptr && g->family == BSX_FAM_SMALL_MIXED;
-  int rc = bsx_group_check_set(g, mixed ? BSX_FAM_SMALL_MIXED : family, index, call,
-                               mixed ? SMALL_MIXED_STRIDE : sizeof(typename Env::args), mixed ? sizeof(int32_t) : 0, BSX_BLOCK);
-  if (rc != 0) return rc;
-  memcpy(&g->args[(size_t)index * g->arg_size], &a, sizeof(a));
-  if (mixed) memcpy(&g->args2[(size_t)index * sizeof(int32_t)], &family, sizeof(int32_t));
-  if (nb > 0x3FFFFFFFull) return BSX_EINVAL;
-  g->blocks[index] = (int32_t)nb;
-  if (lds > g->lds_bytes) g->lds_bytes = lds;
-  g->is_set[index] = 1;
-  g->launch = mixed ? small_obs_mixed_launch : small_obs_group_launch<Env>;
-  return 0;
-}
-
-template <class Env>
-static int launch_small_obs(const typename Env::args& a, int n_steps, void* hip_stream) {
-  hipStream_t st = (hipStream_t)hip_stream;
-  if (n_steps < 1) return BSX_EINVAL;
-  const bool logging = a.ctl.log.steps != nullptr, noise = a.ctl.wrap_kind >= BSX_WRAP_NOISE;
-  const bool lean = !logging && !noise && a.ctl.mt_state == nullptr;
-  const int64_t blocks = (a.ctl.n_lanes + BSX_BLOCK - 1) / BSX_BLOCK;
-  if (blocks > 0x7FFFFFFF) return BSX_EINVAL;
-  const size_t lds = small_obs_lds<Env>(a);
-  const dim3 g((unsigned)blocks), b(BSX_BLOCK);
-  // Per-thread stores (4-byte / 12-byte / 8-byte stores, each wave writing one contiguous range) against
-  // an f32 LDS tile, measured on bandit, discounting_chain, cartpole, mountain_car, memory_len: eager equal
-  // or 2-4 % faster, fused rollout 3-15 % faster (profiles/r02/ab_small_direct_stores.log).  Three 4-byte
-  // stores at stride 12 for the 3-float rows were 5-8 % SLOWER than the tile; one global_store_dwordx3 is
-  // faster.
-#define SMALL_OBS_LAUNCH(D)                                                                                \
-  {                                                                                                        \
-    if (n_steps == 1 && lean) small_obs_kernel<Env, false, 0, 0, 0, D><<<g, b, lds, st>>>(a, 1);           \
-    else if (n_steps == 1) small_obs_kernel<Env, false, -1, -1, -1, D><<<g, b, lds, st>>>(a, 1);           \
-    else if (logging && noise) small_obs_kernel<Env, true, 1, 1, -1, D><<<g, b, lds, st>>>(a, n_steps);    \
-    else if (logging) small_obs_kernel<Env, true, 1, 0, -1, D><<<g, b, lds, st>>>(a, n_steps);             \
-    else if (noise) small_obs_kernel<Env, true, 0, 1, -1, D><<<g, b, lds, st>>>(a, n_steps);               \
-    else if (lean) small_obs_kernel<Env, true, 0, 0, 0, D><<<g, b, lds, st>>>(a, n_steps);                 \
-    else small_obs_kernel<Env, true, 0, 0, -1, D><<<g, b, lds, st>>>(a, n_steps);                          \
-  }
-  if constexpr (Env::PACKED) {
-    if (!bsx_small_direct_shape(a.obs_numel)) {
-      SMALL_OBS_LAUNCH(false)
-      return bsx_launch_status();
-    }
-  }
-  SMALL_OBS_LAUNCH(true)
-#undef SMALL_OBS_LAUNCH
-  return bsx_launch_status();
-}
-
 // ------------------------------------------------------------------------------ bandit
-struct bandit_env {
-  static constexpr bool HAS_REGS = false, PACKED = false;
-  struct regs { int unused; };
-  struct args {
-    bsx_ctl ctl; const int32_t* action; int32_t* state; bsx_timestep_t out; double* info;
-    int32_t obs_numel; int32_t num_actions; double rewards[BSX_BANDIT_MAX_ACTIONS];
-  };
-  template <int LOG, int MT>
-  __device__ static int step(const args& a, int64_t i, int64_t oi, uint64_t, uint64_t, float* o, double& reward) {
-    BSX_NO_CONTRACT
-    o[0] = 1.0f;                                                // bandit.py:54 (ones)
-    if (a.ctl.force_reset || a.state[i]) { a.state[i] = 0; return BSX_FIRST; }
-    int act = a.action[oi];
-    if (act < 0 || act >= a.num_actions) {                      // reference: IndexError (bandit.py:61)
-      bsx_note_invalid_action(a.ctl, i);
-      act = act < 0 ? 0 : a.num_actions - 1;                    // never read OOB
-    }
-    reward = a.rewards[act];                                    // :61
-    a.info[i] += 1.0 - reward;                                  // :62
-    a.state[i] = 1;
-    return BSX_LAST;                                            // :64
-  }
-};
-
 static int bandit_make(const bsx_bandit_t* cfg, const bsx_call_t* call, const int32_t* action, int32_t* state, bsx_timestep_t out, double* info, bandit_env::args* a) {
   if (cfg == nullptr) return BSX_ENULL;
   int rc = bsx_check_call(call, action, out);
@@ -361,70 +45,6 @@ extern "C" int bsx_group_set_bandit(bsx_group_t* g, int32_t index, const bsx_ban
 }
 
 // ------------------------------------------------------------------------------ memory_chain
-#define MC_RESET_BIT (1 << 28)
-struct memory_chain_env {
-  static constexpr bool HAS_REGS = false, PACKED = true;
-  struct regs { int unused; };
-  struct args {
-    bsx_ctl ctl; const int32_t* action; int32_t* state; uint64_t* context; bsx_timestep_t out;
-    double* info; int32_t obs_numel; int32_t L; int32_t nb;
-  };
-  // Packed rows: HEAD = [time, query]; element 2+b is 0 unless t == 0, then +-1 by context bit b: plane 0 says
-  // "non-zero", plane 1 carries the context bit.
-  static constexpr int HEAD = 2, PLANES = 2;
-  __device__ static float decode(uint32_t nonzero, uint32_t bit) {       // integer selects: no branches
-    return __uint_as_float((0u - nonzero) & (0xBF800000u ^ (bit << 31)));
-  }
-  template <bool PACK>
-  __device__ static void observe(const args& a, float* o, int t, int query, uint64_t ctx, const bsx_bit_sink* sink) {
-    BSX_NO_CONTRACT
-    o[0] = (float)(1.0 - (double)t / (double)a.L);              // memory_chain.py:64
-    o[1] = (t == a.L - 1) ? (float)query : 0.0f;                // :66-67
-    if constexpr (PACK) {
-      if (t == 0) {                                             // :69-70
-        const int n0 = a.nb < 32 ? a.nb : 32;
-        sink->put(0, 0, 0xFFFFFFFFu, n0);
-        sink->put(1, 0, (uint32_t)ctx, n0);
-        if (a.nb > 32) {
-          sink->put(0, 1, 0xFFFFFFFFu, a.nb - 32);
-          sink->put(1, 1, (uint32_t)(ctx >> 32), a.nb - 32);
-        }
-      }
-    } else {
-      for (int b = 0; b < a.nb; ++b)                            // :69-70
-        o[2 + b] = (t == 0) ? (float)(2 * (int)((ctx >> b) & 1ull) - 1) : 0.0f;
-    }
-  }
-  template <int LOG, int MT, bool PACK = false>
-  __device__ static int step(const args& a, int64_t i, int64_t oi, uint64_t lane, uint64_t step, float* o, double& reward,
-                             const bsx_bit_sink* sink = nullptr) {
-    int32_t st = a.state[i];
-    int t = st & 0xFFFFF, query = (st >> 20) & 0xFF;
-    uint64_t ctx = a.context[i];
-    if (a.ctl.force_reset || (st & MC_RESET_BIT)) {             // :91-97
-      bsx_draws d;
-      bsx_draws_begin<MT>(&d, a.ctl, i, lane, step);
-      ctx = 0;
-      uint32_t w = 0;
-      for (int b = 0; b < a.nb; ++b) ctx |= (uint64_t)bsx_bern_vec_bit(&d, b, &w) << b;   // BernVec(nb)
-      query = (int)bsx_randint(&d, (uint32_t)a.nb);
-      bsx_draws_end<MT>(&d, a.ctl, i);
-      t = 0;
-      a.context[i] = ctx;
-      a.state[i] = t | (query << 20);
-      observe<PACK>(a, o, t, query, ctx, sink);
-      return BSX_FIRST;
-    }
-    observe<PACK>(a, o, t, query, ctx, sink);                   // :74 — before the increment
-    t += 1;                                                     // :75
-    if (t - 1 < a.L) { a.state[i] = t | (query << 20); return BSX_MID; }   // :77-79
-    if (a.action[oi] == (int)((ctx >> query) & 1ull)) { reward = 1.0; a.info[i] += 1.0; }   // :83-85
-    else { reward = -1.0; a.info[a.ctl.n_lanes + i] += 2.0; }   // :86-88
-    a.state[i] = t | (query << 20) | MC_RESET_BIT;
-    return BSX_LAST;
-  }
-};
-
 static int memory_chain_make(const bsx_memory_chain_t* cfg, const bsx_call_t* call, const int32_t* action, int32_t* state, uint64_t* context, bsx_timestep_t out, double* info, memory_chain_env::args* a) {
   if (cfg == nullptr) return BSX_ENULL;
   int rc = bsx_check_call(call, action, out);
@@ -455,70 +75,6 @@ extern "C" int bsx_group_set_memory_chain(bsx_group_t* g, int32_t index, const b
 }
 
 // ------------------------------------------------------------------------------ umbrella_chain
-#define UC_RESET_BIT (1 << 22)
-struct umbrella_chain_env {
-  static constexpr bool HAS_REGS = false, PACKED = true;
-  struct regs { int unused; };
-  struct args {
-    bsx_ctl ctl; const int32_t* action; int32_t* state; bsx_timestep_t out; double* info;
-    int32_t obs_numel; int32_t L; int32_t nd;
-  };
-  // Packed rows: HEAD = [need, has, time]; element 3+b is distractor bit b as 0.0 / 1.0 (one plane).
-  static constexpr int HEAD = 3, PLANES = 1;
-  __device__ static float decode(uint32_t bit, uint32_t) { return __uint_as_float((0u - bit) & 0x3F800000u); }
-  template <bool PACK>
-  __device__ static void observe(const args& a, float* o, int t, int need, int has, bsx_draws* d, const bsx_bit_sink* sink) {
-    BSX_NO_CONTRACT
-    o[0] = (float)need;                                         // umbrella_chain.py:62
-    o[1] = (float)has;                                          // :63
-    o[2] = (float)(1.0 - (double)t / (double)a.L);              // :64
-    uint32_t w = 0;
-    if constexpr (PACK) {
-      uint32_t acc = 0;
-      for (int b = 0; b < a.nd; ++b) {                          // :65 BernVec(nd)
-        acc |= bsx_bern_vec_bit(d, b, &w) << (b & 31);
-        if ((b & 31) == 31 || b == a.nd - 1) { sink->put(0, b >> 5, acc, (b & 31) + 1); acc = 0; }
-      }
-    } else {
-      for (int b = 0; b < a.nd; ++b) o[3 + b] = (float)bsx_bern_vec_bit(d, b, &w);   // :65 BernVec(nd)
-    }
-  }
-  template <int LOG, int MT, bool PACK = false>
-  __device__ static int step(const args& a, int64_t i, int64_t oi, uint64_t lane, uint64_t step, float* o, double& reward,
-                             const bsx_bit_sink* sink = nullptr) {
-    BSX_NO_CONTRACT
-    int32_t st = a.state[i];
-    int t = st & 0xFFFFF, need = (st >> 20) & 1, has = (st >> 21) & 1;
-    bsx_draws d;
-    bsx_draws_begin<MT>(&d, a.ctl, i, lane, step);
-    if (a.ctl.force_reset || (st & UC_RESET_BIT)) {             // :87-92
-      t = 0;
-      need = (int)bsx_bern(&d);
-      has = (int)bsx_bern(&d);
-      observe<PACK>(a, o, t, need, has, &d, sink);
-      bsx_draws_end<MT>(&d, a.ctl, i);
-      a.state[i] = t | (need << 20) | (has << 21);
-      return BSX_FIRST;
-    }
-    t += 1;                                                     // :69
-    if (t == 1) has = (a.action[oi] == 1);                       // :71-72 (action_spec: {0,1})
-    int type;
-    if (t == a.L) {                                             // :74-81
-      if (has == need) reward = 1.0;
-      else { reward = -1.0; a.info[i] += 2.0; }
-      observe<PACK>(a, o, t, need, has, &d, sink);
-      type = BSX_LAST;
-    } else {                                                    // :83-85
-      reward = 2.0 * (double)bsx_bern(&d) - 1.0;
-      observe<PACK>(a, o, t, need, has, &d, sink);
-      type = BSX_MID;
-    }
-    bsx_draws_end<MT>(&d, a.ctl, i);
-    a.state[i] = t | (need << 20) | (has << 21) | (type == BSX_LAST ? UC_RESET_BIT : 0);
-    return type;
-  }
-};
-
 static int umbrella_chain_make(const bsx_umbrella_chain_t* cfg, const bsx_call_t* call, const int32_t* action, int32_t* state, bsx_timestep_t out, double* info, umbrella_chain_env::args* a) {
   if (cfg == nullptr) return BSX_ENULL;
   int rc = bsx_check_call(call, action, out);
@@ -549,43 +105,6 @@ extern "C" int bsx_group_set_umbrella_chain(bsx_group_t* g, int32_t index, const
 }
 
 // ------------------------------------------------------------------------------ discounting_chain
-#define DC_RESET_BIT (1 << 12)
-struct discounting_chain_env {
-  static constexpr bool HAS_REGS = false, PACKED = false;
-  struct regs { int unused; };
-  struct args {
-    bsx_ctl ctl; const int32_t* action; int32_t* state; bsx_timestep_t out;
-    int32_t obs_numel; int32_t bonus;
-  };
-  template <int LOG, int MT>
-  __device__ static int step(const args& a, int64_t i, int64_t oi, uint64_t, uint64_t, float* o, double& reward) {
-    BSX_NO_CONTRACT
-    int32_t st = a.state[i];
-    int t = st & 0xFF, ctx = ((st >> 8) & 0xF) - 1;
-    if (a.ctl.force_reset || (st & DC_RESET_BIT)) {             // discounting_chain.py:69-73
-      t = 0; ctx = -1;
-      o[0] = -1.0f; o[1] = 0.0f;
-      a.state[i] = 0;
-      return BSX_FIRST;
-    }
-    if (t == 0) {                                               // :76-77
-      ctx = a.action[oi];
-      if (ctx < 0 || ctx > 4) {                                 // reference: IndexError at the reward lookup
-        bsx_note_invalid_action(a.ctl, i);
-        ctx = ctx < 0 ? 0 : 4;                                  // action_spec: 5 values; never OOB
-      }
-    }
-    t += 1;
-    const int when = ctx == 0 ? 1 : ctx == 1 ? 3 : ctx == 2 ? 10 : ctx == 3 ? 30 : 100;   // :49
-    if (t == when) reward = (ctx == a.bonus) ? 1.0 + 0.1 : 1.0;                            // :57-58,80-83
-    o[0] = (float)ctx;                                          // :65
-    o[1] = (float)((double)t / 100.0);                          // :66
-    const int type = (t == 100) ? BSX_LAST : BSX_MID;           // :86-88
-    a.state[i] = t | ((ctx + 1) << 8) | (type == BSX_LAST ? DC_RESET_BIT : 0);
-    return type;
-  }
-};
-
 static int discounting_chain_make(const bsx_discounting_chain_t* cfg, const bsx_call_t* call, const int32_t* action, int32_t* state, bsx_timestep_t out, discounting_chain_env::args* a) {
   if (cfg == nullptr) return BSX_ENULL;
   int rc = bsx_check_call(call, action, out);
@@ -615,148 +134,6 @@ extern "C" int bsx_group_set_discounting_chain(bsx_group_t* g, int32_t index, co
 }
 
 // ------------------------------------------------------------------------------ cartpole / swingup
-#define CP_RESET_BIT (1 << 30)
-// Info columns (f64 [4,B]): 0 raw_return, 1 best_episode, 2 episode_return, 3 total_upright.
-// Classic cartpole pays r in {0, 1}: an episode of k steps returns (k-1) + [last step rewarded], so
-// raw_return / best_episode / episode_return are EXACT integer-valued functions of the step counter and
-// are folded into the f64 columns only when the episode ends (column 0 then holds finished episodes;
-// the host adds the running episode's k, environments/cartpole.py).  That removes two f64
-// read-modify-writes (32 B) per lane per step — a third of the step's HBM traffic.  Swing-up's
-// rewards (-0.1*|a-1| + 1) do not sum exactly out of order and the fused Logging rows snapshot the
-// columns mid-episode, so swing-up and logging runs keep the reference's per-step accumulation.
-struct cartpole_env {
-  struct args {
-    bsx_ctl ctl; const int32_t* action; float* state; int32_t* steps; bsx_timestep_t out;
-    double* info; int32_t obs_numel; bsx_cartpole_t cfg;
-    // derived on the host in f64, rounded once (cartpole_make)
-    float inv_m_total, pole_ml, pole_ml_over_mt, den_a, den_b, inv_x_threshold;
-  };
-  // The lane's state in registers: step() = load + core + store; the fused rollout loads once, runs core
-  // T times and stores once (small_obs_body), instead of a round trip through L2 every step.
-  static constexpr bool HAS_REGS = true, PACKED = false;
-  struct regs { float x, xd, th, thd; int32_t sk; };
-  __device__ static __forceinline__ void load(const args& a, int64_t i, regs& r) {
-    const int64_t B = a.ctl.n_lanes;
-    r.sk = a.steps[i];
-    r.x = a.state[i]; r.xd = a.state[B + i]; r.th = a.state[2 * B + i]; r.thd = a.state[3 * B + i];
-  }
-  __device__ static __forceinline__ void store(const args& a, int64_t i, const regs& r) {
-    const int64_t B = a.ctl.n_lanes;
-    a.state[i] = r.x; a.state[B + i] = r.xd; a.state[2 * B + i] = r.th; a.state[3 * B + i] = r.thd;
-    a.steps[i] = r.sk;
-  }
-  template <int LOG, int MT>
-  __device__ static int step(const args& a, int64_t i, int64_t oi, uint64_t lane, uint64_t step, float* o, double& reward) {
-    regs r;
-    load(a, i, r);
-    const int act = a.ctl.force_reset ? 0 : a.action[oi];
-    const int type = core<LOG, MT>(a, r, act, i, lane, step, o, reward);
-    store(a, i, r);
-    return type;
-  }
-  template <int LOG, int MT>
-  __device__ static __forceinline__ int core(const args& a, regs& rg, const int act, int64_t i, uint64_t lane, uint64_t step,
-                                             float* o, double& reward) {
-    BSX_NO_CONTRACT
-    const int64_t B = a.ctl.n_lanes;
-    const bsx_cartpole_t& g = a.cfg;
-    const int32_t sk = rg.sk;
-    const bool per_step_info = g.swingup || LOG == 1 || (LOG == -1 && a.ctl.log.steps != nullptr);
-    int k = sk & 0x3FFFFFFF;
-    float x, xd, th, thd, si, co;
-    int type;
-    if (a.ctl.force_reset || (sk & CP_RESET_BIT)) {             // cartpole.py:118-128 / swingup:81-91
-      bsx_draws d;
-      bsx_draws_begin<MT>(&d, a.ctl, i, lane, step);
-      const double lo = -g.init_range, hi = g.init_range;
-      x = (float)(lo + (hi - lo) * bsx_uniform(&d));
-      xd = (float)(lo + (hi - lo) * bsx_uniform(&d));
-      th = (float)(g.theta_offset + (lo + (hi - lo) * bsx_uniform(&d)));
-      thd = (float)(lo + (hi - lo) * bsx_uniform(&d));
-      bsx_draws_end<MT>(&d, a.ctl, i);
-      // an explicit reset() in mid-episode abandons it: the k rewards of 1 it has paid stay in raw_return
-      if (!per_step_info && !(sk & CP_RESET_BIT) && k > 0) a.info[i] += (double)k;
-      k = 0;
-      if (per_step_info) a.info[2 * B + i] = 0.0;               // _episode_return = 0
-      bsx_sincosf(th, &si, &co);                               // |theta_offset| + init_range <= 32 (cartpole_make)
-      type = BSX_FIRST;
-    } else {
-      x = rg.x; xd = rg.xd; th = rg.th; thd = rg.thd;
-      // step_cartpole, cartpole.py:37-65, in f32.  One sine/cosine pair per step: that of the OLD
-      // angle; the new angle's pair follows from it by the angle-addition formulas below.
-      float s0, c0;
-      bsx_sincosf(th, &s0, &c0);                                // th is in [0, 2*pi) or a reset value
-      const float force = (float)(act - 1) * g.force_mag;
-      const float temp = (force + a.pole_ml * (thd * thd) * s0) * a.inv_m_total;
-      // theta_acc = (g sin - cos*temp) / (l (4/3 - m_p cos^2 / m_t)); v_rcp_f32 is 1 ulp and the
-      // accelerations enter the state scaled by dt = 0.01
-      const float theta_acc = (g.gravity * s0 - c0 * temp) * __builtin_amdgcn_rcpf(a.den_a - a.den_b * (c0 * c0));
-      const float x_acc = temp - a.pole_ml_over_mt * theta_acc * c0;
-      const float dth = g.timescale * thd;
-      x = __builtin_fmaf(g.timescale, xd, x);
-      xd = __builtin_fmaf(g.timescale, x_acc, xd);
-      // np.remainder(theta + dt*theta_dot, 2*pi) in f64 (the period is not the f32 2*pi): one
-      // conditional +-2*pi is exact (Sterbenz) whenever the sum is within one period of [0, 2*pi)
-      const double raw_ang = (double)th + (double)g.timescale * (double)thd;
-      double ang = raw_ang >= 6.283185307179586 ? raw_ang - 6.283185307179586       // selects, not branches
-                   : (raw_ang < 0.0 ? raw_ang + 6.283185307179586 : raw_ang);
-      if (!(ang >= 0.0 && ang < 6.283185307179586)) {           // |dt*theta_dot| > 2*pi (theta_dot > 600 rad/s:
-        ang = (double)th + (double)g.timescale * (double)thd;   // only reachable from a loaded state)
-        ang -= 6.283185307179586 * floor(ang / 6.283185307179586);
-        if (!(ang >= 0.0 && ang < 6.283185307179586)) ang = 0.0;
-      }
-      th = (float)ang;
-      thd = __builtin_fmaf(g.timescale, theta_acc, thd);
-      if (fabsf(dth) <= 0.5f) bsx_sincos_advance(s0, c0, dth, &si, &co);
-      else bsx_sincosf(th, &si, &co);                           // th is in [0, 2*pi) here
-      k += 1;                                                   // time_elapsed += timescale (:63)
-      const bool timeout = k >= g.last_step;                    // time_elapsed > max_time
-      bool end;
-      double r;
-      if (!g.swingup) {                                         // cartpole.py:142-153
-        const bool ok = (co > g.height_threshold) && (fabsf(x) < g.x_threshold);
-        r = ok ? 1.0 : 0.0;
-        end = timeout || !ok;
-      } else {                                                  // swingup:104-123
-        const bool up = (co > g.height_threshold) && (fabsf(thd) < g.theta_dot_threshold) &&
-                        (fabsf(x) < g.x_reward_threshold);
-        r = -1.0 * fabs((double)(act - 1)) * g.move_cost;
-        if (up) { r += 1.0; a.info[3 * B + i] += 1.0; }
-        end = timeout || (fabsf(x) > g.x_threshold);
-      }
-      reward = r;
-      type = end ? BSX_LAST : BSX_MID;
-      if (per_step_info) {
-        a.info[i] += r;                                         // _raw_return
-        const double ep = a.info[2 * B + i] + r;                // _episode_return
-        a.info[2 * B + i] = ep;
-        if (end) {
-          const double best = a.info[B + i];
-          a.info[B + i] = ep > best ? ep : best;                // max(episode_return, best_episode)
-        }
-      } else if (end) {
-        const double ep = (double)(k - 1) + r;                  // sum of the episode's rewards, exact
-        a.info[i] += ep;
-        const double best = a.info[B + i];
-        a.info[B + i] = ep > best ? ep : best;
-      }
-    }
-    rg.x = x; rg.xd = xd; rg.th = th; rg.thd = thd;
-    rg.sk = k | (type == BSX_LAST ? CP_RESET_BIT : 0);
-    o[0] = x * a.inv_x_threshold;                               // cartpole.py:171-176
-    o[1] = xd * a.inv_x_threshold;
-    o[2] = si;
-    o[3] = co;
-    o[4] = thd;
-    o[5] = g.time_frac[k < g.last_step ? k : g.last_step];
-    if (g.swingup) {                                            // swingup:147-149
-      o[6] = (fabsf(x) < g.x_reward_threshold) ? 1.0f : -1.0f;
-      o[7] = (fabsf(thd) < g.theta_dot_threshold) ? 1.0f : -1.0f;
-    }
-    return type;
-  }
-};
-
 static int cartpole_make(const bsx_cartpole_t* cfg, const bsx_call_t* call, const int32_t* action, float* state, int32_t* steps, bsx_timestep_t out, double* info, cartpole_env::args* a) {
   if (cfg == nullptr) return BSX_ENULL;
   int rc = bsx_check_call(call, action, out);
@@ -799,73 +176,6 @@ extern "C" int bsx_group_set_cartpole(bsx_group_t* g, int32_t index, const bsx_c
 }
 
 // ------------------------------------------------------------------------------ mountain_car
-// Info column 0 = raw_return = -(steps taken): every step pays -1 (mountain_car.py:75-76), so the
-// column is folded at episode ends (+= -t, exact) and the host subtracts the running episode's t;
-// under the fused Logging wrapper (rows snapshot the column mid-episode) it is kept per step.
-struct mountain_car_env {
-  struct args {
-    bsx_ctl ctl; const int32_t* action; float* state; int32_t* steps; bsx_timestep_t out;
-    double* info; int32_t obs_numel; int32_t max_steps;
-  };
-  static constexpr bool HAS_REGS = true, PACKED = false;
-  struct regs { float pos, vel; int32_t sk; };
-  __device__ static __forceinline__ void load(const args& a, int64_t i, regs& r) {
-    r.sk = a.steps[i]; r.pos = a.state[i]; r.vel = a.state[a.ctl.n_lanes + i];
-  }
-  __device__ static __forceinline__ void store(const args& a, int64_t i, const regs& r) {
-    a.state[i] = r.pos; a.state[a.ctl.n_lanes + i] = r.vel; a.steps[i] = r.sk;
-  }
-  template <int LOG, int MT>
-  __device__ static int step(const args& a, int64_t i, int64_t oi, uint64_t lane, uint64_t step, float* o, double& reward) {
-    regs r;
-    load(a, i, r);
-    const int act = a.ctl.force_reset ? 0 : a.action[oi];
-    const int type = core<LOG, MT>(a, r, act, i, lane, step, o, reward);
-    store(a, i, r);
-    return type;
-  }
-  template <int LOG, int MT>
-  __device__ static __forceinline__ int core(const args& a, regs& rg, const int act, int64_t i, uint64_t lane, uint64_t step,
-                                             float* o, double& reward) {
-    BSX_NO_CONTRACT
-    const int32_t sk = rg.sk;
-    int t = sk & 0x3FFFFFFF;
-    float pos, vel;
-    int type;
-    if (a.ctl.force_reset || (sk & CP_RESET_BIT)) {             // mountain_car.py:66-71
-      bsx_draws d;
-      bsx_draws_begin<MT>(&d, a.ctl, i, lane, step);
-      // an explicit reset() in mid-episode abandons it: its t rewards of -1 stay in raw_return
-      if (!(LOG == 1 || (LOG == -1 && a.ctl.log.steps != nullptr)) && !(sk & CP_RESET_BIT) && t > 0) a.info[i] -= (double)t;
-      t = 0;
-      pos = (float)(-0.6 + (-0.4 - -0.6) * bsx_uniform(&d));
-      bsx_draws_end<MT>(&d, a.ctl, i);
-      vel = 0.0f;
-      type = BSX_FIRST;
-    } else {
-      pos = rg.pos; vel = rg.vel;
-      t += 1;                                                   // :74
-      reward = -1.0;
-      float sn, cs;
-      bsx_sincosf(3.0f * pos, &sn, &cs);                        // position is clipped to [-1.2, 0.6]
-      vel += (float)(act - 1) * 0.001f + cs * -0.0025f;            // :79-80
-      vel = fminf(fmaxf(vel, -0.07f), 0.07f);                   // :81
-      pos += vel;                                               // :82
-      pos = fminf(fmaxf(pos, -1.2f), 0.6f);                     // :83
-      if (pos == -1.2f) vel = fminf(fmaxf(vel, 0.0f), 0.07f);   // :84-85
-      type = (pos >= 0.5f || t >= a.max_steps) ? BSX_LAST : BSX_MID;   // :88-90
-      if (LOG == 1 || (LOG == -1 && a.ctl.log.steps != nullptr)) a.info[i] += reward;   // :76, per step under Logging
-      else if (type == BSX_LAST) a.info[i] -= (double)t;        // the episode's t rewards of -1, exact
-    }
-    rg.pos = pos; rg.vel = vel;
-    rg.sk = t | (type == BSX_LAST ? CP_RESET_BIT : 0);
-    o[0] = pos;                                                 // :62-64
-    o[1] = vel;
-    o[2] = (float)t / (float)a.max_steps;                       // both exact in f32; correctly rounded quotient
-    return type;
-  }
-};
-
 static int mountain_car_make(const bsx_mountain_car_t* cfg, const bsx_call_t* call, const int32_t* action, float* state, int32_t* steps, bsx_timestep_t out, double* info, mountain_car_env::args* a) {
   if (cfg == nullptr) return BSX_ENULL;
   int rc = bsx_check_call(call, action, out);
@@ -894,148 +204,3 @@ extern "C" int bsx_group_set_mountain_car(bsx_group_t* g, int32_t index, const b
   return small_obs_group_put<mountain_car_env>(g, BSX_FAM_MOUNTAIN_CAR, index, call, a);
 }
 
-// ------------------------------------------------------------------------------ mixed-family group
-__global__ void __launch_bounds__(BSX_BLOCK) small_obs_mixed_group_kernel(const uint8_t* __restrict__ table,
-                                                                          const int32_t* __restrict__ family,
-                                                                          const bsx_group_index gi) {
-  extern __shared__ __attribute__((aligned(16))) float s_obs[];
-  __shared__ unsigned int s_cnt[2];
-  const bsx_group_slot w = bsx_group_find(gi, (int)blockIdx.x);
-  const int seg = w.seg;
-  const uint32_t blk = w.block;
-  const uint8_t* slot = table + (size_t)seg * SMALL_MIXED_STRIDE;
-#define SMALL_MIXED_CASE(FAM, ENV) \
-  case FAM: small_obs_group_body<ENV>(*reinterpret_cast<const ENV::args*>(slot), blk, s_obs, s_cnt); break;
-  switch (family[seg]) {                           // uniform per workgroup
-    SMALL_MIXED_CASE(BSX_FAM_BANDIT, bandit_env)
-    SMALL_MIXED_CASE(BSX_FAM_MEMORY_CHAIN, memory_chain_env)
-    SMALL_MIXED_CASE(BSX_FAM_UMBRELLA_CHAIN, umbrella_chain_env)
-    SMALL_MIXED_CASE(BSX_FAM_DISCOUNTING_CHAIN, discounting_chain_env)
-    SMALL_MIXED_CASE(BSX_FAM_CARTPOLE, cartpole_env)
-    SMALL_MIXED_CASE(BSX_FAM_MOUNTAIN_CAR, mountain_car_env)
-    default: break;
-  }
-#undef SMALL_MIXED_CASE
-}
-
-static int small_obs_mixed_launch(bsx_group* g, int phase, hipStream_t st) {
-  if (phase == 1) return 0;
-  const dim3 grid((unsigned)g->total_blocks), block(BSX_BLOCK);
-  small_obs_mixed_group_kernel<<<grid, block, g->lds_bytes, st>>>((const uint8_t*)g->d_args, (const int32_t*)g->d_args2, g->index1());
-  return (int)hipGetLastError();
-}
-
-// ------------------------------------------------------------------------------ whole-sweep group, phase 0
-// BSX_FAM_SWEEP_MIXED: ONE launch advances every lane of a heterogeneous sweep — the lane-advance of
-// deep_sea / catch / mnist segments (whose observation stream follows as phase 1, pair_mixed.hip) and the
-// complete step of every small-observation segment.  All of this is latency-bound work that moves a
-// few percent of the sweep's bytes; as separate launches (advance, two small-family groups, counter
-// bump) it cost ~45 us of a ~185 us sweep step whether serialised or spread over HIP
-// streams (cross-queue waits cost ~10 us each; kernels sharing the machine with the store stream
-// stretch it: profiles/r02/ab_sweep_*.log, sweep_*_timeline*.txt).  The last workgroup to retire bumps
-// the call counter the segments share, so no other kernel has to.
-__device__ __forceinline__ void sweep_phase0_body(const uint8_t* __restrict__ table, const int32_t* __restrict__ tags,
-                                                  const bsx_group_index& gi, uint64_t* counter, uint32_t* ticket,
-                                                  const uint32_t block, const uint32_t n_blocks, float* s_obs,
-                                                  unsigned int* s_cnt, deep_sea_fam::shared& s_ds, catch_fam::shared& s_ca) {
-  const bsx_group_slot w = bsx_group_find(gi, (int)block);
-  const int tag = tags[w.seg];                       // uniform per workgroup
-  const uint32_t blk = w.block;
-  const uint8_t* slot = table + (size_t)w.seg * BSX_MIXED_ADV_STRIDE;
-#define SWEEP_SMALL_CASE(FAM, ENV) \
-  case FAM: small_obs_group_body<ENV>(*reinterpret_cast<const ENV::args*>(slot), blk, s_obs, s_cnt); break;
-  switch (tag) {
-    case BSX_FAM_DEEP_SEA: {
-      const deep_sea_fam::args& a = *reinterpret_cast<const deep_sea_fam::args*>(slot);
-      if (bsx_ctl_lean(a.ctl)) bsx_advance_body<deep_sea_fam, true>(a, blk, s_ds, s_cnt);
-      else bsx_advance_body<deep_sea_fam, false>(a, blk, s_ds, s_cnt);
-      break;
-    }
-    case BSX_FAM_CATCH: {
-      const catch_fam::args& a = *reinterpret_cast<const catch_fam::args*>(slot);
-      if (bsx_ctl_lean(a.ctl)) bsx_advance_body<catch_fam, true>(a, blk, s_ca, s_cnt);
-      else bsx_advance_body<catch_fam, false>(a, blk, s_ca, s_cnt);
-      break;
-    }
-    case BSX_FAM_MNIST: mnist_advance_body(*reinterpret_cast<const mnist_args*>(slot), blk, s_cnt); break;
-    SWEEP_SMALL_CASE(BSX_FAM_BANDIT, bandit_env)
-    SWEEP_SMALL_CASE(BSX_FAM_MEMORY_CHAIN, memory_chain_env)
-    SWEEP_SMALL_CASE(BSX_FAM_UMBRELLA_CHAIN, umbrella_chain_env)
-    SWEEP_SMALL_CASE(BSX_FAM_DISCOUNTING_CHAIN, discounting_chain_env)
-    SWEEP_SMALL_CASE(BSX_FAM_CARTPOLE, cartpole_env)
-    SWEEP_SMALL_CASE(BSX_FAM_MOUNTAIN_CAR, mountain_car_env)
-    default: break;
-  }
-#undef SWEEP_SMALL_CASE
-  // Every workgroup read the call counter when it started; the one that retires last moves it on.
-  // Two-level ticket (64 shards, one 128-byte line each, then one word): several thousand arrivals on ONE
-  // word would serialise at ~12 ns each (the lesson of the episode counters, bsx_device.h).
-  __syncthreads();
-  // (No fence: a workgroup's reads of the counter completed before its barrier, and a release fence here
-  // would write back this XCD's whole L2 once per workgroup — measured 165 us instead of 25.)
-  if (threadIdx.x == 0 && counter != nullptr) {
-    const uint32_t shard = block & 63u;
-    const uint32_t in_shard = (n_blocks - shard + 63u) >> 6;            // workgroups with this shard id
-    uint32_t* word = ticket + 32u * (shard + 1u);
-    if (atomicAdd(word, 1u) == in_shard - 1u) {
-      *word = 0u;
-      const uint32_t live_shards = n_blocks < 64u ? n_blocks : 64u;
-      if (atomicAdd(ticket, 1u) == live_shards - 1u) {
-        *ticket = 0u;
-        *counter += 1ull;
-      }
-    }
-  }
-}
-
-__global__ void __launch_bounds__(BSX_BLOCK) __attribute__((amdgpu_waves_per_eu(8))) sweep_phase0_kernel(
-    const uint8_t* __restrict__ table, const int32_t* __restrict__ tags, const bsx_group_index gi, uint64_t* counter,
-    uint32_t* ticket, uint64_t* trace) {
-  extern __shared__ __attribute__((aligned(16))) float s_obs[];
-  __shared__ unsigned int s_cnt[2];
-  __shared__ deep_sea_fam::shared s_ds;
-  __shared__ catch_fam::shared s_ca;
-  if (trace != nullptr && threadIdx.x == 0) trace[3 * blockIdx.x] = wall_clock64();        // bsx_group_trace
-  sweep_phase0_body(table, tags, gi, counter, ticket, blockIdx.x, gridDim.x, s_obs, s_cnt, s_ds, s_ca);
-  if (trace != nullptr && threadIdx.x == 0) {
-    trace[3 * blockIdx.x + 1] = wall_clock64();
-    trace[3 * blockIdx.x + 2] = (uint64_t)tags[bsx_group_find(gi, (int)blockIdx.x).seg];
-  }
-}
-
-int bsx_sweep_launch_phase0(bsx_group* g, hipStream_t st) {
-  sweep_phase0_kernel<<<dim3((unsigned)g->total_blocks), dim3(BSX_BLOCK), g->lds_bytes, st>>>(
-      (const uint8_t*)g->d_args, g->d_tags, g->index1(), g->shared_counter, g->d_ticket, g->trace);
-  return (int)hipGetLastError();
-}
-
-// Software-pipelined sweep step: ONE launch = the observation store stream of sweep step s (group
-// `streams_of`) beside phase 0 — every lane's advance — of step s+1 (group `advances_of`).  The two groups
-// hold the same segments with the two-kernel families' state columns swapped (bsx_call_t.state_alt) and
-// their own TimeStep buffers, so nothing in the launch depends on anything else in it: the stream reads the
-// column phase 0 of step s wrote in the previous launch, phase 0 of step s+1 reads it too and writes the
-// other one.  The latency-bound phase 0 (~26 us alone) hides beside the ~140 us store stream.
-__global__ void __launch_bounds__(BSX_BLOCK) __attribute__((amdgpu_waves_per_eu(8))) sweep_pipelined_kernel(
-    const uint8_t* __restrict__ adv_table, const int32_t* __restrict__ adv_tags, const bsx_group_index adv_gi,
-    uint64_t* counter, uint32_t* ticket, const uint32_t adv_blocks, const uint32_t place,
-    const uint8_t* __restrict__ str_table, const int32_t* __restrict__ str_tags, const bsx_group_index str_gi) {
-  extern __shared__ __attribute__((aligned(16))) float s_obs[];
-  __shared__ unsigned int s_cnt[2];
-  __shared__ deep_sea_fam::shared s_ds;
-  __shared__ catch_fam::shared s_ca;
-  __shared__ float s_lut[256];
-  const bsx_pipe_role r = bsx_pipe_role_of(blockIdx.x, gridDim.x, adv_blocks, place);   // uniform per workgroup
-  if (r.adv) sweep_phase0_body(adv_table, adv_tags, adv_gi, counter, ticket, r.index, adv_blocks, s_obs, s_cnt, s_ds, s_ca);
-  else pair_mixed_stream_body(str_table, str_tags, str_gi, r.index, s_lut);
-}
-
-int bsx_sweep_launch_pipelined(bsx_group* streams_of, bsx_group* advances_of, hipStream_t st) {
-  const uint64_t blocks = (uint64_t)advances_of->total_blocks + (uint64_t)streams_of->total_blocks2;
-  if (blocks == 0 || blocks > 0x7FFFFFFFull) return BSX_EINVAL;
-  static const int place = bsx_env_int("BSX_PIPELINED_PLACE", 0);       // bsx_pipe_role_of: first (measured best)
-  sweep_pipelined_kernel<<<dim3((unsigned)blocks), dim3(BSX_BLOCK), advances_of->lds_bytes, st>>>(
-      (const uint8_t*)advances_of->d_args, advances_of->d_tags, advances_of->index1(), advances_of->shared_counter,
-      advances_of->d_ticket, (uint32_t)advances_of->total_blocks, (uint32_t)place, (const uint8_t*)streams_of->d_args2, streams_of->d_tags,
-      streams_of->index2());
-  return (int)hipGetLastError();
-}

@@ -1,0 +1,152 @@
+// sweep_mixed.hip — the mixed-family launches of a heterogeneous sweep (BASELINE config 5):
+//   BSX_FAM_SMALL_MIXED   every small-observation family in one launch
+//   BSX_FAM_SWEEP_MIXED   phase 0: every lane of EVERY family advanced by one launch (the lane advance of
+//                         deep_sea / catch / mnist + the whole step of the small-observation families), and the
+//                         software-pipelined form: that phase beside the previous step's observation store stream.
+#include "small_obs.h"
+
+// ------------------------------------------------------------------------------ mixed-family group
+__global__ void __launch_bounds__(BSX_BLOCK) small_obs_mixed_group_kernel(const uint8_t* __restrict__ table,
+                                                                          const int32_t* __restrict__ family,
+                                                                          const bsx_group_index gi) {
+  extern __shared__ __attribute__((aligned(16))) float s_obs[];
+  __shared__ unsigned int s_cnt[2];
+  const bsx_group_slot w = bsx_group_find(gi, (int)blockIdx.x);
+  const int seg = w.seg;
+  const uint32_t blk = w.block;
+  const uint8_t* slot = table + (size_t)seg * SMALL_MIXED_STRIDE;
+#define SMALL_MIXED_CASE(FAM, ENV) \
+  case FAM: small_obs_group_body<ENV>(*reinterpret_cast<const ENV::args*>(slot), blk, s_obs, s_cnt); break;
+  switch (family[seg]) {                           // uniform per workgroup
+    SMALL_MIXED_CASE(BSX_FAM_BANDIT, bandit_env)
+    SMALL_MIXED_CASE(BSX_FAM_MEMORY_CHAIN, memory_chain_env)
+    SMALL_MIXED_CASE(BSX_FAM_UMBRELLA_CHAIN, umbrella_chain_env)
+    SMALL_MIXED_CASE(BSX_FAM_DISCOUNTING_CHAIN, discounting_chain_env)
+    SMALL_MIXED_CASE(BSX_FAM_CARTPOLE, cartpole_env)
+    SMALL_MIXED_CASE(BSX_FAM_MOUNTAIN_CAR, mountain_car_env)
+    default: break;
+  }
+#undef SMALL_MIXED_CASE
+}
+
+int bsx_small_mixed_launch(bsx_group* g, int phase, hipStream_t st) {
+  if (phase == 1) return 0;
+  const dim3 grid((unsigned)g->total_blocks), block(BSX_BLOCK);
+  small_obs_mixed_group_kernel<<<grid, block, g->lds_bytes, st>>>((const uint8_t*)g->d_args, (const int32_t*)g->d_args2, g->index1());
+  return (int)hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------ whole-sweep group, phase 0
+// BSX_FAM_SWEEP_MIXED: ONE launch advances every lane of a heterogeneous sweep — the lane-advance of
+// deep_sea / catch / mnist segments (whose observation stream follows as phase 1, pair_mixed.hip) and the
+// complete step of every small-observation segment.  All of this is latency-bound work that moves a
+// few percent of the sweep's bytes; as separate launches (advance, two small-family groups, counter
+// bump) it cost ~45 us of a ~185 us sweep step whether serialised or spread over HIP
+// streams (cross-queue waits cost ~10 us each; kernels sharing the machine with the store stream
+// stretch it: profiles/r02/ab_sweep_*.log, sweep_*_timeline*.txt).  The last workgroup to retire bumps
+// the call counter the segments share, so no other kernel has to.
+__device__ __forceinline__ void sweep_phase0_body(const uint8_t* __restrict__ table, const int32_t* __restrict__ tags,
+                                                  const bsx_group_index& gi, uint64_t* counter, uint32_t* ticket,
+                                                  const uint32_t block, const uint32_t n_blocks, float* s_obs,
+                                                  unsigned int* s_cnt, deep_sea_fam::shared& s_ds, catch_fam::shared& s_ca) {
+  const bsx_group_slot w = bsx_group_find(gi, (int)block);
+  const int tag = tags[w.seg];                       // uniform per workgroup
+  const uint32_t blk = w.block;
+  const uint8_t* slot = table + (size_t)w.seg * BSX_MIXED_ADV_STRIDE;
+#define SWEEP_SMALL_CASE(FAM, ENV) \
+  case FAM: small_obs_group_body<ENV>(*reinterpret_cast<const ENV::args*>(slot), blk, s_obs, s_cnt); break;
+  switch (tag) {
+    case BSX_FAM_DEEP_SEA: {
+      const deep_sea_fam::args& a = *reinterpret_cast<const deep_sea_fam::args*>(slot);
+      if (bsx_ctl_lean(a.ctl)) bsx_advance_body<deep_sea_fam, true>(a, blk, s_ds, s_cnt);
+      else bsx_advance_body<deep_sea_fam, false>(a, blk, s_ds, s_cnt);
+      break;
+    }
+    case BSX_FAM_CATCH: {
+      const catch_fam::args& a = *reinterpret_cast<const catch_fam::args*>(slot);
+      if (bsx_ctl_lean(a.ctl)) bsx_advance_body<catch_fam, true>(a, blk, s_ca, s_cnt);
+      else bsx_advance_body<catch_fam, false>(a, blk, s_ca, s_cnt);
+      break;
+    }
+    case BSX_FAM_MNIST: mnist_advance_body(*reinterpret_cast<const mnist_args*>(slot), blk, s_cnt); break;
+    SWEEP_SMALL_CASE(BSX_FAM_BANDIT, bandit_env)
+    SWEEP_SMALL_CASE(BSX_FAM_MEMORY_CHAIN, memory_chain_env)
+    SWEEP_SMALL_CASE(BSX_FAM_UMBRELLA_CHAIN, umbrella_chain_env)
+    SWEEP_SMALL_CASE(BSX_FAM_DISCOUNTING_CHAIN, discounting_chain_env)
+    SWEEP_SMALL_CASE(BSX_FAM_CARTPOLE, cartpole_env)
+    SWEEP_SMALL_CASE(BSX_FAM_MOUNTAIN_CAR, mountain_car_env)
+    default: break;
+  }
+#undef SWEEP_SMALL_CASE
+  // Every workgroup read the call counter when it started; the one that retires last moves it on.
+  // Two-level ticket (64 shards, one 128-byte line each, then one word): several thousand arrivals on ONE
+  // word would serialise at ~12 ns each (the lesson of the episode counters, bsx_device.h).
+  __syncthreads();
+  // (No fence: a workgroup's reads of the counter completed before its barrier, and a release fence here
+  // would write back this XCD's whole L2 once per workgroup — measured 165 us instead of 25.)
+  if (threadIdx.x == 0 && counter != nullptr) {
+    const uint32_t shard = block & 63u;
+    const uint32_t in_shard = (n_blocks - shard + 63u) >> 6;            // workgroups with this shard id
+    uint32_t* word = ticket + 32u * (shard + 1u);
+    if (atomicAdd(word, 1u) == in_shard - 1u) {
+      *word = 0u;
+      const uint32_t live_shards = n_blocks < 64u ? n_blocks : 64u;
+      if (atomicAdd(ticket, 1u) == live_shards - 1u) {
+        *ticket = 0u;
+        *counter += 1ull;
+      }
+    }
+  }
+}
+
+__global__ void __launch_bounds__(BSX_BLOCK) __attribute__((amdgpu_waves_per_eu(8))) sweep_phase0_kernel(
+    const uint8_t* __restrict__ table, const int32_t* __restrict__ tags, const bsx_group_index gi, uint64_t* counter,
+    uint32_t* ticket, uint64_t* trace) {
+  extern __shared__ __attribute__((aligned(16))) float s_obs[];
+  __shared__ unsigned int s_cnt[2];
+  __shared__ deep_sea_fam::shared s_ds;
+  __shared__ catch_fam::shared s_ca;
+  if (trace != nullptr && threadIdx.x == 0) trace[3 * blockIdx.x] = wall_clock64();        // bsx_group_trace
+  sweep_phase0_body(table, tags, gi, counter, ticket, blockIdx.x, gridDim.x, s_obs, s_cnt, s_ds, s_ca);
+  if (trace != nullptr && threadIdx.x == 0) {
+    trace[3 * blockIdx.x + 1] = wall_clock64();
+    trace[3 * blockIdx.x + 2] = (uint64_t)tags[bsx_group_find(gi, (int)blockIdx.x).seg];
+  }
+}
+
+int bsx_sweep_launch_phase0(bsx_group* g, hipStream_t st) {
+  sweep_phase0_kernel<<<dim3((unsigned)g->total_blocks), dim3(BSX_BLOCK), g->lds_bytes, st>>>(
+      (const uint8_t*)g->d_args, g->d_tags, g->index1(), g->shared_counter, g->d_ticket, g->trace);
+  return (int)hipGetLastError();
+}
+
+// Software-pipelined sweep step: ONE launch = the observation store stream of sweep step s (group
+// `streams_of`) beside phase 0 — every lane's advance — of step s+1 (group `advances_of`).  The two groups
+// hold the same segments with the two-kernel families' state columns swapped (bsx_call_t.state_alt) and
+// their own TimeStep buffers, so nothing in the launch depends on anything else in it: the stream reads the
+// column phase 0 of step s wrote in the previous launch, phase 0 of step s+1 reads it too and writes the
+// other one.  The latency-bound phase 0 (~26 us alone) hides beside the ~140 us store stream.
+__global__ void __launch_bounds__(BSX_BLOCK) __attribute__((amdgpu_waves_per_eu(8))) sweep_pipelined_kernel(
+    const uint8_t* __restrict__ adv_table, const int32_t* __restrict__ adv_tags, const bsx_group_index adv_gi,
+    uint64_t* counter, uint32_t* ticket, const uint32_t adv_blocks, const uint32_t place,
+    const uint8_t* __restrict__ str_table, const int32_t* __restrict__ str_tags, const bsx_group_index str_gi) {
+  extern __shared__ __attribute__((aligned(16))) float s_obs[];
+  __shared__ unsigned int s_cnt[2];
+  __shared__ deep_sea_fam::shared s_ds;
+  __shared__ catch_fam::shared s_ca;
+  __shared__ float s_lut[256];
+  const bsx_pipe_role r = bsx_pipe_role_of(blockIdx.x, gridDim.x, adv_blocks, place);   // uniform per workgroup
+  if (r.adv) sweep_phase0_body(adv_table, adv_tags, adv_gi, counter, ticket, r.index, adv_blocks, s_obs, s_cnt, s_ds, s_ca);
+  else pair_mixed_stream_body(str_table, str_tags, str_gi, r.index, s_lut);
+}
+
+int bsx_sweep_launch_pipelined(bsx_group* streams_of, bsx_group* advances_of, hipStream_t st) {
+  const uint64_t blocks = (uint64_t)advances_of->total_blocks + (uint64_t)streams_of->total_blocks2;
+  if (blocks == 0 || blocks > 0x7FFFFFFFull) return BSX_EINVAL;
+  static const int place = bsx_env_int("BSX_PIPELINED_PLACE", 0);       // bsx_pipe_role_of: first (measured best)
+  sweep_pipelined_kernel<<<dim3((unsigned)blocks), dim3(BSX_BLOCK), advances_of->lds_bytes, st>>>(
+      (const uint8_t*)advances_of->d_args, advances_of->d_tags, advances_of->index1(), advances_of->shared_counter,
+      advances_of->d_ticket, (uint32_t)advances_of->total_blocks, (uint32_t)place, (const uint8_t*)streams_of->d_args2, streams_of->d_tags,
+      streams_of->index2());
+  return (int)hipGetLastError();
+}

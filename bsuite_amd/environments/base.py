@@ -193,13 +193,17 @@ class Environment(dm_env.EnvironmentBase):
     """Records this environment as segment `index` of a grouped launch (bsx_group_set_<family>):
     static arguments — `action` is read in place every group step, outputs go to buffer 0 (or to `out`, a
     dict of reward / discount / step_type / observation tensors), the call index comes from the (shared)
-    device step counter.  `state_alt` (two-kernel families, pipelined sweeps): the lane advance reads that
+    device step counter.  `action` is int32 [B], or an action RING [R, B] with R a power of two: group step s
+    then reads row s mod R (bsx_call_t.action_ring) — pre-generated random actions that change every step.  `state_alt` (two-kernel families, pipelined sweeps): the lane advance reads that
     column and writes the environment's own; with `swap_state` the roles are exchanged."""
     self._ensure_allocated()
+    ring = int(action.shape[0]) if (torch.is_tensor(action) and action.dim() == 2) else 0
     if (not torch.is_tensor(action) or action.dtype != torch.int32 or action.device != self._device
-        or tuple(action.shape) != (self._batch,) or not action.is_contiguous()):
+        or tuple(action.shape) not in ((self._batch,), (ring, self._batch)) or not action.is_contiguous()
+        or (action.dim() == 2 and (ring < 1 or ring & (ring - 1)))):
       raise ValueError(f'grouped launches read the action tensor in place every step: need a contiguous int32 '
-                       f'tensor of shape ({self._batch},) on {self._device}')
+                       f'tensor of shape ({self._batch},) — or an action ring (R, {self._batch}) with R a power '
+                       f'of two — on {self._device}')
     if not self._device_step_counter:
       raise ValueError('grouped launches need device_step_counter / shared_step_counter')
     if self._delta:
@@ -210,6 +214,7 @@ class Environment(dm_env.EnvironmentBase):
     call.wrap.kind, call.wrap.param, call.wrap.seed, call.wrap.param2 = kind, param, wseed, param2
     self._wrap_applied = self._wrap
     call.stream.step_index = 0
+    call.action_ring = ring
     self._buf = 1 % self._num_buffers
     ptrs = self._out_ptrs[0] if out is None else _native.TimeStepPtrs(
         out['reward'].data_ptr(), out['discount'].data_ptr(), out['step_type'].data_ptr(), out['observation'].data_ptr())
@@ -224,6 +229,7 @@ class Environment(dm_env.EnvironmentBase):
           group, index, *self._native_args(call, action.data_ptr(), ptrs))
     finally:
       call.state_alt = None
+      call.action_ring = 0
       if state_alt is not None:
         self._state['state'] = own
 

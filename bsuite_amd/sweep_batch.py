@@ -128,16 +128,20 @@ class SweepBatch:
     return self._arena[begin:begin + n].view(shape)
 
   # ---------------------------------------------------------------------------------------
-  def random_actions(self, seed: int = 0) -> List[torch.Tensor]:
+  def random_actions(self, seed: int = 0, ring: int = 0) -> List[torch.Tensor]:
     """One int32 action tensor per local segment (uniform over each action_spec).  The generator is
     re-seeded per segment from (seed, global segment index), so a segment gets the same actions
-    whichever rank it was packed onto."""
+    whichever rank it was packed onto.  ring = R (a power of two): tensors [R, lanes] — an action ring the
+    grouped launches walk on the device, row (sweep step mod R) per step (`prepare_groups`): the batched,
+    pre-generated form of bsuite/baselines/random/agent.py:35-37 (actions [T,B])."""
+    if ring and (ring < 1 or ring & (ring - 1)):
+      raise ValueError('an action ring needs a power of two of rows')
     g = torch.Generator(device=self.device)
     out = []
     for k, (env, (_, _, lanes)) in zip(self.local, zip(self.envs, self.segments)):
       g.manual_seed(int(seed) * 1000003 + k)
-      out.append(torch.randint(env.action_spec().num_values, (lanes,), generator=g, device=self.device,
-                               dtype=torch.int32))
+      out.append(torch.randint(env.action_spec().num_values, (ring, lanes) if ring else (lanes,), generator=g,
+                               device=self.device, dtype=torch.int32))
     return out
 
   def _bump(self, grouped: bool = False):

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define BSX_ABI_VERSION 9
+#define BSX_ABI_VERSION 10
 
 #define BSX_FIRST 0
 #define BSX_MID 1
@@ -179,6 +179,14 @@ typedef struct {
                                  groups with the columns swapped step alternately, see
                                  bsx_group_step_pipelined.
                                Ignored by step()/reset() calls and by the other families.          */
+  int32_t action_ring;      /* 0 or 1: `action` is [B].  R = 2^k > 1 (ABI v10): `action` is a ring [R,B] of
+                               pre-generated actions and the call whose index is s (stream.step_index +
+                               *stream.step_base) reads row s mod R — the batched form of an agent that acts
+                               without looking (bsuite/baselines/random/agent.py:35-37) for callers whose
+                               arguments are static: the segments of a group (every group step then feeds
+                               fresh actions with no host work) and captured hipGraphs.  Not a power of two:
+                               BSX_EINVAL; with n_steps > 1 or obs_paint: BSX_EMODE.                 */
+  int32_t _pad2;
 } bsx_call_t;
 
 /* ---- deep_sea : bsuite/environments/deep_sea.py:51-155 ------------------------------------ */

@@ -134,10 +134,13 @@ class _RowCollector:
 
 
 def run_case(bs, name, family, kwargs, lanes, T, seed=42, step0=0, wrap=None, policies=None,
-             reset_at=(), case_seed=0, log=None, rng='replay'):
+             reset_at=(), case_seed=0, log=None, rng='replay', bsuite_id=None, write=True):
   """rng='replay': the reference's RandomState is swapped for a replay of the engine's stream, keyed
   by (seed, lane).  rng='mt19937': NOTHING is swapped — each "lane" value is the integer seed the
-  unmodified reference constructor is given (np.random.RandomState(seed) inside it)."""
+  unmodified reference constructor is given (np.random.RandomState(seed) inside it).
+  bsuite_id: build every lane's environment with the reference's own `bsuite.load_from_id` (registry, sweep
+  settings and experiment loader included) instead of the family constructor.  write=False: return
+  (meta, arrays) without touching tests/golden (tests/test_gpu_vs_reference_live.py)."""
   lanes = [int(x) for x in lanes]
   L = len(lanes)
   policies = list(policies or []) + ['random'] * L
@@ -150,7 +153,7 @@ def run_case(bs, name, family, kwargs, lanes, T, seed=42, step0=0, wrap=None, po
       env = _make_env(bs, family, dict(kwargs) if family == 'bandit' else dict(kwargs, seed=lane), wrap, wrap_seed=lane)
       rngs.append([])
     else:
-      env = _make_env(bs, family, kwargs, wrap)
+      env = bs.load_from_id(bsuite_id) if bsuite_id is not None else _make_env(bs, family, kwargs, wrap)
       rngs.append(replay.attach_replay(env, seed, lane))
     if log is not None:   # the UNMODIFIED reference Logging wrapper (utils/wrappers.py:34-137)
       from bsuite.utils import wrappers as ref_wrappers  # pylint: disable=import-outside-toplevel
@@ -195,6 +198,8 @@ def run_case(bs, name, family, kwargs, lanes, T, seed=42, step0=0, wrap=None, po
               wrap=list(wrap) if wrap else None, info_keys=info_keys,
               reset_at=[int(x) for x in reset_at], num_actions=int(num_actions),
               obs_shape=list(obs_shape), policies=policies[:L], rng=rng)
+  if bsuite_id is not None:
+    meta['bsuite_id'] = bsuite_id
   out = dict(meta=np.array(json.dumps(meta)), lanes=np.array(lanes, np.uint64), actions=actions,
              step_type=step_type, reward=reward, discount=discount, obs=obs, info=info)
   if phys is not None:
@@ -211,11 +216,14 @@ def run_case(bs, name, family, kwargs, lanes, T, seed=42, step0=0, wrap=None, po
     meta['log'] = log
     meta['log_columns'] = cols
     out['meta'] = np.array(json.dumps(meta))
+  if not write:
+    return meta, {k: v for k, v in out.items() if k != 'meta'}
   os.makedirs(OUT_DIR, exist_ok=True)
   path = os.path.join(OUT_DIR, name + '.npz')
   np.savez_compressed(path, **out)
   n_last = int((step_type == 2).sum())
   print(f'{name:42s} T={T:5d} L={L} LAST={n_last:4d} {os.path.getsize(path)/1024:7.1f} KiB')
+  return meta, {k: v for k, v in out.items() if k != 'meta'}
 
 
 LANES = [0, 1, 2, 3, 63, 64, 1000003, BIG_LANE]

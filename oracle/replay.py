@@ -1,8 +1,11 @@
 """ORACLE (test infrastructure): drive the UNMODIFIED reference environments with a replay of the
 engine's draw stream.
 
-Only usable where /root/reference exists (this build container) — it is how tests/golden/*.npz are
-produced (oracle/make_golden.py).  Nothing under tests -m gpu / bench.py / smoke() imports it.
+Where /root/reference exists (the build container) the reference is imported from there — that is how
+tests/golden/*.npz are produced (oracle/make_golden.py).  On the GPU box it is imported from the
+byte-code tree oracle/stage_reference.py compiled from those sources at build time (oracle/_ref,
+git-ignored): tests/test_gpu_vs_reference_live.py and bench.py's cpu_baseline leg use it there.
+The product (bsuite_amd/) never imports this module.
 
 `ReplayRNG` quacks like the np.random.RandomState members the reference calls
 (deep_sea.py:126,130; catch.py:71; memory_chain.py:94-95; umbrella_chain.py:65,83,89-90;
@@ -20,16 +23,37 @@ REFERENCE_ROOT = os.environ.get('BSX_REFERENCE_ROOT', '/root/reference')
 from oracle import stream as S  # noqa: E402
 
 
-def reference_available():
+def reference_source_available():
   return os.path.isdir(os.path.join(REFERENCE_ROOT, 'bsuite'))
 
 
+def reference_available():
+  """The reference can be imported: from its sources (build container) or from the staged byte-code."""
+  from oracle import stage_reference  # pylint: disable=import-outside-toplevel
+  return reference_source_available() or stage_reference.staged()
+
+
+def reference_origin():
+  """'source' (/root/reference), 'staged' (oracle/_ref byte-code) or None."""
+  from oracle import stage_reference  # pylint: disable=import-outside-toplevel
+  if os.environ.get('BSX_REFERENCE_STAGED') and stage_reference.staged():
+    return 'staged'                      # test hook: exercise the staged tree where the sources exist too
+  if reference_source_available():
+    return 'source'
+  return 'staged' if stage_reference.staged() else None
+
+
 def import_reference():
-  """Import the real `bsuite` package from /root/reference with the shim third-party modules."""
-  if not reference_available():
-    raise RuntimeError('reference tree not present (only exists in the build container)')
+  """Import the real `bsuite` package (sources, else the staged byte-code) with the shim third-party modules."""
+  from oracle import stage_reference  # pylint: disable=import-outside-toplevel
+  origin = reference_origin()
+  if origin is None:
+    raise RuntimeError('reference not present: neither /root/reference nor oracle/_ref (python -m oracle.stage_reference '
+                       'in the build container stages it)')
+  root = REFERENCE_ROOT if origin == 'source' else stage_reference.STAGE_DIR
   shims = os.path.join(_HERE, 'ref_shims')
-  for p in (REFERENCE_ROOT, shims):
+  sys.dont_write_bytecode = True         # never write __pycache__ into the read-only reference tree
+  for p in (root, shims):
     if p not in sys.path:
       sys.path.insert(0, p)
   import bsuite  # pylint: disable=import-outside-toplevel

@@ -100,10 +100,16 @@ def cartpole_cfg(family, kwargs):
 
 
 class PhysicsChecker:
-  """Compares engine TimeSteps with reference ones call by call.  A lane may disagree on step_type,
-  reward or a sign-flag observation ONLY on a call where `physics_ties` holds for it — a genuine
-  threshold tie inside the tolerance; everything else must be within 1e-6*max(1,|b|).  Lanes that
-  ever tied are `tainted`: their bsuite_info accumulators legitimately differ from then on."""
+  """Compares engine TimeSteps with reference ones call by call.  The CONTINUOUS observation components
+  (x, x_dot, sin, cos, theta_dot, time | position, velocity, time) must be within 1e-6*max(1,|b|) on EVERY
+  lane and call — a threshold tie waives nothing there.  On a call where `physics_ties` holds for a lane —
+  a deciding quantity within the tolerance of its threshold in the reference's f64 state — that lane may
+  disagree on what the threshold decides, and only that: step_type (and the discount that follows from
+  it), the reward, and swing-up's two sign-flag observation elements (obs[6], obs[7]:
+  cartpole_swingup.py:147-149).  Lanes that ever tied are `tainted`: their bsuite_info accumulators
+  legitimately differ from then on."""
+
+  SIGN_FLAGS = {'cartpole_swingup': (6, 7)}
 
   def __init__(self, family, kwargs, batch):
     self.family, self.cfg = family, cartpole_cfg(family, kwargs)
@@ -117,29 +123,36 @@ class PhysicsChecker:
     post-call state (x, theta, theta_dot | position)."""
     gst, gr, gd, go = got
     st, r, d, o = want
+    B = len(st)
     tie = physics_ties(self.family, self.cfg, **state)
     ok_obs, err_obs = within_tol(go, o)
+    ok_obs, err_obs = ok_obs.reshape(B, -1), err_obs.reshape(B, -1)
+    flag = np.zeros(ok_obs.shape[1], bool)
+    flag[list(self.SIGN_FLAGS.get(self.family, ()))] = True
+    # never waivable: the continuous components
+    cont_ok = ok_obs[:, ~flag].all(axis=1)
+    assert cont_ok.all(), (f'{msg}: lanes {np.flatnonzero(~cont_ok)[:5].tolist()}: continuous observation components beyond '
+                           f'1e-6*max(1,|b|): max err {err_obs[:, ~flag].max():.3e} (a threshold tie does not waive these)')
     live = st != 0
     ok_r, err_r = within_tol(gr, r)
     ok_r |= ~live                              # FIRST: reward is None in the reference
     ok_d = (gd == np.where(live, d, 1.0).astype(np.float32)) | (gst != st)
-    lane_ok = ok_obs.reshape(len(st), -1).all(axis=1) & ok_r & (gst == st) & ok_d
-    bad = ~lane_ok & ~tie
-    assert not bad.any(), (f'{msg}: lanes {np.flatnonzero(bad)[:5].tolist()} differ beyond 1e-6 without a threshold tie; '
-                           f'step_type {gst[bad][:5]} vs {st[bad][:5]}, reward {gr[bad][:5]} vs {r[bad][:5]}, '
-                           f'max obs err {err_obs.reshape(len(st), -1)[bad].max():.3e}')
-    self.ties += int((~lane_ok).sum())
-    self.tainted |= ~lane_ok
-    good = lane_ok
+    decided_ok = ok_obs[:, flag].all(axis=1) & ok_r & (gst == st) & ok_d
+    bad = ~decided_ok & ~tie
+    assert not bad.any(), (f'{msg}: lanes {np.flatnonzero(bad)[:5].tolist()} differ in step_type / reward / sign flag without a '
+                           f'threshold tie; step_type {gst[bad][:5]} vs {st[bad][:5]}, reward {gr[bad][:5]} vs {r[bad][:5]}')
+    self.ties += int((~decided_ok).sum())
+    self.tainted |= ~decided_ok
+    self.max_err['observation'] = max(self.max_err['observation'], float(err_obs[:, ~flag].max()))
+    good = decided_ok & live
     if good.any():
-      self.max_err['observation'] = max(self.max_err['observation'], float(err_obs.reshape(len(st), -1)[good].max()))
-      if (good & live).any():
-        self.max_err['reward'] = max(self.max_err['reward'], float(err_r[good & live].max()))
+      self.max_err['reward'] = max(self.max_err['reward'], float(err_r[good].max()))
     self.calls += 1
 
-  def assert_few_ties(self, max_fraction=2e-3):
+  def assert_few_ties(self, max_fraction=1e-5):
+    """Measured tie rate: 0 in 6.5e6 lane-steps per family (profiles/r02/physics_error.json)."""
     n = self.calls * len(self.tainted)
-    assert self.ties <= max(2, int(max_fraction * n)), f'{self.ties} threshold ties in {n} lane-steps'
+    assert self.ties <= max(1, int(max_fraction * n)), f'{self.ties} threshold ties in {n} lane-steps'
 
 
 def oracle_physics_state(orc, family):
@@ -159,3 +172,86 @@ def teacher_force(raw_env, orc, family):
     k = np.rint(orc.s['state'][:, 4] / orc.cfg.timescale).astype(np.int32)
   raw_env._state['state'].copy_(torch.from_numpy(np.ascontiguousarray(st32)).cuda())
   raw_env._state['steps'].copy_(torch.from_numpy(k | (orc.reset_next.astype(np.int32) << 30)).cuda())
+
+
+def _force_physics_state(env, fam, phys_prev, idx):
+  r = raw(env)
+  if fam == 'mountain_car':
+    st = np.stack([phys_prev[idx, 0], phys_prev[idx, 1]]).astype(np.float32)
+  else:
+    st = phys_prev[idx, :4].T.astype(np.float32)
+  r._state['state'].copy_(torch.from_numpy(np.ascontiguousarray(st)).to(r.device))
+
+
+def check_against_case(name, meta, g):
+  """Steps the engine through one recorded case of the reference (a tests/golden fixture, or one recorded live by
+  tests/test_gpu_vs_reference_live.py): `meta`, `g` as oracle/make_golden.run_case writes them.  Integer / grid
+  families bit-exact; physics families teacher-forced per step at 1e-6*max(1,|b|)."""
+  from tests import golden_util as gu
+  fam = meta['family']
+  phys = fam in gu.PHYSICS
+  wrap = tuple(meta['wrap']) if meta['wrap'] else None
+  T = g['actions'].shape[0]
+  kwargs = dict(meta['kwargs'])
+  if fam == 'mnist':
+    kwargs['images'], kwargs['labels'] = gu.mnist_dataset()
+  for (i0, lane0, n) in gu.contiguous_runs(g['lanes']):
+    idx = slice(i0, i0 + n)
+    if meta.get('bsuite_id'):     # recorded from the reference's own load_from_id: ours builds the engine side
+      import bsuite_amd
+      import warnings
+      ekw = dict(images=kwargs['images'], labels=kwargs['labels']) if fam == 'mnist' else {}
+      if meta.get('seed_is_ours', True):
+        ekw['seed'] = meta['seed']
+      with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        env = bsuite_amd.load_from_id(meta['bsuite_id'], batch=n, lane_offset=lane0, num_buffers=1, **ekw)
+    else:
+      env = make_env(fam, kwargs, batch=n, lane_offset=lane0, seed=meta['seed'], wrap=wrap)
+    raw(env)._step_index = meta['step0']
+    logged = None
+    if meta.get('log'):
+      from bsuite_amd.utils import wrappers
+      env = logged = wrappers.Logging(env, None, log_by_step=meta['log'] == 'by_step',
+                                      log_every=meta['log'] == 'every', max_rows=g['log_rows'].shape[1] + 3)
+    for t in range(T):
+      if phys and t > 0:
+        _force_physics_state(env, fam, g['phys'][t - 1], idx)
+      if t in meta['reset_at']:
+        ts = env.reset()
+      else:
+        ts = env.step(torch.from_numpy(g['actions'][t, idx]).to('cuda'))
+      st, r, d, o = to_np(ts)
+      gst, gr, gd, go = g['step_type'][t, idx], g['reward'][t, idx], g['discount'][t, idx], g['obs'][t, idx]
+      np.testing.assert_array_equal(st, gst, err_msg=f'{name} step_type t={t}')
+      first = gst == 0
+      assert (r[first] == 0).all() and (d[first] == 1).all()
+      np.testing.assert_array_equal(d[~first], gd[~first].astype(np.float32))
+      if phys:      # |a-b| <= 1e-6*max(1,|b|), the north_star bound (not rtol+atol = 2e-6)
+        assert_within_tol(o, go, err_msg=f'{name} obs t={t}')
+        assert_within_tol(r[~first], gr[~first], err_msg=f'{name} reward t={t}')
+      else:
+        np.testing.assert_array_equal(f32_bits(r[~first]), f32_bits(gr[~first].astype(np.float32)),
+                                      err_msg=f'{name} reward t={t}')
+        np.testing.assert_array_equal(f32_bits(o), f32_bits(go), err_msg=f'{name} obs t={t}')
+      info = env.bsuite_info()
+      for j, k in enumerate(meta['info_keys']):
+        got = info[k].cpu().numpy()
+        if phys:
+          np.testing.assert_allclose(got, g['info'][t, idx, j], rtol=1e-9, atol=1e-9, err_msg=f'{k} t={t}')
+        else:
+          np.testing.assert_array_equal(got, g['info'][t, idx, j], err_msg=f'{name} {k} t={t}')
+    if logged is not None:   # rows the unmodified reference Logging wrapper wrote, per lane
+      assert list(raw(env).logging_columns()[:5]) == meta['log_columns'][:5]
+      cols = [meta['log_columns'].index(c) for c in raw(env).logging_columns() if not c.startswith('_')]
+      keep = [j for j, c in enumerate(raw(env).logging_columns()) if not c.startswith('_')]
+      n_rows = logged.num_rows().cpu().numpy()
+      np.testing.assert_array_equal(n_rows, g['log_n_rows'][idx], err_msg=f'{name} n_rows')
+      rows = logged._lg['rows'].cpu().numpy()
+      for l in range(n):
+        want = g['log_rows'][i0 + l, :n_rows[l]][:, cols]
+        got = rows[l, :n_rows[l]][:, keep]
+        if phys:
+          np.testing.assert_allclose(got, want, rtol=1e-9, atol=1e-9, err_msg=f'{name} lane {l}')
+        else:
+          np.testing.assert_array_equal(got, want, err_msg=f'{name} lane {l}')

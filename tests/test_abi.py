@@ -37,12 +37,13 @@ def test_struct_layouts_match_header():
 #include <stddef.h>
 #include "bsuite_amd.h"
 int main(void) {
-  printf("%zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu\n", sizeof(bsx_stream_t), sizeof(bsx_reward_wrap_t),
+  printf("%zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu ", sizeof(bsx_stream_t), sizeof(bsx_reward_wrap_t),
          sizeof(bsx_timestep_t), sizeof(bsx_call_t), sizeof(bsx_deep_sea_t), sizeof(bsx_catch_t),
          sizeof(bsx_bandit_t), sizeof(bsx_cartpole_t), offsetof(bsx_call_t, counters),
          offsetof(bsx_cartpole_t, move_cost), offsetof(bsx_cartpole_t, time_frac),
          sizeof(bsx_logging_t), sizeof(bsx_mnist_t), offsetof(bsx_call_t, logging),
          offsetof(bsx_stream_t, mt_pos), offsetof(bsx_logging_t, log_by_step));
+  printf("%zu\n", offsetof(bsx_call_t, action_ring));
   return 0;
 }'''
   import tempfile
@@ -59,14 +60,14 @@ int main(void) {
           _native.Call.counters.offset, _native.CartpoleCfg.move_cost.offset,
           _native.CartpoleCfg.time_frac.offset,
           ctypes.sizeof(_native.Logging), ctypes.sizeof(_native.MnistCfg), _native.Call.logging.offset,
-          _native.Stream.mt_pos.offset, _native.Logging.log_by_step.offset]
+          _native.Stream.mt_pos.offset, _native.Logging.log_by_step.offset, _native.Call.action_ring.offset]
   assert got == want
 
 
 def test_argument_errors_without_touching_the_gpu():
   from bsuite_amd import _native
   lib = _native.lib
-  assert lib.bsx_abi_version() == 9
+  assert lib.bsx_abi_version() == 10
   assert lib.bsx_strerror(0) == b'ok'
   cfg = _native.DeepSeaCfg(size=10, deterministic=1, move_cost=0.001, inv_size=0.1)
   call = _native.Call(n_lanes=4)
@@ -83,6 +84,12 @@ def test_argument_errors_without_touching_the_gpu():
   cfg.size = 10
   assert lib.bsx_deep_sea_step(ctypes.byref(cfg), ctypes.byref(call), 0, 0, out, 0) == 0     # empty batch
   assert b'NULL' in lib.bsx_strerror(-2)
+  # ABI v10: the action ring is a power of two of rows, single-step calls only
+  call.n_lanes, call.action_ring = 4, 3
+  assert lib.bsx_deep_sea_step(ctypes.byref(cfg), ctypes.byref(call), 16, 16, out, 16) == -1  # BSX_EINVAL
+  call.action_ring, call.n_steps = 4, 2
+  assert lib.bsx_deep_sea_step(ctypes.byref(cfg), ctypes.byref(call), 16, 16, out, 16) == -5  # BSX_EMODE
+  call.action_ring, call.n_steps = 0, 0
   # ABI v9: pipelined group step / phase-0 trace refuse what they cannot run (host-side checks only)
   assert lib.bsx_group_step_pipelined(None, None, None) == -2
   assert lib.bsx_group_trace(None, None, 0) == -2

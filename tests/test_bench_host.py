@@ -38,16 +38,33 @@ def test_synthetic_actions_are_a_function_of_global_lane_and_step():
   assert int(big.min()) >= 0 and int(big.max()) <= 10
 
 
-def test_reference_cpu_baseline_record_is_committed_and_consistent():
-  import glob
-  hits = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*', 'cpu_reference_numpy.json')))
-  assert hits, 'tools/cpu_reference_numpy.py output missing'
-  d = json.load(open(hits[-1]))
-  for bid in ('deep_sea/10', 'catch/0', 'cartpole/0', 'mountain_car/0'):
-    rec = d['results'][bid]
-    assert 2e4 < rec['single_core']['value'] < 2e6                     # the numpy reference: ~1e5 env-steps/s per core
-    assert rec['all_cores']['cores'] == d['host']['cores'] >= 1
-    assert rec['all_cores']['value'] > rec['single_core']['value'] * 0.8
+def test_cpu_baseline_times_the_reference_live():
+  """`cpu_baseline` is measured in the run, on the box: the unmodified reference (from /root/reference here, from the
+  staged oracle/_ref byte-code on the GPU box) on one core and on one process per core, the C port beside it."""
+  from oracle import replay
+  if not replay.reference_available():
+    import pytest
+    pytest.skip('no reference on this box')
+  rec = bench.cpu_baseline('catch/0', 'catch', {}, 3, single_s=1.0, all_s=1.0)
+  assert rec['kind'] == 'reference' and rec['cores'] == 1 and rec['unit'] == 'env-steps/s'
+  assert 2e4 < rec['value'] < 2e6                                      # the numpy reference: ~1e5 env-steps/s per core
+  assert rec['all_cores']['cores'] == bench._host_cores() and rec['all_cores']['value'] > 0.5 * rec['value']
+  assert rec['port']['kind'] == 'port' and rec['port']['value'] > rec['value']
+  assert 'load_from_id' in rec['sample']
+
+
+def test_the_line_is_rounded_and_the_staged_reference_imports():
+  line = bench.sig({'a': 1.23456789e9, 'b': [0.000123456789, 3], 'c': {'d': float('nan'), 'e': 'text'}})
+  assert line == {'a': 1.2346e9, 'b': [0.00012346, 3], 'c': {'d': None, 'e': 'text'}}
+  from oracle import stage_reference
+  if stage_reference.reference_present():
+    assert stage_reference.stage()
+    env = dict(os.environ, BSX_REFERENCE_STAGED='1')
+    code = ('import sys; sys.path.insert(0, %r); from oracle import replay; bs = replay.import_reference(); '
+            'assert replay.reference_origin() == "staged" and bs.__file__.endswith(".pyc"), bs.__file__; '
+            'print(bs.load_from_id("deep_sea/10").reset().observation.shape)' % ROOT)
+    out = subprocess.run([sys.executable, '-c', code], env=env, stdout=subprocess.PIPE, text=True, timeout=120, check=True).stdout
+    assert '(30, 30)' in out
 
 
 def test_self_launch_refuses_when_devices_are_missing():

@@ -40,31 +40,53 @@ def _bench(*argv, ranks_on_one_gpu=False):
 def test_two_self_launched_ranks_reproduce_one_rank(workload):
   common = ['--workload', workload, '--steps', '32', '--warmup', '8']
   one = _bench('--gpus', '1', '--lanes', '8192', *common)
-  two = _bench('--gpus', '2', '--lanes', '4096', *common, ranks_on_one_gpu=True)     # weak: 4096 per rank
+  two = _bench('--gpus', '2', '--lanes', '4096', '--weak', *common, ranks_on_one_gpu=True)     # weak: 4096 per rank
   assert (one['n_gpus'], two['n_gpus']) == (1, 2)
   assert one['config']['global_lanes'] == two['config']['global_lanes'] == 8192
   assert two['scaling'] == 'weak'
   assert one['episodes_finished'] == two['episodes_finished'] > 0
   assert one['bsuite_info_sums'] == two['bsuite_info_sums']
   assert one['timed_mix'] == two['timed_mix']
-  strong = _bench('--gpus', '2', '--lanes', '8192', '--strong', *common, ranks_on_one_gpu=True)
+  # the default for N > 1: BASELINE's batch is GLOBAL, split over the ranks (strong scaling)
+  strong = _bench('--gpus', '2', '--lanes', '8192', *common, ranks_on_one_gpu=True)
   assert strong['scaling'] == 'strong' and strong['config']['lanes_per_gpu'] == 4096
+  assert strong['config']['global_lanes'] == 8192
   assert strong['episodes_finished'] == one['episodes_finished']
   assert strong['bsuite_info_sums'] == one['bsuite_info_sums']
 
 
 @pytest.mark.timeout(900)
-def test_default_line_two_ranks_has_strong_and_sweep_records():
+def test_default_line_two_ranks_is_strong_with_weak_and_sweep_records():
   two = _bench('--gpus', '2', '--lanes', '8192', '--steps', '8', '--warmup', '4', ranks_on_one_gpu=True)
   assert two['n_gpus'] == 2 and two['config']['workload'].startswith('deep_sea/10')
+  assert two['scaling'] == 'strong' and two['config']['lanes_per_gpu'] == 4096 and two['config']['global_lanes'] == 8192
+  assert two['roofline']['alg_bytes'] == 3621 * 4096
   also = two['also']
-  assert 'error' not in also['catch/0']
-  assert also['strong']['deep_sea/10']['roofline']['algorithmic_bytes_per_launch'] == 3621 * 4096
+  assert list(also)[0] == 'catch/0' and 'error' not in also['catch/0'] and also['catch/0']['lanes_per_gpu'] == 4096
+  assert also['weak']['scaling'] == 'weak' and also['weak']['lanes_per_gpu'] == 8192 and also['weak']['global_lanes'] == 16384
   sweep = also['sweep']
   assert sum(sweep['segments_per_rank']) == 468 and min(sweep['segments_per_rank']) > 0
-  assert sweep['global_lanes'] == 8192
+  assert sweep['global_lanes'] == 8192 and sweep['action_ring'] == 16 and sweep['pipelined']['open_loop'] is True
   one = _bench('--gpus', '1', '--workload', 'sweep', '--lanes', '8192', '--steps', '100', '--warmup', '20')   # the sub-record's K / W
   assert one['episodes_finished'] == sweep['episodes_finished'] > 0
+
+
+@pytest.mark.timeout(900)
+def test_default_line_fits_the_drivers_tail():
+  """The driver keeps the last 8000 characters of the line: the whole default line — headline, every BASELINE config
+  with its roofline, the live cpu_baseline — must fit, catch/0 first among the sub-records."""
+  env = dict(os.environ)
+  env.pop('WORLD_SIZE', None)
+  p = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--lanes', '65536', '--steps', '8', '--warmup', '4'],
+                     env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=800)
+  assert p.returncode == 0, p.stderr[-3000:]
+  text = [l for l in p.stdout.splitlines() if l.startswith('{')][0]
+  assert len(text) < 7500, len(text)
+  line = json.loads(text)
+  assert list(line['also'])[0] == 'catch/0'
+  for k in ('catch/0', 'catch/0 r32', 'deep_sea/10 r16', 'cartpole/0', 'cartpole/0 r16', 'mountain_car/0', 'mountain_car/0 r16', 'sweep'):
+    assert 'frac' in line['also'][k]['roofline'], (k, line['also'][k])
+  assert line['cpu_baseline']['kind'] in ('reference', 'port') and line['roofline']['frac'] > 0
 
 
 # ---------------------------------------------------------------------------------------------------

@@ -98,8 +98,8 @@ def test_pipelined_rollout_equals_steps(family, kwargs, na, T, logging):
 
 @pytest.mark.parametrize('place', ['1', '2'])
 def test_pipelined_rollout_other_placements(place):
-  """BSX_PIPELINED_PLACE (read once per process) = where the advance workgroups sit in the fused grid: the last
-  workgroups, or spread evenly.  The default (first) is what every other test runs; the A/B placements must
+  """BSX_PIPELINED_PLACE (an A/B knob: only the tuning build of the library reads it, bsuite_amd/build.py) = where the
+  advance workgroups sit in the fused grid: the last workgroups, or spread evenly.  The default (first) is what every other test runs; the A/B placements must
   produce the same TimeSteps (catch at a batch whose stream has fewer / more workgroups than its advance)."""
   import subprocess
   import sys
@@ -123,7 +123,9 @@ for family, kwargs, na, batch in (('catch', dict(), 3, 1024), ('catch', dict(row
 print('placements ok')
 '''
   root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-  env = dict(os.environ, BSX_PIPELINED_PLACE=place, PYTHONPATH=root)
+  from bsuite_amd import build as _build
+  env = dict(os.environ, BSX_PIPELINED_PLACE=place, PYTHONPATH=root, BSX_NATIVE_LIB=_build.build(tuning=True),
+             BSX_FUSED_TILE_MAX_BYTES='0')          # (small batches would otherwise take the fused one-launch step)
   p = subprocess.run([sys.executable, '-c', code], cwd=root, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT,
                      text=True, timeout=300)
   assert p.returncode == 0 and 'placements ok' in p.stdout, p.stdout[-2000:]

@@ -11,6 +11,10 @@ from tests import golden_util as gu
 @pytest.mark.parametrize('name', gu.replay_case_names())
 def test_oracle_matches_reference(name):
   meta, g = gu.load_case(name)
+  check_oracle_against_case(meta, g)
+
+
+def check_oracle_against_case(meta, g):
   fam = meta['family']
   kwargs = dict(meta['kwargs'])
   if fam == 'mnist':
@@ -57,3 +61,30 @@ def test_fixtures_reach_rare_branches():
   assert g['info'][-1, :, meta['info_keys'].index('total_upright')].max() > 50   # upright reward branch
   _, g = gu.load_case('mnist_synthetic')
   assert (g['obs'] < 0).any()                                                # int8 pixel quirk present
+
+
+# ---------------------------------------------------------------------------------------------------
+# The same restatement against the reference LIVE (build container: /root/reference; elsewhere the staged
+# byte-code of oracle/stage_reference.py): the random cases of tests/test_gpu_vs_reference_live.py, so the
+# checker the GPU fuzz runs against is itself pinned on cases no fixture holds.
+@pytest.mark.parametrize('chunk', range(4))
+def test_oracle_matches_the_live_reference(chunk):
+  from oracle import replay
+  if not replay.reference_available():
+    pytest.skip('no reference on this box')
+  bs = replay.import_reference()
+  from oracle import make_golden as mg
+  from bsuite_amd.utils import datasets as _ds
+  from tests import test_gpu_vs_reference_live as live
+  imgs, labs = mg.synthetic_mnist()
+  _ds.write_idx_files(mg.MNIST_DIR, imgs, labs)
+  rng = np.random.default_rng(9000 + chunk)
+  for j in range(live.CASES_PER_CHUNK):
+    c = live._random_case(rng)
+    meta, g = mg.run_case(bs, 'live', c['family'], c['kwargs'], c['lanes'], c['T'], seed=c['seed'], step0=c['step0'],
+                          wrap=c['wrap'], policies=c['policies'], reset_at=c['reset_at'], case_seed=chunk * 100 + j,
+                          write=False)
+    try:
+      check_oracle_against_case(meta, g)
+    except AssertionError as e:
+      raise AssertionError(f'{c}: {e}') from e
