@@ -160,22 +160,17 @@ def _host_cores():
   return len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
 
 
-def _fan_out(code, argv, n_procs):
-  """One PROCESS per core, like the reference's own fan-out (bsuite/baselines/utils/pool.py:35,48; threads would
-  serialise on the interpreter lock); each prints "<env-steps> <seconds>"."""
-  import subprocess
-  t0 = time.perf_counter()
-  procs = [subprocess.Popen([sys.executable, '-c', code] + [str(a) for a in argv] + [str(j)], stdout=subprocess.PIPE,
-                            stderr=subprocess.DEVNULL, text=True) for j in range(n_procs)]
-  res = []
-  for pr in procs:
-    o, _ = pr.communicate()
-    try:
-      x, y = o.split()[-2:]
-      res.append((float(x), float(y)))
-    except ValueError:
-      pass
-  return res, time.perf_counter() - t0
+def _reference_pool(bsuite_id, seconds, n_procs):
+  """Runs in a fresh helper interpreter (no torch, no HIP): imports the reference once, then forks one worker
+  PROCESS per core — the shape of the reference's own fan-out (bsuite/baselines/utils/pool.py:35,48; threads would
+  serialise on the interpreter lock) — and prints one "<env-steps> <seconds>" pair per worker."""
+  import multiprocessing
+  from oracle import replay
+  replay.import_reference()                       # the workers inherit the imported package: no 256 cold imports
+  with multiprocessing.get_context('fork').Pool(n_procs) as pool:
+    res = pool.starmap(_reference_loop, [(bsuite_id, seconds, 1 + j) for j in range(n_procs)])
+  for calls, dt in res:
+    print(calls, dt)
 
 
 def cpu_port_baseline(family, kwargs, num_actions, budget_s=2.5):
@@ -202,9 +197,14 @@ def cpu_baseline(bsuite_id, family, kwargs, num_actions, single_s=8.0, all_s=5.0
              sample=f"unmodified bsuite.load_from_id('{bsuite_id}') + random agent, {calls} reset()/step() calls in "
                     f"{dt:.1f} s on one core of this box ({origin}: {'/root/reference' if origin == 'source' else 'oracle/_ref byte-code'})")
   if cores > 1 and all_s > 0:
+    import subprocess
     code = ('import sys; sys.path.insert(0, %r); import bench; '
-            'print(*bench._reference_loop(sys.argv[1], float(sys.argv[2]), 1 + int(sys.argv[3])))' % ROOT)
-    res, wall = _fan_out(code, [bsuite_id, all_s], cores)
+            'bench._reference_pool(sys.argv[1], float(sys.argv[2]), int(sys.argv[3]))' % ROOT)
+    t0 = time.perf_counter()
+    p = subprocess.run([sys.executable, '-c', code, bsuite_id, str(all_s), str(cores)], stdout=subprocess.PIPE,
+                       stderr=subprocess.DEVNULL, text=True, check=False)
+    wall = time.perf_counter() - t0
+    res = [tuple(float(x) for x in l.split()) for l in p.stdout.splitlines() if len(l.split()) == 2]
     if res:
       out['all_cores'] = dict(value=sum(r[0] for r in res) / max(r[1] for r in res), cores=len(res),
                               sample=f'{len(res)} processes x {all_s:.0f} s (pool.py:35,48 shape), {wall:.1f} s wall incl. start-up')
@@ -478,7 +478,7 @@ class Rank:
            'frac': r['achieved'] / HBM_PEAK_GBPS, 'traffic': r['traffic']}
     if full:
       ceiling = self.store_ceiling()
-      out.update(traffic_src=r['traffic_src'], alg_bytes=r['bytes_per_step'] * r['lanes'], kernel_ms=r['kernel_ms'],
+      out.update(traffic_src=r['traffic_src'], alg_bytes=int(round(r['bytes_per_step'] * r['lanes'])), kernel_ms=r['kernel_ms'],
                  box_fill_GBps=ceiling, frac_of_box_fill=r['achieved'] / ceiling)
     if r['mode'] == 'rollout' and r['family'] in ('cartpole', 'mountain_car'):
       v = pmc_valu(r['workload'], f"rollout{r['chunk']}", r['lanes'])

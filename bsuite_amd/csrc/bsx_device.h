@@ -490,6 +490,53 @@ __global__ void __launch_bounds__(BSX_BLOCK) bsx_fused_tile_kernel(const typenam
   bsx_tile_stream(obs + lane0 * (int64_t)cells, s_state, left < BSX_BLOCK ? (int)left : BSX_BLOCK, cells, cells_magic, fn);
 }
 
+// The same for a rollout of T steps: ONE launch.  Lanes never interact, so a workgroup can take its 256 lanes
+// through all T steps on its own — packed state in a register, actions prefetched one step ahead, per step one
+// barrier (the LDS state tile is double-buffered) and the [256 x cells] tile of slice t streamed while the next
+// step's advance is already under way in the faster waves.  No launch boundary, no state round trip.
+template <class Fam, bool LEAN, class HotFn>
+__global__ void __launch_bounds__(BSX_BLOCK) bsx_fused_rollout_kernel(const typename Fam::args a, const int n_steps,
+                                                                      float* __restrict__ obs, const uint32_t cells,
+                                                                      const uint32_t cells_magic, const HotFn fn) {
+  __shared__ typename Fam::shared s_fam;
+  __shared__ unsigned int s_cnt[2];
+  __shared__ int32_t s_state[2][BSX_BLOCK];
+  if (threadIdx.x < 2) s_cnt[threadIdx.x] = 0;
+  Fam::stage(a, s_fam);
+  __syncthreads();
+  const int64_t B = a.ctl.n_lanes;
+  const int64_t lane0 = (int64_t)blockIdx.x * BSX_BLOCK;
+  const int64_t i = lane0 + threadIdx.x;
+  const bool mine = i < B;
+  const int lanes_here = B - lane0 < BSX_BLOCK ? (int)(B - lane0) : BSX_BLOCK;
+  const uint64_t lane = a.ctl.lane_offset + (uint64_t)i;
+  const uint64_t step0 = bsx_step_of(a.ctl);
+  int32_t st = mine ? a.state[i] : 0;
+  int act_next = mine ? a.action[i] : 0;
+#pragma unroll 1
+  for (int t = 0; t < n_steps; ++t) {
+    int type = -1;
+    const int act = act_next;
+    if (mine) {
+      if (t + 1 < n_steps) act_next = a.action[(int64_t)(t + 1) * B + i];
+      int32_t nst; double reward;
+      type = Fam::template advance<LEAN>(a, s_fam, i, lane, step0 + (uint64_t)t, st, act, nst, reward);
+      st = nst;
+      s_state[t & 1][threadIdx.x] = nst;
+      if (LEAN) bsx_emit_at<0, 0>(a.ctl, a.out, i, (int64_t)t * B + i, lane, step0 + (uint64_t)t, type, reward);
+      else bsx_emit_at(a.ctl, a.out, i, (int64_t)t * B + i, lane, step0 + (uint64_t)t, type, reward);
+    }
+    bsx_count_types(a.ctl, type, s_cnt);
+    // one barrier per step: tile t is read from s_state[t & 1] after it; step t+1 writes the other buffer, and no
+    // thread reaches step t+2 (which rewrites this one) before every thread has passed the barrier of step t+1
+    __syncthreads();
+    bsx_tile_stream(obs + ((int64_t)t * B + lane0) * (int64_t)cells, s_state[t & 1], lanes_here, cells, cells_magic, fn);
+  }
+  if (mine) a.state[i] = st;
+  __syncthreads();
+  bsx_flush_counts(a.ctl, s_cnt, blockIdx.x);
+}
+
 // Software-pipelined rollout step of a two-kernel family: ONE launch runs the observation stream of
 // step t beside the lane advance of step t+1.  Nothing inside the launch depends on anything else inside
 // it — both halves read the packed state column W(t) that the previous launch wrote, the advance writes

@@ -276,14 +276,27 @@ static int bsx_pair_call(const typename Fam::args& a0, const bsx_call_t* call, c
   const bool pipelined = pipe_env != 0 && T > 1 && call->state_alt != nullptr && call->obs_paint == nullptr &&
                          cells >= 4u && (((uint64_t)B * cells) & 3ull) == 0;
   int rc = 0;
-  // small batches: one fused launch per step (bsx_fused_tile_kernel) while the observation array is at most
-  // BSX_FUSED_TILE_MAX_BYTES (measured crossover, profiles/r03/ab_fused_tile.log); the tile start
-  // block*256*cells*4 is always 16-byte aligned when the slice is.
-  static const int64_t fused_max = (int64_t)bsx_env_int("BSX_FUSED_TILE_MAX_BYTES", 64 << 20);
-  const bool fused = call->obs_paint == nullptr && cells >= 4u && cells <= 4096u && B * (int64_t)cells * 4 <= fused_max &&
-                     (((uint64_t)B * cells) & 3ull) == 0 && (reinterpret_cast<uintptr_t>(out.observation) & 15u) == 0;
+  // Boards of at most BSX_FUSED_TILE_MAX_CELLS floats (catch's 50; a workgroup's [256 x cells] tile is then <= 128 KiB):
+  // ONE fused launch per step (bsx_fused_tile_kernel) and ONE per rollout (bsx_fused_rollout_kernel) while the
+  // observation array of a step is at most BSX_FUSED_TILE_MAX_MIB / BSX_FUSED_ROLLOUT_MAX_MIB — measured crossovers,
+  // profiles/r03/ab_fused_tile*.log; deep_sea N=30 (900 cells, 0.9 MiB tiles) never fuses.  The tile start
+  // block*256*cells*4 is always 16-byte aligned when the slice is.  (A barrier-free variant — every wave its own
+  // 64 lanes, neighbour states through ds_bpermute — measured 1-9 % slower: profiles/r03/ab_fused_wave.log.)
+  static const int fused_cells = bsx_env_int("BSX_FUSED_TILE_MAX_CELLS", 128);
+  static const int fused_step_mib = bsx_env_int("BSX_FUSED_TILE_MAX_MIB", 256);
+  static const int fused_roll_mib = bsx_env_int("BSX_FUSED_ROLLOUT_MAX_MIB", 256);
+  const int64_t step_bytes = B * (int64_t)cells * 4;
+  const bool fusable = call->obs_paint == nullptr && cells >= 4u && (int)cells <= fused_cells &&
+                       (((uint64_t)B * cells) & 3ull) == 0 && (reinterpret_cast<uintptr_t>(out.observation) & 15u) == 0;
+  const bool fused = fusable && step_bytes <= ((int64_t)(T > 1 ? fused_roll_mib : fused_step_mib) << 20);
+  const bool lean_f = a0.ctl.log.steps == nullptr && a0.ctl.wrap_kind < BSX_WRAP_NOISE && a0.ctl.mt_state == nullptr;
+  if (fused && T > 1) {
+    const dim3 grid((unsigned)((B + BSX_BLOCK - 1) / BSX_BLOCK)), block(BSX_BLOCK);
+    if (lean_f) bsx_fused_rollout_kernel<Fam, true, HotFn><<<grid, block, 0, st>>>(a0, T, out.observation, cells, magic, fn);
+    else bsx_fused_rollout_kernel<Fam, false, HotFn><<<grid, block, 0, st>>>(a0, T, out.observation, cells, magic, fn);
+    return bsx_launch_status();
+  }
   if (!pipelined || fused) {
-    const bool lean_f = a0.ctl.log.steps == nullptr && a0.ctl.wrap_kind < BSX_WRAP_NOISE && a0.ctl.mt_state == nullptr;
     for (int t = 0; t < T && rc == 0; ++t) {
       const typename Fam::args s = at(t);
       if (call->obs_paint != nullptr) {

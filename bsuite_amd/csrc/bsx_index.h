@@ -30,11 +30,10 @@ BSX_HD bsx_pipe_role bsx_pipe_role_of(uint32_t b, uint32_t grid, uint32_t adv_bl
   return r;
 }
 
-// Rows a lane's own thread stores (1, 3 or an even number <= 8 floats); other rows of the families with a
-// parametric row length go through the bit-plane tile (small_obs.hip).
-BSX_HD int bsx_small_direct_shape(int numel) {
-  return numel <= 8 && (numel == 1 || numel == 3 || (numel & 1) == 0);
-}
+// Rows a lane's own thread stores (at most 8 floats: 8-byte stores for an even length, one 12-byte store for 3, 4-byte
+// stores for 1, 5, 7); longer rows of the families with a parametric row length go through the bit-plane tile
+// (small_obs.h), whose lane-owned HEAD chunks need numel >= 9 to be disjoint between neighbouring lanes.
+BSX_HD int bsx_small_direct_shape(int numel) { return numel <= 8; }
 
 // Split of one 32-bit piece of a lane's bit string for the flat bit planes of a tile: the piece starts at flat
 // bit `pos` and has n bits (1..32, the low n bits of w).  Word index, the part that goes into that word and the

@@ -122,56 +122,92 @@ __device__ __forceinline__ void small_obs_body(const typename Env::args& a, cons
           row3 v; v.a = o[0]; v.b = o[1]; v.c = o[2];
           *reinterpret_cast<row3*>(dst) = v;
         } else {
-          dst[0] = o[0];                                                // numel == 1
+#pragma unroll
+          for (int k = 0; k < 7; ++k)                                   // numel == 1, 5, 7: 4-byte stores
+            if (k < numel) dst[k] = o[k];
         }
       }
       bsx_count_types(a.ctl, type, s_cnt);
     } else {
-      constexpr int HEAD = Env::HEAD, PLANES = Env::PLANES;
+      constexpr int HEAD = Env::HEAD, PLANES = Env::PLANES;          // numel >= 9 here (bsx_small_direct_shape)
+      // LDS: PLANES data planes + 1 plane marking the HEAD elements (a fixed pattern: bits l*numel + k, k < HEAD —
+      // built once per launch), `stride` words each; then the 256 lanes' HEAD floats (4 floats of padding either side).
       uint32_t* __restrict__ planes = reinterpret_cast<uint32_t*>(s_obs);
       const int stride = numel * (BSX_BLOCK / 32);                       // words per plane
-      for (int w = threadIdx.x; w < PLANES * stride; w += BSX_BLOCK) planes[w] = 0u;
+      uint32_t* __restrict__ head_plane = planes + PLANES * stride;
+      float* __restrict__ s_head = reinterpret_cast<float*>(head_plane + stride) + 4;
+      if (t == 0) {
+        for (int w = threadIdx.x; w < (PLANES + 1) * stride; w += BSX_BLOCK) planes[w] = 0u;
+      } else {
+        __syncthreads();                                                 // every chunk of step t-1 has been read
+        for (int w = threadIdx.x; w < PLANES * stride; w += BSX_BLOCK) planes[w] = 0u;
+      }
       __syncthreads();
-      float head[HEAD];
       if (mine) {
         double reward = 0.0;
+        float head[HEAD];
         const bsx_bit_sink sink{planes, stride, (uint32_t)((int)threadIdx.x * numel + HEAD)};
         type = Env::template step<LOG, MT, true>(a, i, oi, lane, step0 + (uint64_t)t, head, reward, &sink);
         bsx_emit_at<LOG, NOISE>(a.ctl, a.out, i, oi, lane, step0 + (uint64_t)t, type, reward);
+#pragma unroll
+        for (int k = 0; k < HEAD; ++k) s_head[threadIdx.x * HEAD + k] = head[k];
+        if (t == 0) {
+          const bsx_bit_sink hs{head_plane, stride, (uint32_t)((int)threadIdx.x * numel)};
+          hs.put(0, 0, 0xFFFFFFFFu, HEAD);
+        }
       }
       bsx_count_types(a.ctl, type, s_cnt);
       __syncthreads();
 
-      // stream the tile: [lanes_here x numel] floats, contiguous in HBM, 16-byte aligned start
+      // Stream the tile: [lanes_here x numel] floats, contiguous in HBM, 16-byte aligned start, every byte written
+      // exactly once and only by full 16-byte chunks (1 KiB per wave instruction).  Chunk c is the nibble at bit 4c of
+      // each plane, four bit-tests away from a float4; where the HEAD plane's nibble is non-zero the lane's HEAD
+      // floats are spliced in from LDS: numel >= 9 means at most ONE lane's HEAD run lies in a chunk, so one magic
+      // division finds it and element j of the chunk is s_head[base + j].  What this replaces, and why
+      // (profiles/r03/ab_wide_rows*.log): r02 streamed zeros into the HEAD places and patched them with a 12-byte
+      // store per lane after a third barrier and the store acknowledgements of the whole tile; storing the HEAD
+      // chunks from their own lanes instead (no patch, no third barrier) was no faster — the L2 is bound by write
+      // REQUESTS here, and a million scattered partial-line stores are a third of all requests: without any HEAD
+      // stores the same kernel takes 86 us instead of 116 (umbrella_distract).
       float* __restrict__ tile = a.out.observation + ((int64_t)t * B + lane0) * (int64_t)numel;
       const int total = lanes_here * numel;
       const bool vec = ((((int64_t)t * B * numel) & 3) == 0);            // [t] slice 16-byte aligned?
       const int n_chunks = vec ? total >> 2 : 0;
+      const uint32_t numel_magic = a.numel_magic;                        // f / numel = __umulhi(f, magic), f < 2^16
       bsx_f4* __restrict__ t4 = reinterpret_cast<bsx_f4*>(tile);
       for (int ch = threadIdx.x; ch < n_chunks; ch += BSX_BLOCK) {
-        const uint32_t n0 = planes[ch >> 3] >> ((ch & 7) << 2);
-        const uint32_t n1 = PLANES > 1 ? planes[stride + (ch >> 3)] >> ((ch & 7) << 2) : 0u;
+        const int sh = (ch & 7) << 2;
+        const uint32_t n0 = planes[ch >> 3] >> sh;
+        const uint32_t n1 = PLANES > 1 ? planes[stride + (ch >> 3)] >> sh : 0u;
+        const uint32_t hm = (head_plane[ch >> 3] >> sh) & 0xFu;
         bsx_f4 q;
         q.x = Env::decode(n0 & 1u, n1 & 1u);
         q.y = Env::decode((n0 >> 1) & 1u, (n1 >> 1) & 1u);
         q.z = Env::decode((n0 >> 2) & 1u, (n1 >> 2) & 1u);
         q.w = Env::decode((n0 >> 3) & 1u, (n1 >> 3) & 1u);
+        if (hm != 0u) {
+          const int j1 = __ffs((int)hm) - 1;                             // first HEAD element of the chunk
+          const uint32_t f1 = ((uint32_t)ch << 2) + (uint32_t)j1;
+          const uint32_t l = __umulhi(f1, numel_magic);                  // its lane
+          const int base = (int)(l * (uint32_t)HEAD + (f1 - l * (uint32_t)numel)) - j1;   // >= -3: padded
+          const float h0 = s_head[base], h1 = s_head[base + 1], h2 = s_head[base + 2], h3 = s_head[base + 3];
+          q.x = (hm & 1u) ? h0 : q.x;
+          q.y = (hm & 2u) ? h1 : q.y;
+          q.z = (hm & 4u) ? h2 : q.z;
+          q.w = (hm & 8u) ? h3 : q.w;
+        }
         t4[ch] = q;
       }
+      // elements beyond the 16-byte chunks (an unaligned [t] slice, or the < 4 floats at the end of an odd tile)
       for (int f = (n_chunks << 2) + (int)threadIdx.x; f < total; f += BSX_BLOCK) {
         const uint32_t b0 = (planes[f >> 5] >> (f & 31)) & 1u;
         const uint32_t b1 = PLANES > 1 ? (planes[stride + (f >> 5)] >> (f & 31)) & 1u : 0u;
-        tile[f] = Env::decode(b0, b1);
-      }
-      // The barrier orders every tile store of the block before the HEAD floats that overwrite their
-      // places (and the plane reads above before the next step's zeroing).
-      __syncthreads();
-      if (mine) {
-        struct __attribute__((packed, aligned(4))) head_row { float v[HEAD]; };
-        head_row h;
-#pragma unroll
-        for (int k = 0; k < HEAD; ++k) h.v[k] = head[k];
-        *reinterpret_cast<head_row*>(a.out.observation + oi * (int64_t)numel) = h;
+        float v = Env::decode(b0, b1);
+        if ((head_plane[f >> 5] >> (f & 31)) & 1u) {
+          const uint32_t l = __umulhi((uint32_t)f, numel_magic);
+          v = s_head[l * (uint32_t)HEAD + ((uint32_t)f - l * (uint32_t)numel)];
+        }
+        tile[f] = v;
       }
     }
   }
@@ -192,7 +228,8 @@ __global__ void __launch_bounds__(BSX_BLOCK) small_obs_kernel(const typename Env
 // Dynamic LDS of one workgroup stepping `a`.
 template <class Env>
 static size_t small_obs_lds(const typename Env::args& a) {
-  if constexpr (Env::PACKED) return bsx_small_direct_shape(a.obs_numel) ? 0 : (size_t)Env::PLANES * a.obs_numel * (BSX_BLOCK / 32) * 4;
+  if constexpr (Env::PACKED)     // PLANES data planes + the HEAD-position plane + the lanes' HEAD floats (padded)
+    return bsx_small_direct_shape(a.obs_numel) ? 0 : (size_t)(Env::PLANES + 1) * a.obs_numel * (BSX_BLOCK / 32) * 4 + (size_t)(BSX_BLOCK * Env::HEAD + 8) * 4;
   else return 0;
 }
 
@@ -338,7 +375,7 @@ struct memory_chain_env {
   struct regs { int unused; };
   struct args {
     bsx_ctl ctl; const int32_t* action; int32_t* state; uint64_t* context; bsx_timestep_t out;
-    double* info; int32_t obs_numel; int32_t L; int32_t nb;
+    double* info; int32_t obs_numel; int32_t L; int32_t nb; uint32_t numel_magic;
   };
   // Packed rows: HEAD = [time, query]; element 2+b is 0 unless t == 0, then +-1 by context bit b: plane 0 says
   // "non-zero", plane 1 carries the context bit.
@@ -376,8 +413,14 @@ struct memory_chain_env {
       bsx_draws d;
       bsx_draws_begin<MT>(&d, a.ctl, i, lane, step);
       ctx = 0;
-      uint32_t w = 0;
-      for (int b = 0; b < a.nb; ++b) ctx |= (uint64_t)bsx_bern_vec_bit(&d, b, &w) << b;   // BernVec(nb)
+      if (MT == 0 || d.mt == nullptr) {                         // BernVec(nb) = the low nb bits of ceil(nb/32) words
+        ctx = (uint64_t)bsx_word(&d);
+        if (a.nb > 32) ctx |= (uint64_t)bsx_word(&d) << 32;
+        ctx &= (1ull << a.nb) - 1ull;                           // nb <= 62
+      } else {
+        uint32_t w = 0;
+        for (int b = 0; b < a.nb; ++b) ctx |= (uint64_t)bsx_bern_vec_bit(&d, b, &w) << b;   // one legacy double per bit
+      }
       query = (int)bsx_randint(&d, (uint32_t)a.nb);
       bsx_draws_end<MT>(&d, a.ctl, i);
       t = 0;
@@ -403,12 +446,12 @@ struct umbrella_chain_env {
   struct regs { int unused; };
   struct args {
     bsx_ctl ctl; const int32_t* action; int32_t* state; bsx_timestep_t out; double* info;
-    int32_t obs_numel; int32_t L; int32_t nd;
+    int32_t obs_numel; int32_t L; int32_t nd; uint32_t numel_magic;
   };
   // Packed rows: HEAD = [need, has, time]; element 3+b is distractor bit b as 0.0 / 1.0 (one plane).
   static constexpr int HEAD = 3, PLANES = 1;
   __device__ static float decode(uint32_t bit, uint32_t) { return __uint_as_float((0u - bit) & 0x3F800000u); }
-  template <bool PACK>
+  template <bool PACK, int MT>
   __device__ static void observe(const args& a, float* o, int t, int need, int has, bsx_draws* d, const bsx_bit_sink* sink) {
     BSX_NO_CONTRACT
     o[0] = (float)need;                                         // umbrella_chain.py:62
@@ -416,10 +459,20 @@ struct umbrella_chain_env {
     o[2] = (float)(1.0 - (double)t / (double)a.L);              // :64
     uint32_t w = 0;
     if constexpr (PACK) {
-      uint32_t acc = 0;
-      for (int b = 0; b < a.nd; ++b) {                          // :65 BernVec(nd)
-        acc |= bsx_bern_vec_bit(d, b, &w) << (b & 31);
-        if ((b & 31) == 31 || b == a.nd - 1) { sink->put(0, b >> 5, acc, (b & 31) + 1); acc = 0; }
+      if (MT == 0 || d->mt == nullptr) {
+        // :65 BernVec(nd) IS a run of stream words (bit i of the vector = bit i%32 of word i/32): hand the words to
+        // the tile as they come — a bit-by-bit loop cost ~30 scalar + ~5 vector instructions per distractor
+        // (3400 SALU per wave at nd = 100, profiles/r03/umbrella_distract_before_pmc_sq.json)
+        for (int k = 0; 32 * k < a.nd; ++k) {
+          const int n = a.nd - 32 * k;
+          sink->put(0, k, bsx_word(d), n < 32 ? n : 32);
+        }
+      } else {
+        uint32_t acc = 0;
+        for (int b = 0; b < a.nd; ++b) {                        // MT19937-exact mode: one legacy double per bit
+          acc |= bsx_bern_vec_bit(d, b, &w) << (b & 31);
+          if ((b & 31) == 31 || b == a.nd - 1) { sink->put(0, b >> 5, acc, (b & 31) + 1); acc = 0; }
+        }
       }
     } else {
       for (int b = 0; b < a.nd; ++b) o[3 + b] = (float)bsx_bern_vec_bit(d, b, &w);   // :65 BernVec(nd)
@@ -437,7 +490,7 @@ struct umbrella_chain_env {
       t = 0;
       need = (int)bsx_bern(&d);
       has = (int)bsx_bern(&d);
-      observe<PACK>(a, o, t, need, has, &d, sink);
+      observe<PACK, MT>(a, o, t, need, has, &d, sink);
       bsx_draws_end<MT>(&d, a.ctl, i);
       a.state[i] = t | (need << 20) | (has << 21);
       return BSX_FIRST;
@@ -448,11 +501,11 @@ struct umbrella_chain_env {
     if (t == a.L) {                                             // :74-81
       if (has == need) reward = 1.0;
       else { reward = -1.0; a.info[i] += 2.0; }
-      observe<PACK>(a, o, t, need, has, &d, sink);
+      observe<PACK, MT>(a, o, t, need, has, &d, sink);
       type = BSX_LAST;
     } else {                                                    // :83-85
       reward = 2.0 * (double)bsx_bern(&d) - 1.0;
-      observe<PACK>(a, o, t, need, has, &d, sink);
+      observe<PACK, MT>(a, o, t, need, has, &d, sink);
       type = BSX_MID;
     }
     bsx_draws_end<MT>(&d, a.ctl, i);

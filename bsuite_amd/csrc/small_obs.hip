@@ -54,6 +54,7 @@ static int memory_chain_make(const bsx_memory_chain_t* cfg, const bsx_call_t* ca
   if (call->n_lanes > 0 && (state == nullptr || context == nullptr || info == nullptr)) return BSX_ENULL;
   a->ctl = bsx_make_ctl(call); a->action = action; a->state = state; a->context = context; a->out = out;
   a->info = info; a->obs_numel = cfg->num_bits + 2; a->L = cfg->memory_length; a->nb = cfg->num_bits;
+  a->numel_magic = bsx_div_magic((uint32_t)a->obs_numel);
   return 0;
 }
 
@@ -84,6 +85,7 @@ static int umbrella_chain_make(const bsx_umbrella_chain_t* cfg, const bsx_call_t
   if (call->n_lanes > 0 && (state == nullptr || info == nullptr)) return BSX_ENULL;
   a->ctl = bsx_make_ctl(call); a->action = action; a->state = state; a->out = out; a->info = info;
   a->obs_numel = 3 + cfg->n_distractor; a->L = cfg->chain_length; a->nd = cfg->n_distractor;
+  a->numel_magic = bsx_div_magic((uint32_t)a->obs_numel);
   return 0;
 }
 

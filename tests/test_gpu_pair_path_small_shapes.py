@@ -1,10 +1,10 @@
 """GPU: the TWO-launch step (lane advance + observation store stream) and the software-pipelined rollout of deep_sea /
-catch at SMALL shapes.  In the product library a batch whose observation array is at most 64 MiB takes the fused
-one-launch step (bsx_fused_tile_kernel), so the in-process parity tests at small shapes — ragged and 1-lane batches,
+catch at SMALL boards.  In the product library a board of at most 128 floats (catch 10x5, deep_sea N <= 11) takes the
+fused one-launch step / rollout (bsx_fused_tile_kernel, bsx_fused_rollout_kernel), so the in-process parity tests at such shapes — ragged and 1-lane batches,
 boards whose 16-byte chunks straddle two lanes, odd slice alignments, both parities of T — exercise the FUSED kernel;
-the pair path runs in-process only at the benched sizes (tests/test_gpu_full_size.py, test_gpu_benched_sizes.py).  Here
+the pair path runs in-process only for bigger boards (deep_sea N >= 12, incl. the benched N=30) and batches.  Here
 the same small-shape parity tests run once more in a subprocess against the tuning build of the library (-DBSX_TUNING,
-bsuite_amd/build.py) with BSX_FUSED_TILE_MAX_BYTES=0, i.e. with the fused step switched off: every edge case of the
+bsuite_amd/build.py) with BSX_FUSED_TILE_MAX_CELLS=0, i.e. with the fused step switched off: every edge case of the
 stream kernel stays covered against the golden fixtures and the C oracle."""
 import os
 import subprocess
@@ -19,7 +19,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 @pytest.mark.timeout(1200)
 def test_pair_path_parity_at_small_shapes():
   from bsuite_amd import build as _build
-  env = dict(os.environ, BSX_NATIVE_LIB=_build.build(tuning=True), BSX_FUSED_TILE_MAX_BYTES='0', PYTHONPATH=ROOT)
+  env = dict(os.environ, BSX_NATIVE_LIB=_build.build(tuning=True), BSX_FUSED_TILE_MAX_CELLS='0', PYTHONPATH=ROOT)
   p = subprocess.run([sys.executable, '-m', 'pytest', '-q', '-x', '-m', 'gpu', '-p', 'no:cacheprovider',
                       'tests/test_gpu_golden.py', 'tests/test_gpu_oracle_batch.py', 'tests/test_gpu_rollout.py',
                       'tests/test_gpu_delta_obs.py', 'tests/test_gpu_engine_features.py',

@@ -125,7 +125,7 @@ print('placements ok')
   root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
   from bsuite_amd import build as _build
   env = dict(os.environ, BSX_PIPELINED_PLACE=place, PYTHONPATH=root, BSX_NATIVE_LIB=_build.build(tuning=True),
-             BSX_FUSED_TILE_MAX_BYTES='0')          # (small batches would otherwise take the fused one-launch step)
+             BSX_FUSED_TILE_MAX_CELLS='0')          # (small batches would otherwise take the fused one-launch step)
   p = subprocess.run([sys.executable, '-c', code], cwd=root, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT,
                      text=True, timeout=300)
   assert p.returncode == 0 and 'placements ok' in p.stdout, p.stdout[-2000:]

@@ -45,7 +45,7 @@ def test_pipelined_roles_partition_the_grid(shim, place, adv, stream):
 
 
 def test_direct_shape_rule(shim):
-  assert [n for n in range(1, 40) if shim.shim_direct_shape(n)] == [1, 2, 3, 4, 6, 8]
+  assert [n for n in range(1, 40) if shim.shim_direct_shape(n)] == [1, 2, 3, 4, 5, 6, 7, 8]
 
 
 @settings(max_examples=60, deadline=None)
