@@ -19,17 +19,20 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
-#include <mutex>
-
 #include "../../include/bsuite_amd.h"
 #include "bsx_device.h"
 #include "bsx_host.h"
+
+// The anti-aliasing half kernels travel BY VALUE in the kernel arguments (2 x 65 doubles = 1040 B) and are copied to
+// LDS by the workgroups that filter: no device buffer owned by the library, so no allocation or synchronous upload
+// inside the entry point (capturable from the first call) and nothing tied to the device that happened to be current
+// when a configuration was first seen (a process-global cache of device pointers faulted on a second GPU).
+struct image_gauss { double w[2][BSX_IMAGE_MAX_RADIUS + 1]; };   // [0] rows (y), [1] columns (x)
 
 struct image_args {
   const float* obs; float* image; int64_t n_lanes;
   int32_t mode, in_rows, in_cols, out_rows, out_cols, tail;
   int32_t radius_y, radius_x;                     // anti-aliasing Gaussian (down-scaling), 0 = none
-  const double* gauss;                            // device: [2][BSX_IMAGE_MAX_RADIUS+1] half kernels (y, x), or null
   uint32_t numel;                                 // out_rows*out_cols*tail (< 2^20)
   uint32_t tail_magic, cols_magic;                // bsx_div_magic(tail), bsx_div_magic(out_cols)
   uint32_t blocks_per_lane;
@@ -138,9 +141,14 @@ __device__ __forceinline__ void img_gauss_pass(const float* src, float* dst, int
 }
 
 template <int IMG_K>
-__global__ void __launch_bounds__(BSX_BLOCK) bsx_image_kernel(const image_args a) {
+__global__ void __launch_bounds__(BSX_BLOCK) bsx_image_kernel(const image_args a, const image_gauss gw) {
   constexpr uint32_t IMG_RUN = IMG_K * BSX_BLOCK * 4;
   extern __shared__ __attribute__((aligned(16))) unsigned char s_raw[];
+  __shared__ double s_gauss[2][BSX_IMAGE_MAX_RADIUS + 1];
+  if (a.radius_y > 0 || a.radius_x > 0) {         // uniform
+    for (int j = threadIdx.x; j < 2 * (BSX_IMAGE_MAX_RADIUS + 1); j += BSX_BLOCK)
+      s_gauss[j / (BSX_IMAGE_MAX_RADIUS + 1)][j % (BSX_IMAGE_MAX_RADIUS + 1)] = gw.w[j / (BSX_IMAGE_MAX_RADIUS + 1)][j % (BSX_IMAGE_MAX_RADIUS + 1)];
+  }
   // LDS layout: y weights f64 [2*H] | x weights f64 [2*W] | y idx i32 [H] | x idx i32 [W] | obs f32
   double* s_yw = reinterpret_cast<double*>(s_raw);
   double* s_xw = s_yw + 2 * a.out_rows;
@@ -169,12 +177,12 @@ __global__ void __launch_bounds__(BSX_BLOCK) bsx_image_kernel(const image_args a
   }
   __syncthreads();
   if (a.radius_y > 0) {                            // uniform branches: the barriers are safe
-    img_gauss_pass(s_obs, s_tmp, a.in_rows, a.in_cols, 0, a.radius_y, a.gauss);
+    img_gauss_pass(s_obs, s_tmp, a.in_rows, a.in_cols, 0, a.radius_y, s_gauss[0]);
     __syncthreads();
     float* t = s_obs; s_obs = s_tmp; s_tmp = t;
   }
   if (a.radius_x > 0) {
-    img_gauss_pass(s_obs, s_tmp, a.in_rows, a.in_cols, 1, a.radius_x, a.gauss + (BSX_IMAGE_MAX_RADIUS + 1));
+    img_gauss_pass(s_obs, s_tmp, a.in_rows, a.in_cols, 1, a.radius_x, s_gauss[1]);
     __syncthreads();
     float* t = s_obs; s_obs = s_tmp; s_tmp = t;
   }
@@ -217,26 +225,6 @@ __global__ void __launch_bounds__(BSX_BLOCK) bsx_image_kernel(const image_args a
   }
 }
 
-// Device copy of the two half kernels of a configuration.  Configurations are few (one per wrapped
-// environment): a small cache keyed by the weights themselves; entries live until the process ends.
-struct img_gauss_entry { double w[2 * (BSX_IMAGE_MAX_RADIUS + 1)]; double* dev; };
-static const double* img_gauss_upload(const bsx_image_t* cfg, hipStream_t st) {
-  static std::vector<img_gauss_entry> cache;
-  static std::mutex mu;
-  img_gauss_entry e;
-  memset(e.w, 0, sizeof(e.w));
-  for (int j = 0; j <= cfg->radius_y; ++j) e.w[j] = cfg->gauss_y[j];
-  for (int j = 0; j <= cfg->radius_x; ++j) e.w[BSX_IMAGE_MAX_RADIUS + 1 + j] = cfg->gauss_x[j];
-  std::lock_guard<std::mutex> lock(mu);
-  for (const img_gauss_entry& c : cache)
-    if (memcmp(c.w, e.w, sizeof(e.w)) == 0) return c.dev;
-  if (hipMalloc((void**)&e.dev, sizeof(e.w)) != hipSuccess) return nullptr;
-  if (hipMemcpy(e.dev, e.w, sizeof(e.w), hipMemcpyHostToDevice) != hipSuccess) { (void)hipFree(e.dev); return nullptr; }
-  (void)st;
-  try { cache.push_back(e); } catch (...) { (void)hipFree(e.dev); return nullptr; }
-  return e.dev;
-}
-
 extern "C" int bsx_image_observation(const bsx_image_t* cfg, int64_t n_lanes, const float* obs, float* image,
                                      void* hip_stream) {
   if (cfg == nullptr) return BSX_ENULL;
@@ -260,7 +248,6 @@ extern "C" int bsx_image_observation(const bsx_image_t* cfg, int64_t n_lanes, co
   a.mode = cfg->mode; a.in_rows = cfg->in_rows; a.in_cols = cfg->in_cols;
   a.out_rows = cfg->out_rows; a.out_cols = cfg->out_cols; a.tail = cfg->tail;
   a.radius_y = filtered ? cfg->radius_y : 0; a.radius_x = filtered ? cfg->radius_x : 0;
-  a.gauss = nullptr;
   a.numel = (uint32_t)numel;
   a.tail_magic = bsx_div_magic((uint32_t)cfg->tail);
   a.cols_magic = bsx_div_magic((uint32_t)cfg->out_cols);
@@ -278,18 +265,17 @@ extern "C" int bsx_image_observation(const bsx_image_t* cfg, int64_t n_lanes, co
   const size_t lds = (size_t)(cfg->out_rows + cfg->out_cols) * (16 + 4) + (size_t)in_numel * 4 * (filtered ? 2 : 1);
   const dim3 grid((unsigned)blocks), block(BSX_BLOCK);
   hipStream_t st = (hipStream_t)hip_stream;
+  image_gauss gw;
+  memset(&gw, 0, sizeof(gw));
   if (filtered) {
-    // The half kernels live in a small device buffer owned by the library, uploaded (synchronously) the
-    // first time a configuration is seen and reused afterwards: later calls are asynchronous and
-    // capturable like every other entry point.  Down-scaling is the rare path of this adapter.
-    a.gauss = img_gauss_upload(cfg, st);
-    if (a.gauss == nullptr) return BSX_ENOMEM;
+    for (int j = 0; j <= cfg->radius_y; ++j) gw.w[0][j] = cfg->gauss_y[j];
+    for (int j = 0; j <= cfg->radius_x; ++j) gw.w[1][j] = cfg->gauss_x[j];
   }
   switch (k) {
-    case 2: bsx_image_kernel<2><<<grid, block, lds, st>>>(a); break;
-    case 8: bsx_image_kernel<8><<<grid, block, lds, st>>>(a); break;
-    case 16: bsx_image_kernel<16><<<grid, block, lds, st>>>(a); break;
-    default: bsx_image_kernel<4><<<grid, block, lds, st>>>(a); break;
+    case 2: bsx_image_kernel<2><<<grid, block, lds, st>>>(a, gw); break;
+    case 8: bsx_image_kernel<8><<<grid, block, lds, st>>>(a, gw); break;
+    case 16: bsx_image_kernel<16><<<grid, block, lds, st>>>(a, gw); break;
+    default: bsx_image_kernel<4><<<grid, block, lds, st>>>(a, gw); break;
   }
   return bsx_launch_status();
 }

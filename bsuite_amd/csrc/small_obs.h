@@ -63,10 +63,109 @@ struct bsx_bit_sink {
   }
 };
 
+// A table staged in LDS, typed as such: a generic pointer would make every read a FLAT load, which counts in vmcnt
+// AND lgkmcnt and drags a full `s_waitcnt vmcnt(0)` (a drain of the wave's stores) in front of its first use.
+typedef const float __attribute__((address_space(3)))* bsx_lds_table;
+
+// A lane's own thread stores its short row (<= 8 floats).  A wave's 64 rows are one contiguous range, written by
+// back-to-back instructions that the L2 merges line by line.
+__device__ __forceinline__ void small_obs_store_row(float* __restrict__ dst, const float* o, int numel) {
+  if ((numel & 1) == 0) {
+    float2* __restrict__ d2 = reinterpret_cast<float2*>(dst);
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+      if (2 * k < numel) d2[k] = make_float2(o[2 * k], o[2 * k + 1]);
+  } else if (numel == 3) {
+    // one 12-byte store per lane (global_store_dwordx3): a wave's 64 rows are 768 contiguous bytes
+    struct __attribute__((packed, aligned(4))) row3 { float a, b, c; };
+    row3 v; v.a = o[0]; v.b = o[1]; v.c = o[2];
+    *reinterpret_cast<row3*>(dst) = v;
+  } else {
+#pragma unroll
+    for (int k = 0; k < 7; ++k)                                   // numel == 1, 5, 7: 4-byte stores
+      if (k < numel) dst[k] = o[k];
+  }
+}
+
+// Fused T-step rollout of a family whose lane state fits in registers (cartpole, swing-up, mountain_car): ONE launch,
+// and nothing inside the step loop ever waits for memory —
+//  * the state AND the bsuite_info accumulators of the lane live in registers for the T steps (without the Logging
+//    wrapper, whose rows snapshot the columns): the episode-end read-modify-writes were `s_waitcnt vmcnt(0)` in the
+//    loop, i.e. a drain of every store the wave had in flight, on 6 steps in 10 (some lane of 64 ends an episode);
+//  * actions are loaded RUN steps at a time, ahead of the run: on gfx9 stores count in vmcnt too, so waiting for a
+//    one-step-ahead prefetch issued before a divergent number of stores also meant vmcnt(0) — once per step;
+//  * cartpole's time-fraction table sits in LDS (lgkmcnt) when it fits.
+// r02 (prefetch + in-loop RMW): 70 % of the wave cycles were waits, cartpole 15.1 us per step at 53 % VALU-busy
+// (profiles/r03/cartpole_rollout16_before_pmc_sq.json).
+template <class Env, int LOG, int NOISE, int MT, bool TAB>
+__device__ __forceinline__ void small_obs_regs_rollout(const typename Env::args& a, const int n_steps, const uint32_t block_id,
+                                                       float* s_dyn, unsigned int* s_cnt) {
+  constexpr bool IREGS = LOG == 0;
+  constexpr int RUN = 8;
+  if (threadIdx.x < 2) s_cnt[threadIdx.x] = 0;
+  // TAB: the family's table is staged in LDS (a compile-time fact inside the loop: were the source of a value
+  // decided at run time, the compiler would wait for the global load it MIGHT have been — vmcnt — at every use)
+  bsx_lds_table s_tab = (bsx_lds_table)0;
+  if constexpr (TAB) s_tab = Env::stage_tables(a, s_dyn);
+  __syncthreads();
+  const int numel = a.obs_numel;
+  const int64_t B = a.ctl.n_lanes;
+  const int64_t i = (int64_t)block_id * BSX_BLOCK + threadIdx.x;
+  const bool mine = i < B;
+  const uint64_t lane = a.ctl.lane_offset + (uint64_t)i;
+  const uint64_t step0 = bsx_step_of(a.ctl);
+  typename Env::regs rg;
+  if (mine) {
+    Env::load(a, i, rg);
+    if constexpr (IREGS) Env::load_info(a, i, rg);
+  }
+#pragma unroll 1
+  for (int t0 = 0; t0 < n_steps; t0 += RUN) {
+    int acts[RUN];
+#pragma unroll
+    for (int j = 0; j < RUN; ++j) acts[j] = (mine && t0 + j < n_steps) ? a.action[(int64_t)(t0 + j) * B + i] : 0;
+    // Everything loaded so far has landed before the run starts (vmcnt(0) lgkmcnt(0)): the compiler's wait insertion
+    // then knows that no register is waiting for memory inside the run — otherwise every first use of a
+    // conditionally loaded value (the swing-up info columns) gets its own vmcnt(0), and on gfx9 that is a drain of
+    // the STORES in flight as well.  One drain per RUN steps instead of several per step.
+    __builtin_amdgcn_s_waitcnt(0x0070);
+    // (a ROLLED loop: unrolled, the scheduler interleaves the steps and the kernel needs 140 VGPRs instead of ~75 —
+    // half the waves per SIMD, no gain, profiles/r03/ab_regs_rollout.log; the run's action is picked by selects)
+#pragma unroll 1
+    for (int j = 0; j < RUN; ++j) {
+      const int t = t0 + j;
+      int type = -1;
+      int act = acts[0];
+#pragma unroll
+      for (int q = 1; q < RUN; ++q) act = j == q ? acts[q] : act;
+      if (mine && t < n_steps) {
+        const int64_t oi = (int64_t)t * B + i;
+        double reward = 0.0;
+        float o[8];
+        type = Env::template core<LOG, MT, IREGS, TAB>(a, rg, act, i, lane, step0 + (uint64_t)t, o, reward, s_tab);
+        bsx_emit_at<LOG, NOISE>(a.ctl, a.out, i, oi, lane, step0 + (uint64_t)t, type, reward);
+        small_obs_store_row(a.out.observation + oi * (int64_t)numel, o, numel);
+      }
+      if (t < n_steps) bsx_count_types(a.ctl, type, s_cnt);             // uniform
+    }
+  }
+  if (mine) {
+    Env::store(a, i, rg);
+    if constexpr (IREGS) Env::store_info(a, i, rg);
+  }
+  __syncthreads();
+  bsx_flush_counts(a.ctl, s_cnt, block_id);
+}
+
 template <class Env, bool ROLLOUT, int LOG, int NOISE, int MT, bool DIRECT_ARG>
 __device__ __forceinline__ void small_obs_body(const typename Env::args& a, const int n_steps_arg,
                                                const uint32_t block_id, float* s_obs, unsigned int* s_cnt) {
   constexpr bool DIRECT = DIRECT_ARG || !Env::PACKED;
+  if constexpr (ROLLOUT && Env::HAS_REGS) {
+    if (Env::table_fits(a)) small_obs_regs_rollout<Env, LOG, NOISE, MT, true>(a, n_steps_arg, block_id, s_obs, s_cnt);   // uniform
+    else small_obs_regs_rollout<Env, LOG, NOISE, MT, false>(a, n_steps_arg, block_id, s_obs, s_cnt);
+    return;
+  }
   const int n_steps = ROLLOUT ? n_steps_arg : 1;   // the single-step instantiation has no loop: keeping
                                                     // every kernarg live across iterations costs ~120 VGPRs
   if (threadIdx.x < 2) s_cnt[threadIdx.x] = 0;
@@ -77,55 +176,22 @@ __device__ __forceinline__ void small_obs_body(const typename Env::args& a, cons
   const int64_t remaining = B - lane0;
   const int lanes_here = remaining < BSX_BLOCK ? (int)remaining : BSX_BLOCK;
   const uint64_t step0 = bsx_step_of(a.ctl);
-  // Fused rollout of a family with HAS_REGS: the lane's state lives in registers for the T steps and the
-  // action of step t+1 is in flight while step t computes.
-  constexpr bool REGS = ROLLOUT && Env::HAS_REGS;
   const bool mine = (int)threadIdx.x < lanes_here;
   const int64_t i = lane0 + threadIdx.x;
   const uint64_t lane = a.ctl.lane_offset + (uint64_t)i;
-  typename Env::regs rg;
-  int act_next = 0;
-  if constexpr (REGS) {
-    if (mine) {
-      Env::load(a, i, rg);
-      act_next = a.action[i];
-    }
-  }
 
 #pragma unroll 1
   for (int t = 0; t < n_steps; ++t) {
-    int act = 0;
-    if constexpr (REGS) {
-      act = act_next;
-      if (mine && t + 1 < n_steps) act_next = a.action[(int64_t)(t + 1) * B + i];
-    }
     const int64_t oi = (int64_t)t * B + i;
     int type = -1;
     if constexpr (DIRECT) {
-      // A wave's 64 rows are one contiguous range, written by back-to-back instructions that the L2 merges
-      // line by line; the waves of a block (and the steps of a fused rollout) never wait for each other.
+      // the waves of a block (and the steps of a fused rollout) never wait for each other
       if (mine) {
         double reward = 0.0;
         float o[8];
-        if constexpr (REGS) type = Env::template core<LOG, MT>(a, rg, act, i, lane, step0 + (uint64_t)t, o, reward);
-        else type = Env::template step<LOG, MT>(a, i, oi, lane, step0 + (uint64_t)t, o, reward);
+        type = Env::template step<LOG, MT>(a, i, oi, lane, step0 + (uint64_t)t, o, reward);
         bsx_emit_at<LOG, NOISE>(a.ctl, a.out, i, oi, lane, step0 + (uint64_t)t, type, reward);
-        float* __restrict__ dst = a.out.observation + oi * (int64_t)numel;
-        if ((numel & 1) == 0) {
-          float2* __restrict__ d2 = reinterpret_cast<float2*>(dst);
-#pragma unroll
-          for (int k = 0; k < 4; ++k)
-            if (2 * k < numel) d2[k] = make_float2(o[2 * k], o[2 * k + 1]);
-        } else if (numel == 3) {
-          // one 12-byte store per lane (global_store_dwordx3): a wave's 64 rows are 768 contiguous bytes
-          struct __attribute__((packed, aligned(4))) row3 { float a, b, c; };
-          row3 v; v.a = o[0]; v.b = o[1]; v.c = o[2];
-          *reinterpret_cast<row3*>(dst) = v;
-        } else {
-#pragma unroll
-          for (int k = 0; k < 7; ++k)                                   // numel == 1, 5, 7: 4-byte stores
-            if (k < numel) dst[k] = o[k];
-        }
+        small_obs_store_row(a.out.observation + oi * (int64_t)numel, o, numel);
       }
       bsx_count_types(a.ctl, type, s_cnt);
     } else {
@@ -211,9 +277,6 @@ __device__ __forceinline__ void small_obs_body(const typename Env::args& a, cons
       }
     }
   }
-  if constexpr (REGS) {
-    if (mine) Env::store(a, i, rg);
-  }
   __syncthreads();
   bsx_flush_counts(a.ctl, s_cnt, block_id);
 }
@@ -231,6 +294,12 @@ static size_t small_obs_lds(const typename Env::args& a) {
   if constexpr (Env::PACKED)     // PLANES data planes + the HEAD-position plane + the lanes' HEAD floats (padded)
     return bsx_small_direct_shape(a.obs_numel) ? 0 : (size_t)(Env::PLANES + 1) * a.obs_numel * (BSX_BLOCK / 32) * 4 + (size_t)(BSX_BLOCK * Env::HEAD + 8) * 4;
   else return 0;
+}
+// ... and of a fused rollout: the tables a register-resident family stages (cartpole: the time fractions)
+template <class Env>
+static size_t small_obs_rollout_lds(const typename Env::args& a) {
+  if constexpr (Env::HAS_REGS) return Env::table_bytes(a);
+  else return small_obs_lds<Env>(a);
 }
 
 // One workgroup of a grouped launch: the single-step body.  A segment without Logging wrapper, RewardNoise and
@@ -315,7 +384,7 @@ static int launch_small_obs(const typename Env::args& a, int n_steps, void* hip_
   const bool lean = !logging && !noise && a.ctl.mt_state == nullptr;
   const int64_t blocks = (a.ctl.n_lanes + BSX_BLOCK - 1) / BSX_BLOCK;
   if (blocks > 0x7FFFFFFF) return BSX_EINVAL;
-  const size_t lds = small_obs_lds<Env>(a);
+  const size_t lds = n_steps > 1 ? small_obs_rollout_lds<Env>(a) : small_obs_lds<Env>(a);
   const dim3 g((unsigned)blocks), b(BSX_BLOCK);
   // Per-thread stores (4-byte / 12-byte / 8-byte stores, each wave writing one contiguous range) against
   // an f32 LDS tile, measured on bandit, discounting_chain, cartpole, mountain_car, memory_len: eager equal
@@ -572,7 +641,27 @@ struct cartpole_env {
   // The lane's state in registers: step() = load + core + store; the fused rollout loads once, runs core
   // T times and stores once (small_obs_body), instead of a round trip through L2 every step.
   static constexpr bool HAS_REGS = true, PACKED = false;
-  struct regs { float x, xd, th, thd; int32_t sk; };
+  struct regs { float x, xd, th, thd; int32_t sk; double inf[4]; };     // inf: the info columns in a fused rollout
+  // Fused rollouts keep the time-fraction table in LDS when it is small (the default 1002 entries: 4 KiB)
+  static constexpr int TABLE_MAX_BYTES = 16384;
+  __host__ __device__ static bool table_fits(const args& a) { return ((int64_t)a.cfg.last_step + 1) * 4 <= TABLE_MAX_BYTES; }
+  static size_t table_bytes(const args& a) { return table_fits(a) ? ((size_t)a.cfg.last_step + 1) * 4 : 0; }
+  __device__ static __forceinline__ bsx_lds_table stage_tables(const args& a, float* s_dyn) {
+    const int n = a.cfg.last_step + 1;
+    for (int k = threadIdx.x; k < n; k += BSX_BLOCK) s_dyn[k] = a.cfg.time_frac[k];
+    return (bsx_lds_table)s_dyn;
+  }
+  __device__ static __forceinline__ void load_info(const args& a, int64_t i, regs& r) {
+    const int64_t B = a.ctl.n_lanes;
+    r.inf[0] = a.info[i]; r.inf[1] = a.info[B + i];
+    if (a.cfg.swingup) { r.inf[2] = a.info[2 * B + i]; r.inf[3] = a.info[3 * B + i]; }
+    else { r.inf[2] = 0.0; r.inf[3] = 0.0; }
+  }
+  __device__ static __forceinline__ void store_info(const args& a, int64_t i, const regs& r) {
+    const int64_t B = a.ctl.n_lanes;
+    a.info[i] = r.inf[0]; a.info[B + i] = r.inf[1];
+    if (a.cfg.swingup) { a.info[2 * B + i] = r.inf[2]; a.info[3 * B + i] = r.inf[3]; }
+  }
   __device__ static __forceinline__ void load(const args& a, int64_t i, regs& r) {
     const int64_t B = a.ctl.n_lanes;
     r.sk = a.steps[i];
@@ -592,18 +681,26 @@ struct cartpole_env {
     store(a, i, r);
     return type;
   }
-  template <int LOG, int MT>
+  // IREGS: the info columns are rg.inf[] (fused rollout without Logging), else read-modify-written in HBM.
+  // s_tf: the time-fraction table in LDS, or nullptr (-> g.time_frac in device memory).
+  template <int LOG, int MT, bool IREGS = false, bool TAB = false>
   __device__ static __forceinline__ int core(const args& a, regs& rg, const int act, int64_t i, uint64_t lane, uint64_t step,
-                                             float* o, double& reward) {
+                                             float* o, double& reward, bsx_lds_table s_tf = (bsx_lds_table)0) {
     BSX_NO_CONTRACT
     const int64_t B = a.ctl.n_lanes;
     const bsx_cartpole_t& g = a.cfg;
+    auto info_get = [&](int col) -> double { if constexpr (IREGS) return rg.inf[col]; else return a.info[(int64_t)col * B + i]; };
+    auto info_set = [&](int col, double v) { if constexpr (IREGS) rg.inf[col] = v; else a.info[(int64_t)col * B + i] = v; };
     const int32_t sk = rg.sk;
     const bool per_step_info = g.swingup || LOG == 1 || (LOG == -1 && a.ctl.log.steps != nullptr);
     int k = sk & 0x3FFFFFFF;
     float x, xd, th, thd, si, co;
     int type;
     if (a.ctl.force_reset || (sk & CP_RESET_BIT)) {             // cartpole.py:118-128 / swingup:81-91
+      // (Tried, not adopted — profiles/r03/ab_regs_rollout_scalar_reset_draws.log: walking the wave's few resetting
+      // lanes one at a time with wave-uniform inputs puts the Philox rounds on the scalar unit and cuts the vector
+      // instructions by 19 %, but the ~200-instruction dependent scalar chain per resetting lane stalls the wave
+      // longer than the divergent branch did: fused rollout 12.5 -> 14.7 us per step.)
       bsx_draws d;
       bsx_draws_begin<MT>(&d, a.ctl, i, lane, step);
       const double lo = -g.init_range, hi = g.init_range;
@@ -613,9 +710,9 @@ struct cartpole_env {
       thd = (float)(lo + (hi - lo) * bsx_uniform(&d));
       bsx_draws_end<MT>(&d, a.ctl, i);
       // an explicit reset() in mid-episode abandons it: the k rewards of 1 it has paid stay in raw_return
-      if (!per_step_info && !(sk & CP_RESET_BIT) && k > 0) a.info[i] += (double)k;
+      if (!per_step_info && !(sk & CP_RESET_BIT) && k > 0) info_set(0, info_get(0) + (double)k);
       k = 0;
-      if (per_step_info) a.info[2 * B + i] = 0.0;               // _episode_return = 0
+      if (per_step_info) info_set(2, 0.0);                      // _episode_return = 0
       bsx_sincosf(th, &si, &co);                               // |theta_offset| + init_range <= 32 (cartpole_make)
       type = BSX_FIRST;
     } else {
@@ -659,24 +756,24 @@ struct cartpole_env {
         const bool up = (co > g.height_threshold) && (fabsf(thd) < g.theta_dot_threshold) &&
                         (fabsf(x) < g.x_reward_threshold);
         r = -1.0 * fabs((double)(act - 1)) * g.move_cost;
-        if (up) { r += 1.0; a.info[3 * B + i] += 1.0; }
+        if (up) { r += 1.0; info_set(3, info_get(3) + 1.0); }
         end = timeout || (fabsf(x) > g.x_threshold);
       }
       reward = r;
       type = end ? BSX_LAST : BSX_MID;
       if (per_step_info) {
-        a.info[i] += r;                                         // _raw_return
-        const double ep = a.info[2 * B + i] + r;                // _episode_return
-        a.info[2 * B + i] = ep;
+        info_set(0, info_get(0) + r);                           // _raw_return
+        const double ep = info_get(2) + r;                      // _episode_return
+        info_set(2, ep);
         if (end) {
-          const double best = a.info[B + i];
-          a.info[B + i] = ep > best ? ep : best;                // max(episode_return, best_episode)
+          const double best = info_get(1);
+          info_set(1, ep > best ? ep : best);                   // max(episode_return, best_episode)
         }
       } else if (end) {
         const double ep = (double)(k - 1) + r;                  // sum of the episode's rewards, exact
-        a.info[i] += ep;
-        const double best = a.info[B + i];
-        a.info[B + i] = ep > best ? ep : best;
+        info_set(0, info_get(0) + ep);
+        const double best = info_get(1);
+        info_set(1, ep > best ? ep : best);
       }
     }
     rg.x = x; rg.xd = xd; rg.th = th; rg.thd = thd;
@@ -686,7 +783,9 @@ struct cartpole_env {
     o[2] = si;
     o[3] = co;
     o[4] = thd;
-    o[5] = g.time_frac[k < g.last_step ? k : g.last_step];
+    const int kf = k < g.last_step ? k : g.last_step;
+    if constexpr (TAB) o[5] = s_tf[kf];                         // the fused rollout's LDS copy
+    else o[5] = g.time_frac[kf];
     if (g.swingup) {                                            // swingup:147-149
       o[6] = (fabsf(x) < g.x_reward_threshold) ? 1.0f : -1.0f;
       o[7] = (fabsf(thd) < g.theta_dot_threshold) ? 1.0f : -1.0f;
@@ -705,7 +804,12 @@ struct mountain_car_env {
     double* info; int32_t obs_numel; int32_t max_steps;
   };
   static constexpr bool HAS_REGS = true, PACKED = false;
-  struct regs { float pos, vel; int32_t sk; };
+  struct regs { float pos, vel; int32_t sk; double inf0; };             // inf0: raw_return in a fused rollout
+  __host__ __device__ static bool table_fits(const args&) { return false; }
+  static size_t table_bytes(const args&) { return 0; }
+  __device__ static __forceinline__ bsx_lds_table stage_tables(const args&, float*) { return (bsx_lds_table)0; }
+  __device__ static __forceinline__ void load_info(const args& a, int64_t i, regs& r) { r.inf0 = a.info[i]; }
+  __device__ static __forceinline__ void store_info(const args& a, int64_t i, const regs& r) { a.info[i] = r.inf0; }
   __device__ static __forceinline__ void load(const args& a, int64_t i, regs& r) {
     r.sk = a.steps[i]; r.pos = a.state[i]; r.vel = a.state[a.ctl.n_lanes + i];
   }
@@ -721,19 +825,20 @@ struct mountain_car_env {
     store(a, i, r);
     return type;
   }
-  template <int LOG, int MT>
+  template <int LOG, int MT, bool IREGS = false, bool TAB = false>
   __device__ static __forceinline__ int core(const args& a, regs& rg, const int act, int64_t i, uint64_t lane, uint64_t step,
-                                             float* o, double& reward) {
+                                             float* o, double& reward, bsx_lds_table = (bsx_lds_table)0) {
     BSX_NO_CONTRACT
     const int32_t sk = rg.sk;
     int t = sk & 0x3FFFFFFF;
+    auto info_add = [&](double v) { if constexpr (IREGS) rg.inf0 += v; else a.info[i] += v; };
     float pos, vel;
     int type;
     if (a.ctl.force_reset || (sk & CP_RESET_BIT)) {             // mountain_car.py:66-71
       bsx_draws d;
       bsx_draws_begin<MT>(&d, a.ctl, i, lane, step);
       // an explicit reset() in mid-episode abandons it: its t rewards of -1 stay in raw_return
-      if (!(LOG == 1 || (LOG == -1 && a.ctl.log.steps != nullptr)) && !(sk & CP_RESET_BIT) && t > 0) a.info[i] -= (double)t;
+      if (!(LOG == 1 || (LOG == -1 && a.ctl.log.steps != nullptr)) && !(sk & CP_RESET_BIT) && t > 0) info_add(-(double)t);
       t = 0;
       pos = (float)(-0.6 + (-0.4 - -0.6) * bsx_uniform(&d));
       bsx_draws_end<MT>(&d, a.ctl, i);
@@ -751,8 +856,8 @@ struct mountain_car_env {
       pos = fminf(fmaxf(pos, -1.2f), 0.6f);                     // :83
       if (pos == -1.2f) vel = fminf(fmaxf(vel, 0.0f), 0.07f);   // :84-85
       type = (pos >= 0.5f || t >= a.max_steps) ? BSX_LAST : BSX_MID;   // :88-90
-      if (LOG == 1 || (LOG == -1 && a.ctl.log.steps != nullptr)) a.info[i] += reward;   // :76, per step under Logging
-      else if (type == BSX_LAST) a.info[i] -= (double)t;        // the episode's t rewards of -1, exact
+      if (LOG == 1 || (LOG == -1 && a.ctl.log.steps != nullptr)) info_add(reward);   // :76, per step under Logging
+      else if (type == BSX_LAST) info_add(-(double)t);          // the episode's t rewards of -1, exact
     }
     rg.pos = pos; rg.vel = vel;
     rg.sk = t | (type == BSX_LAST ? CP_RESET_BIT : 0);

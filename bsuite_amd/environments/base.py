@@ -395,12 +395,15 @@ class Environment(dm_env.EnvironmentBase):
     """Turns on per-lane steps/episode/return tracking and log-spaced snapshot rows.
 
     max_count: largest episode (or step) count to tabulate log points for (default 10^18: every
-    count a 63-bit counter can reach — 14 points per decade, a few hundred entries).
-    max_rows: snapshot rows kept per lane.  Default: every row a run of any length can produce at
-    log points — len(points) + 2, twice that with log_by_step (a log-point LAST and the FIRST after
-    it share one step count and both log, wrappers.py:96-102) — or 4096 with log_every in the
-    batched view; the scalar view hands each row to its logger right after the step and reuses the
-    buffer, so it never fills.  Rows past max_rows are counted, not stored: `Logging.rows()` raises."""
+    count a 63-bit counter can reach — 14 points per decade, a few hundred table entries, cheap).
+    max_rows: snapshot rows kept PER LANE — the rows tensor is B x max_rows x (5 + n_info) f64, so this is
+    what sizes the HBM footprint.  Default (batched view): the rows a run of 100 x bsuite_num_episodes
+    episodes (at least 10^4; by step: 10^3 x that many steps) produces at log points — + 2, twice that with
+    log_by_step (a log-point LAST and the FIRST after it share one step count and both log,
+    wrappers.py:96-102) — ~70 rows instead of the ~250 of every reachable count (at B = 2^20 that is 4 GB
+    instead of 14-30 GB per wrapped environment); 4096 with log_every.  The scalar view hands
+    each row to its logger right after the step and reuses the buffer, so it never fills.  Rows past
+    max_rows are counted, not stored, and `Logging.rows()` raises: pass max_rows / max_count for longer runs."""
     from bsuite_amd.utils import wrappers as _w  # pylint: disable=import-outside-toplevel
     self._ensure_allocated()
     if self._logging is None:
@@ -409,6 +412,7 @@ class Environment(dm_env.EnvironmentBase):
       # bring the columns up to date with the running episodes first.
       for j, pending in self._pending_info().items():
         self._info[j] += pending
+    explicit_count = max_count is not None
     if max_count is None:
       max_count = 10 ** 18
     points = _w.logarithmic_logging_points(max_count)
@@ -418,7 +422,9 @@ class Environment(dm_env.EnvironmentBase):
       elif log_every:
         max_rows = 4096
       else:
-        max_rows = (2 if log_by_step else 1) * len(points) + 2
+        horizon = max_count if explicit_count else (
+            max(10 ** 4, 100 * int(getattr(self, 'bsuite_num_episodes', 0) or 0)) * (1000 if log_by_step else 1))
+        max_rows = (2 if log_by_step else 1) * sum(1 for p_ in points if p_ <= horizon) + 2
     B, dev = self._batch, self._device
     n_info = len(self._info_keys)
     # scalar view: the one lane's counters and rows sit in mapped host memory like its TimeStep, so

@@ -38,6 +38,14 @@ class _RewardWrapper(dm_env.EnvironmentBase):
     if not isinstance(raw, base.Environment):
       raise TypeError('bsuite_amd reward wrappers fuse into a bsuite_amd environment kernel; got '
                       f'{type(env).__name__}')
+    if getattr(raw, '_logging', None) is not None:
+      # The fused Logging bookkeeping tracks the reward the kernel's epilogue returns, i.e. it always behaves as the
+      # OUTERMOST wrapper.  In the reference a Logging *inside* a reward wrapper records the un-perturbed rewards
+      # (utils/wrappers.py:74-77 sees the inner env's timestep): that composition would silently log other
+      # total_return / episode_return rows here, so it is refused.
+      raise NotImplementedError('a reward wrapper around an environment that is already wrapped in Logging would log '
+                                'the perturbed rewards here but the raw ones in the reference; wrap in this order: '
+                                'Logging(RewardNoise(env), ...)')
     self._env = env
     self._raw = raw
 

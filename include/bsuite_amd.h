@@ -350,7 +350,12 @@ typedef struct bsx_group bsx_group_t;
                                   two-kernel families and the whole step of the small-observation families —
                                   and, when its last workgroup retires, bumps the call counter itself (all
                                   segments must share one stream.step_base; do NOT bsx_counter_add it);
-                                  phase 1 is the one observation store stream of BSX_FAM_PAIR_MIXED */
+                                  phase 1 is the one observation store stream of BSX_FAM_PAIR_MIXED.
+                                  EXCLUSIVITY: the self-bump and the retirement ticket use plain (unfenced) device
+                                  accesses — every launch that reads or bumps that step_base (this group's steps,
+                                  eager step() calls of its segments, bsx_counter_add) must be STREAM-ORDERED with
+                                  the group's launches: same HIP stream, or an event between them.  Two groups
+                                  over one counter may alternate (bsx_group_step_pipelined) but never overlap.   */
 int bsx_group_create(int32_t family, int32_t n_segments, bsx_group_t** group);
 int bsx_group_set_deep_sea(bsx_group_t* g, int32_t index, const bsx_deep_sea_t* cfg, const bsx_call_t* call,
                            const int32_t* action, int32_t* state, bsx_timestep_t out, double* info);

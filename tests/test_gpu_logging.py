@@ -138,3 +138,16 @@ def test_state_dict_carries_logging_and_wrapper_state():
   plain = eu.make_env('catch', {}, batch=B, lane_offset=0, seed=4)
   with pytest.raises(ValueError):
     plain.load_state_dict(a.raw_env.state_dict())            # taken with Logging, loaded without
+
+
+def test_reward_wrapper_around_logging_is_refused():
+  """the fused Logging bookkeeping sees the reward the kernel's epilogue returns — it is always the
+  OUTERMOST wrapper.  RewardNoise(Logging(env)) would log raw rewards in the reference (utils/wrappers.py:74-77) and
+  perturbed ones here: refused instead of silently different."""
+  env = eu.make_env('catch', {}, batch=64, lane_offset=0, seed=1)
+  logged = wrappers.Logging(env, None)
+  with pytest.raises(NotImplementedError):
+    wrappers.RewardNoise(logged, noise_scale=0.5, seed=1)
+  with pytest.raises(NotImplementedError):
+    wrappers.RewardScale(logged, reward_scale=2.0, seed=1)
+  wrappers.Logging(wrappers.RewardNoise(eu.make_env('catch', {}, batch=64, lane_offset=0, seed=1), noise_scale=0.5, seed=1), None)

@@ -186,3 +186,63 @@ def test_pipelined_groups_refuse_the_other_schedules():
   assert first is outs[0] and batch.step_grouped() is outs[1] and batch.step_grouped() is outs[0]
   batch.sync()
   batch.release_groups()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('pipelined', [False, True])
+def test_action_ring_feeds_fresh_actions_every_group_step(tmp_path, pipelined):
+  """bsx_call_t.action_ring: every segment reads row (sweep step mod R) of a pre-generated [R, lanes] ring on the
+  device — 11 steps over a ring of 4 wrap it nearly three times — and reproduces stand-alone environments fed the
+  same rows by the host.  Rings that are not a power of two are refused."""
+  from bsuite_amd.utils import datasets
+  imgs, labels = gu.mnist_dataset()
+  datasets.write_idx_files(str(tmp_path), imgs.view(np.uint8), labels)
+  mn = dict(data_dir=str(tmp_path))
+  kw = dict(mnist=mn, mnist_noise=mn, mnist_scale=mn)
+  seed, reps, ring = 31, 11, 4
+  batch = sb.SweepBatch(IDS, len(IDS) * 300 + 1, seed=seed, env_kwargs=kw)
+  with pytest.raises(ValueError):
+    batch.random_actions(seed=1, ring=3)
+  bad = [torch.zeros((3, l), dtype=torch.int32, device='cuda') for _, _, l in batch.segments]
+  with pytest.raises(ValueError):
+    batch.prepare_groups(bad)
+  acts = batch.random_actions(seed=5, ring=ring)
+  assert all(a.shape == (ring, l) for a, (_, _, l) in zip(acts, batch.segments))
+  assert any(not torch.equal(a[0], a[1]) for a in acts)
+  batch.prepare_groups(acts, pipelined=pipelined)
+  for _ in range(reps):
+    outs = batch.step_grouped()
+  batch.sync()
+  for (bid, begin, lanes), a, out, env in zip(batch.segments, acts, outs, batch.envs):
+    name = bid.split('/')[0]
+    ekw = dict(kw.get(name, {}), seed=seed)
+    ref = bsuite_amd.load_from_id(bid, batch=lanes, lane_offset=begin, num_buffers=1, **ekw)
+    for s in range(reps):
+      ts = ref.step(a[s % ring])
+    for x, y in zip(eu.to_np(out), eu.to_np(ts)):
+      np.testing.assert_array_equal(x, y, err_msg=bid)
+  batch.release_groups()
+
+
+@pytest.mark.gpu
+def test_eager_and_grouped_steps_alternate_on_one_counter():
+  """a whole-sweep group bumps the shared call counter itself with plain device accesses; eager step()
+  calls of the same segments bump it with bsx_counter_add.  Stream-ordered (one HIP stream) the two may alternate
+  freely and every segment sees consecutive call indices."""
+  ids = ['catch/0', 'bandit/3', 'deep_sea/2', 'cartpole/1', 'umbrella_distract/12', 'memory_size/9']
+  seed = 9
+  batch = sb.SweepBatch(ids, len(ids) * 500, seed=seed)
+  acts = batch.random_actions(seed=2)
+  batch.prepare_groups(acts)
+  pattern = 'gegggeegge'
+  for c in pattern:
+    outs = batch.step_grouped() if c == 'g' else batch.step(acts)
+  batch.sync()
+  assert int(batch._step_counter.item()) == len(pattern)
+  for (bid, begin, lanes), a, out in zip(batch.segments, acts, outs):
+    ref = bsuite_amd.load_from_id(bid, batch=lanes, lane_offset=begin, num_buffers=1, seed=seed)
+    for _ in pattern:
+      ts = ref.step(a)
+    for x, y in zip(eu.to_np(out), eu.to_np(ts)):
+      np.testing.assert_array_equal(x, y, err_msg=bid)
+  batch.release_groups()
