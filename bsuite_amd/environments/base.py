@@ -23,7 +23,6 @@ for the reference's run loop, which holds `timestep` and `new_timestep`
 There is no CPU fallback: without a HIP device the first reset()/step() raises.
 """
 import contextlib
-import os
 import secrets
 from typing import Any, Dict, Optional
 
@@ -63,6 +62,8 @@ class Environment(dm_env.EnvironmentBase):
   _supports_delta = False  # families whose observation is a board with <= 2 hot cells
   _pipelined_rollout = False  # two-kernel families whose rollouts are software-pipelined (state_alt)
   _state_alt = None
+  scalar_host_buffers = True   # scalar view: TimeStep / action buffers in pinned host memory mapped into the device (class
+                               # attribute: set False before the first step to A/B against device buffers + read-backs)
   _info_keys = ()          # names of the f64 info columns, in native column order
   _info_int_keys = ()      # keys the reference reports as Python ints
 
@@ -289,7 +290,7 @@ class Environment(dm_env.EnvironmentBase):
       # Scalar view: TimeStep buffers and the action live in pinned host memory, which HIP maps into
       # the device address space — the kernels write the TimeStep straight into host RAM and a step
       # costs one stream synchronisation instead of a fill kernel + four device-to-host reads.
-      self._host_out = self._scalar and os.environ.get('BSX_SCALAR_HOST_BUFFERS', '1') != '0'
+      self._host_out = self._scalar and self.scalar_host_buffers
       place = dict(pin_memory=True) if self._host_out else dict(device=dev)
       for _ in range(self._num_buffers):
         o = dict(

@@ -161,7 +161,7 @@ class SweepBatch:
 
   # -- grouped launches --------------------------------------------------------------------
   def prepare_groups(self, actions: Sequence[torch.Tensor], mix_small: bool = True, mix_pairs: bool = True,
-                     mix_all: bool = True, pipelined: bool = False):
+                     mix_all: bool = True, pipelined: bool = False, heavy_first: bool = True):
     """Builds the launch groups.  With `mix_all` (default) ONE group for the whole sweep
     (BSX_FAM_SWEEP_MIXED): a sweep step is two launches — phase 0 advances every lane of every family
     and bumps the shared call counter, phase 1 is the observation store stream of the two-kernel
@@ -205,8 +205,6 @@ class SweepBatch:
     outs_of = [outs, [None] * len(self.envs)]
     self._state_alt = {}
     costs = []
-    import os  # pylint: disable=import-outside-toplevel
-    heavy_first = os.environ.get('BSX_SWEEP_HEAVY_FIRST', '1') != '0'
     for (name, _), members in sorted(buckets.items()):
       if name == 'sweep_mixed' and heavy_first:
         # Phase 0 ends when its slowest workgroup retires: put the long-running ones — wide observation rows
@@ -281,7 +279,7 @@ class SweepBatch:
     return self._group_outs
 
   # -- eager two-stream schedule ----------------------------------------------------------
-  def step_grouped_streams(self):
+  def step_grouped_streams(self, small_beside: str = 'advance'):
     """One sweep step, eager, on HIP streams owned by the batch (no graph).  Two phases, separated by what
     bounds the kernels:
       1. everything latency-bound at once — the advance kernel of the two-kernel families on the `pipe`
@@ -305,8 +303,7 @@ class SweepBatch:
       self._small = self._smalls[0]
       self._ev_adv, self._ev_bump, self._ev_stream = torch.cuda.Event(), torch.cuda.Event(), torch.cuda.Event()
       self._ev_small = [torch.cuda.Event() for _ in self._smalls]
-      import os  # pylint: disable=import-outside-toplevel
-      self._small_beside_stream = os.environ.get('BSX_SWEEP_SMALL_BESIDE', 'advance') == 'stream'
+      self._small_beside_stream = small_beside == 'stream'      # A/B: small groups beside the store stream (slower)
       for st in [self._pipe] + self._smalls:
         st.wait_stream(cur)
       first = True

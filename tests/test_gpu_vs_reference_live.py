@@ -23,7 +23,8 @@ from tests import engine_util as eu
 pytestmark = pytest.mark.gpu
 
 
-N_CHUNKS, CASES_PER_CHUNK = 8, 30
+# BSX_LIVE_CASES=<n per chunk> scales the run (tools/profiles.sh logs a 2000-case run under profiles/rNN/)
+N_CHUNKS, CASES_PER_CHUNK = 8, int(os.environ.get('BSX_LIVE_CASES', '30'))
 
 
 @pytest.fixture(scope='module')

@@ -16,17 +16,20 @@ timeout 400 python tools/kernel_stats.py $out/bench_headline_kernel_stats.csv --
 timeout 400 python tools/kernel_stats.py $out/bench_catch_kernel_stats.csv -- --workload catch --steps 200 --warmup 20 $A > /dev/null 2>>$out/kernel_stats.err
 timeout 400 python tools/kernel_stats.py $out/bench_sweep_kernel_stats.csv --last 100 -- --workload sweep --steps 100 --warmup 20 > /dev/null 2>>$out/kernel_stats.err
 # HBM traffic (WRITE_SIZE / FETCH_SIZE, separate passes) of every BASELINE config
-pm() { timeout 500 python tools/pmc.py "$@" 2>&1 | tail -1; }
+pm() { timeout 240 python tools/pmc.py "$@" 2>&1 | tail -1; }
 pm traffic deep_sea $out/deep_sea_pmc_traffic.json --kernels "bsx_advance_kernel<deep_sea_fam" "bsx_hot_stream_kernel<deep_sea_hot" --alg-bytes $((3621*B)) -- --steps 20 --warmup 4 $A --workload deep_sea
 pm traffic catch $out/catch_pmc_traffic.json --kernels "bsx_fused_tile_kernel<catch_fam" --alg-bytes $((221*B)) -- --steps 20 --warmup 4 $A --workload catch
 pm traffic cartpole $out/cartpole_pmc_traffic.json --kernels "small_obs_kernel<cartpole_env" --alg-bytes $((85*B)) -- --steps 20 --warmup 4 $A --workload cartpole
-pm traffic mountain_car $out/mountain_car_pmc_traffic.json --kernels "small_obs_kernel<mountain_car_env" --alg-bytes $((49*B)) -- --steps 20 --warmup 4 $A --workload mountain_car
+# (mountain_car lock-step: staggering its 1001-call episodes is ~10^4 torch launches, minutes under a PMC pass; in 24
+#  calls no lane resets either way)
+pm traffic mountain_car $out/mountain_car_pmc_traffic.json --kernels "small_obs_kernel<mountain_car_env" --alg-bytes $((49*B)) -- --steps 20 --warmup 4 $A --no-stagger --workload mountain_car
 pm traffic sweep_closed $out/sweep_closed_pmc_traffic.json --kernels sweep_phase0_kernel pair_mixed_stream_kernel --alg-bytes 885580000 --last 40 -- --workload sweep --steps 40 --warmup 10
 pm traffic sweep_pipelined $out/sweep_pipelined_pmc_traffic.json --kernels sweep_pipelined_kernel --alg-bytes 885580000 --last 40 -- --workload sweep --steps 40 --warmup 10
 # issue-side counters of the fused rollouts (bound "valu") and of the eager physics steps
 for w in cartpole mountain_car; do
-  pm sq ${w}_rollout16 $out/${w}_rollout16_pmc_sq.json --kernels "small_obs_kernel<${w}_env, true" --last 4 -- --workload $w --rollout 16 --steps 64 --warmup 16 $A
-  pm sq ${w}_eager $out/${w}_eager_pmc_sq.json --kernels "small_obs_kernel<${w}_env, false" -- --workload $w --steps 20 --warmup 4 $A
+  ns=""; [ $w = mountain_car ] && ns="--no-stagger"
+  pm sq ${w}_rollout16 $out/${w}_rollout16_pmc_sq.json --kernels "small_obs_kernel<${w}_env, true" --last 4 -- --workload $w --rollout 16 --steps 64 --warmup 16 $A $ns
+  pm sq ${w}_eager $out/${w}_eager_pmc_sq.json --kernels "small_obs_kernel<${w}_env, false" -- --workload $w --steps 20 --warmup 4 $A $ns
 done
 if [ "${1:-}" != quick ]; then
   for w in bandit discounting_chain memory_len umbrella_length umbrella_distract memory_size cartpole mountain_car catch deep_sea mnist; do
@@ -36,6 +39,8 @@ import sys,json; d=json.loads(sys.stdin.read()); r=d['roofline']; print('%-18s e
   timeout 400 python tools/strong_scaling_proxy.py $out/strong_scaling_proxy.json > $out/strong_scaling_proxy.log 2>&1
   BSX_BENCH_BACKEND=gloo BSX_BENCH_SINGLE_DEVICE=1 timeout 400 python bench.py --gpus 2 --no-cpu-baseline 2>/dev/null | grep '^{' > $out/bench_2ranks_on_one_gpu_gloo.json
   timeout 300 python tools/physics_error.py > $out/physics_error.log 2>&1; cp gpurun_out/physics_error.json $out/ 2>/dev/null
-  timeout 240 python tools/fuzz_gpu.py --seconds 150 --seed 3 > $out/fuzz_gpu.log 2>&1; tail -1 $out/fuzz_gpu.log
+  timeout 240 python tools/fuzz_gpu.py --seconds 120 --seed 3 > $out/fuzz_gpu.log 2>&1; tail -1 $out/fuzz_gpu.log
+  # the engine against the UNMODIFIED reference, live: 8 x 250 random cases (families, kwargs, wrappers, resets, policies)
+  ( BSX_LIVE_CASES=250 timeout 600 python -m pytest tests/test_gpu_vs_reference_live.py -q -m gpu ) > $out/live_reference_2000_cases.log 2>&1; tail -2 $out/live_reference_2000_cases.log
 fi
 ls -la $out
