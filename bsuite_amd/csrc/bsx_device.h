@@ -247,15 +247,16 @@ struct bsx_group_index {
   int n;
 };
 
-struct bsx_group_slot { int seg; uint32_t block; };
+struct bsx_group_slot { int seg; uint32_t block; int tag; };   // tag: the segment's family in a mixed group, -1 = look it up
 
 __device__ __forceinline__ bsx_group_slot bsx_group_find(const bsx_group_index& gi, int b) {
   bsx_group_slot r;
   if (gi.map != nullptr) {
     const int2 v = gi.map[b];
-    r.seg = v.x; r.block = (uint32_t)v.y;
+    r.seg = v.x & 0x00FFFFFF; r.block = (uint32_t)v.y; r.tag = ((v.x >> 24) & 0x7F) - 1;
     return r;
   }
+  r.tag = -1;
   int lo = 0, hi = gi.n;         // invariant: start[lo] <= b < start[hi]
   while (hi - lo > 1) {
     const int mid = (lo + hi) >> 1;
@@ -369,6 +370,9 @@ __device__ __forceinline__ void bsx_hot_stream_body(float* __restrict__ obs,
   int r0[K];
   int32_t s0[K], s1[K];
   bool live[K];
+  // (One state load per WAVE — lane j fetches row (first row of the wave) + j — handed to the chunks through
+  // ds_bpermute instead of one mostly redundant load per chunk: 7 % slower, deep_sea 593 -> 636 us; the K stores then
+  // all hang on one load + a cross-lane hop.  profiles/r03/ab_stream_wave_state_load.log)
 #pragma unroll
   for (int u = 0; u < K; ++u) {
     // chunk within the block: each wave owns K consecutive KiB (store u of wave w covers KiB

@@ -155,7 +155,13 @@ static int group_commit(bsx_group* g) {
     std::vector<int2> map((size_t)total);
     size_t w = 0;
     for (int i = 0; i < g->n; ++i)
-      for (int32_t b = 0; b < blocks[i]; ++b) { map[w].x = i; map[w].y = b; ++w; }
+      // the segment's family tag rides in the top byte of the entry (mixed groups): the workgroup then needs ONE
+      // load, not map entry -> tag, before it can fetch its argument slot
+      for (int32_t b = 0; b < blocks[i]; ++b) {
+        map[w].x = i | ((g->tags.empty() ? 0 : ((g->tags[i] + 1) & 0x7F)) << 24);   // tag + 1; 0 = none
+        map[w].y = b;
+        ++w;
+      }
     rc = upload(map.data(), map.size() * sizeof(int2), (void**)(pass == 0 ? &g->d_map : &g->d_map2));
   }
   if (rc != 0) return rc;

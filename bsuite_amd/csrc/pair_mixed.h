@@ -35,7 +35,7 @@ __device__ __forceinline__ void pair_mixed_stream_body(const uint8_t* __restrict
                                                        const bsx_group_index& gi, uint32_t block, float* s_lut) {
   const bsx_group_slot w = bsx_group_find(gi, (int)block);
   const uint8_t* slot = table + (size_t)w.seg * BSX_MIXED_STR_STRIDE;
-  switch (family[w.seg] & 0xFF) {                   // uniform per workgroup
+  switch (w.tag >= 0 ? w.tag : (family[w.seg] & 0xFF)) {   // uniform per workgroup
     case BSX_FAM_DEEP_SEA: {
       const bsx_stream_seg<deep_sea_hot>& g = *reinterpret_cast<const bsx_stream_seg<deep_sea_hot>*>(slot);
       bsx_hot_stream_body<deep_sea_hot, 4, BSX_BLOCK>(g.obs, g.state, g.n_lanes, g.cells, g.cells_magic, g.dv, g.fn, w.block);

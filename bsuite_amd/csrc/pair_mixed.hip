@@ -32,7 +32,7 @@ __global__ void __launch_bounds__(BSX_BLOCK) pair_mixed_advance_kernel(const uin
   __shared__ unsigned int s_cnt[2];
   const bsx_group_slot w = bsx_group_find(gi, (int)blockIdx.x);
   const uint8_t* slot = table + (size_t)w.seg * PAIR_ADV_STRIDE;
-  switch (family[w.seg] & 0xFF) {                   // uniform per workgroup
+  switch (w.tag >= 0 ? w.tag : (family[w.seg] & 0xFF)) {   // uniform per workgroup
     case BSX_FAM_DEEP_SEA: bsx_advance_body<deep_sea_fam>(*reinterpret_cast<const deep_sea_fam::args*>(slot), w.block, s_ds, s_cnt); break;
     case BSX_FAM_CATCH: bsx_advance_body<catch_fam>(*reinterpret_cast<const catch_fam::args*>(slot), w.block, s_ca, s_cnt); break;
     case BSX_FAM_MNIST: mnist_advance_body(*reinterpret_cast<const mnist_args*>(slot), w.block, s_cnt); break;

@@ -17,7 +17,7 @@ __global__ void __launch_bounds__(BSX_BLOCK) small_obs_mixed_group_kernel(const 
   const uint8_t* slot = table + (size_t)seg * SMALL_MIXED_STRIDE;
 #define SMALL_MIXED_CASE(FAM, ENV) \
   case FAM: small_obs_group_body<ENV>(*reinterpret_cast<const ENV::args*>(slot), blk, s_obs, s_cnt); break;
-  switch (family[seg]) {                           // uniform per workgroup
+  switch (w.tag >= 0 ? w.tag : family[seg]) {      // uniform per workgroup
     SMALL_MIXED_CASE(BSX_FAM_BANDIT, bandit_env)
     SMALL_MIXED_CASE(BSX_FAM_MEMORY_CHAIN, memory_chain_env)
     SMALL_MIXED_CASE(BSX_FAM_UMBRELLA_CHAIN, umbrella_chain_env)
@@ -50,7 +50,7 @@ __device__ __forceinline__ void sweep_phase0_body(const uint8_t* __restrict__ ta
                                                   const uint32_t block, const uint32_t n_blocks, float* s_obs,
                                                   unsigned int* s_cnt, deep_sea_fam::shared& s_ds, catch_fam::shared& s_ca) {
   const bsx_group_slot w = bsx_group_find(gi, (int)block);
-  const int tag = tags[w.seg];                       // uniform per workgroup
+  const int tag = w.tag >= 0 ? w.tag : tags[w.seg];  // uniform per workgroup
   const uint32_t blk = w.block;
   const uint8_t* slot = table + (size_t)w.seg * BSX_MIXED_ADV_STRIDE;
 #define SWEEP_SMALL_CASE(FAM, ENV) \

@@ -34,11 +34,14 @@ SQ_PASSES = (['SQ_WAVES', 'SQ_INSTS_VALU', 'SQ_INSTS_SALU', 'SQ_ACTIVE_INST_VALU
               'SQ_INSTS_VMEM_RD', 'GRBM_GUI_ACTIVE'])
 
 
+SCRIPT = [os.path.join(ROOT, 'bench.py')]
+
+
 def one_pass(counters, bench_args, wanted, last):
   """{kernel: {counter: mean over its last `last` dispatches}, '_n': dispatches used, '_dur_ns': mean duration}."""
   out = tempfile.mkdtemp(prefix='pmc_', dir='/tmp')
   cmd = ['timeout', '600', 'rocprofv3', '--pmc'] + list(counters) + ['--kernel-trace', '--output-format', 'csv', '-d', out, '--',
-         sys.executable, os.path.join(ROOT, 'bench.py')] + bench_args
+         sys.executable] + SCRIPT + bench_args
   p = subprocess.run(cmd, cwd='/tmp', env=dict(os.environ, TMPDIR='/tmp'), stdout=subprocess.PIPE, stderr=subprocess.PIPE,
                      text=True, check=False)
   rows = collections.defaultdict(lambda: collections.defaultdict(dict))          # kernel -> dispatch -> counter -> value
@@ -80,9 +83,12 @@ def main():
   ap.add_argument('--alg-bytes', type=float, default=0.0)
   ap.add_argument('--lanes', type=int, default=1 << 20)
   ap.add_argument('--last', type=int, default=0)
+  ap.add_argument('--script', default=None, help='profile this python script instead of bench.py (needs --last)')
   sep = sys.argv.index('--', 2)
   args = ap.parse_args(sys.argv[1:sep])
   bench_args = sys.argv[sep + 1:]
+  if args.script:
+    SCRIPT[0] = os.path.abspath(args.script)
   last = args.last or int(bench_args[bench_args.index('--steps') + 1])
   doc = dict(name=args.name, lanes=args.lanes, last_dispatches_per_kernel=last,
              command='rocprofv3 --pmc <one group per run> --kernel-trace --output-format csv -- python bench.py ' + ' '.join(bench_args)
