@@ -278,13 +278,17 @@ static int bsx_pair_call(const typename Fam::args& a0, const bsx_call_t* call, c
   int rc = 0;
   // Boards of at most BSX_FUSED_TILE_MAX_CELLS floats (catch's 50; a workgroup's [256 x cells] tile is then <= 128 KiB):
   // ONE fused launch per step (bsx_fused_tile_kernel) and ONE per rollout (bsx_fused_rollout_kernel) while the
-  // observation array of a step is at most BSX_FUSED_TILE_MAX_MIB / BSX_FUSED_ROLLOUT_MAX_MIB — measured crossovers,
-  // profiles/r03/ab_fused_tile*.log; deep_sea N=30 (900 cells, 0.9 MiB tiles) never fuses.  The tile start
+  // observation array of a step is at most BSX_FUSED_TILE_MAX_MIB / BSX_FUSED_ROLLOUT_MAX_MIB = 128 MiB: catch up to
+  // 2^19 lanes (105 MB: 20 vs 23 us eager, 20 vs 22 us per rollout step; 2^17: 9.4 vs 11 and 7.1 vs 9.0).  At 2^20
+  // lanes (210 MB) the winner depends on the box — fused 41.9 vs 43.5 on one, 44.4-45.2 vs 43.2-43.6 on another; a
+  // rollout 36.9 vs 39.6 and 43.4-45.5 vs 39.7-40.9 (its T slices lie 210 MB apart: page-mapping luck) — so the
+  // decoupled pair / the pipelined rollout, steady within 2 % everywhere, keep that size (profiles/r03/
+  // ab_fused_tile*.log, ab_fused_crossover.log); deep_sea N=30 (900 cells, 0.9 MiB tiles) never fuses.  The tile start
   // block*256*cells*4 is always 16-byte aligned when the slice is.  (A barrier-free variant — every wave its own
   // 64 lanes, neighbour states through ds_bpermute — measured 1-9 % slower: profiles/r03/ab_fused_wave.log.)
   static const int fused_cells = bsx_env_int("BSX_FUSED_TILE_MAX_CELLS", 128);
-  static const int fused_step_mib = bsx_env_int("BSX_FUSED_TILE_MAX_MIB", 256);
-  static const int fused_roll_mib = bsx_env_int("BSX_FUSED_ROLLOUT_MAX_MIB", 256);
+  static const int fused_step_mib = bsx_env_int("BSX_FUSED_TILE_MAX_MIB", 128);
+  static const int fused_roll_mib = bsx_env_int("BSX_FUSED_ROLLOUT_MAX_MIB", 128);
   const int64_t step_bytes = B * (int64_t)cells * 4;
   const bool fusable = call->obs_paint == nullptr && cells >= 4u && (int)cells <= fused_cells &&
                        (((uint64_t)B * cells) & 3ull) == 0 && (reinterpret_cast<uintptr_t>(out.observation) & 15u) == 0;

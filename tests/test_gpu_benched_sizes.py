@@ -106,23 +106,26 @@ def test_config5_full_sweep_as_benched(tmp_path, pipelined):
   batch.release_groups()
 
 
-def _subsample(rng, n=4096):
+def _subsample(rng, n=4096, B=B):
   idx = np.unique(np.concatenate([rng.integers(0, B, size=n), [0, 1, 63, 64, 255, 256, B - 1]]))
   return idx.astype(np.int64)
 
 
 @pytest.mark.timeout(900)
-@pytest.mark.parametrize('family,kwargs,na,T,warm', [('deep_sea', dict(size=30, mapping_seed=42), 2, 16, 20),
-                                                     ('catch', dict(), 3, 32, 3)])
-def test_pipelined_rollout_as_benched(family, kwargs, na, T, warm):
-  """`rollout(actions[T, 2^20])` of the two-kernel families, software-pipelined (T+1 launches, two state columns):
-  after `warm` eager steps, two consecutive rollouts — deep_sea's cross the episode end at call 31 — compared on a
-  4096-lane subsample with the oracle on every step, plus size-independent invariants over all 2^20 lanes."""
+@pytest.mark.parametrize('family,kwargs,na,T,warm,B', [('deep_sea', dict(size=30, mapping_seed=42), 2, 16, 20, 1 << 20),
+                                                       ('catch', dict(), 3, 32, 3, 1 << 20),
+                                                       ('catch', dict(), 3, 32, 3, 1 << 19)])
+def test_pipelined_rollout_as_benched(family, kwargs, na, T, warm, B):
+  """`rollout(actions[T, B])` of the two-kernel families at the benched sizes: software-pipelined at 2^20 lanes (T+1
+  launches, two state columns); catch at 2^19 lanes (a rank's share of a 2-GPU strong-scaled run) is the largest batch
+  that takes the fused ONE-launch rollout (bsx_fused_rollout_kernel).  After `warm` eager steps, two consecutive
+  rollouts — deep_sea's cross the episode end at call 31 — compared on a 4096-lane subsample with the oracle on every
+  step, plus size-independent invariants over all lanes."""
   seed = 11
   env = eu.make_env(family, kwargs, batch=B, lane_offset=0, seed=seed, num_buffers=1)
   assert eu.raw(env)._pipelined_rollout
   rng = np.random.default_rng(3)
-  idx = _subsample(rng)
+  idx = _subsample(rng, B=B)
   idx_t = torch.from_numpy(idx).cuda()
   orc = coracle.OracleEnv(family, kwargs, idx.astype(np.uint64), seed=seed)
   g = torch.Generator(device='cuda'); g.manual_seed(9)
