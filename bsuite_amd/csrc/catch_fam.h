@@ -7,6 +7,14 @@
 #include "bsx_device.h"
 
 #define CATCH_RESET_BIT (1 << 24)
+// Bits 25..31 of the packed state: misses not yet folded into the total_regret column (ABI v10).  A miss costs
+// regret 2, a catch 0 (catch.py:92-94), so the column is an exact function of the number of misses: without the
+// Logging wrapper (whose rows snapshot the column) the lane counts its misses in the state word it rewrites anyway and
+// adds 2*127 to the f64 column once per 127 misses, instead of read-modify-writing the column on every episode end —
+// in steady state that touched EVERY line of the column on every call (17 of the advance's 37 MB at 2^20 lanes) and
+// put a memory round trip in the middle of every wave's advance.  total_regret = info + 2 * pending.
+#define CATCH_PENDING_SHIFT 25
+#define CATCH_PENDING_MAX 127
 
 struct catch_fam {
   struct args {
@@ -27,6 +35,8 @@ struct catch_fam {
                                                 double& reward) {
     const int rows = a.rows, cols = a.columns;
     int ball_x = st & 0xFF, ball_y = (st >> 8) & 0xFF, paddle_x = (st >> 16) & 0xFF;
+    uint32_t pending = ((uint32_t)st >> CATCH_PENDING_SHIFT) & 0x7Fu;
+    const bool fold = LEAN || a.ctl.log.steps == nullptr;      // uniform
     int type;
     reward = 0.0;
     if (a.ctl.force_reset || (st & CATCH_RESET_BIT)) {         // catch.py:80-81 -> :68-76
@@ -45,16 +55,20 @@ struct catch_fam {
       ball_y += 1;                                              // :88
       if (ball_y == rows - 1) {                                 // :91-95
         reward = (paddle_x == ball_x) ? 1.0 : -1.0;
-        // (a fire-and-forget global_atomic_add_f64 instead of this read-modify-write — exact, the increments are 0 / 2 —
-        // saves the lane a memory round trip but costs the L2 100k scattered 8-byte atomics per step: catch 45.0 -> 50.4 us
-        // at 2^20 lanes, profiles/r03/ab_info_atomics.log)
-        a.info[i] += (1.0 - reward);
+        if (!fold) {
+          a.info[i] += (1.0 - reward);                          // :94 (per episode under the Logging wrapper)
+        } else if (paddle_x != ball_x) {
+          // (also tried: a fire-and-forget global_atomic_add_f64 per miss — 100k scattered 8-byte atomics per step cost
+          // the L2 more than the round trip cost the wave: 45.0 -> 50.4 us at 2^20 lanes, profiles/r03/ab_info_atomics.log)
+          if (++pending == CATCH_PENDING_MAX) { a.info[i] += 2.0 * CATCH_PENDING_MAX; pending = 0; }
+        }
         type = BSX_LAST;
       } else {
         type = BSX_MID;                                         // :97
       }
     }
-    nst = ball_x | (ball_y << 8) | (paddle_x << 16) | (type == BSX_LAST ? CATCH_RESET_BIT : 0);
+    nst = (int32_t)((uint32_t)(ball_x | (ball_y << 8) | (paddle_x << 16) | (type == BSX_LAST ? CATCH_RESET_BIT : 0)) |
+                    (pending << CATCH_PENDING_SHIFT));
     return type;
   }
 };

@@ -31,6 +31,11 @@ class Catch(base.Environment):
   def _state_tensors(self):
     return dict(state=torch.full((self._batch,), 1 << 24, dtype=torch.int32, device=self._device))
 
+  def _pending_info(self):
+    # Without the Logging wrapper the kernel counts a lane's misses in bits 25..31 of its packed state and adds
+    # 2 * 127 to the total_regret column once per 127 misses (csrc/catch_fam.h); a miss costs regret 2 (catch.py:92-94).
+    return {0: 2.0 * ((self._state['state'] >> 25) & 0x7F).to(torch.float64)}
+
   _abi_name = 'catch'
   _supports_delta = True
   _pipelined_rollout = True

@@ -210,8 +210,11 @@ typedef struct {
   int32_t rows;     /* catch.py:46 (default 10); 2..64 */
   int32_t columns;  /* catch.py:47 (default 5);  1..64 */
 } bsx_catch_t;
-/* state: int32 [B] = ball_x | ball_y<<8 | paddle_x<<16 | reset_next<<24 (initialise to 1<<24)
- * info : double [1,B] = total_regret (catch.py:116-117)
+/* state: int32 [B] = ball_x | ball_y<<8 | paddle_x<<16 | reset_next<<24 | pending_misses<<25 (initialise to 1<<24)
+ * info : double [1,B] = total_regret (catch.py:116-117).  Accounting (ABI v10): with call->logging the column is
+ *        updated at every episode end like the reference.  Without it the lane counts its misses (regret 2 each, a
+ *        catch costs 0: catch.py:92-94) in bits 25..31 of the state word and adds 2*127 to the column once per 127
+ *        misses: the reference's value is  info[0][i] + 2 * ((uint32_t)state[i] >> 25).
  * obs  : float [B, rows, columns] */
 int bsx_catch_step(const bsx_catch_t* cfg, const bsx_call_t* call, const int32_t* action,
                    int32_t* state, bsx_timestep_t out, double* info);
