@@ -413,6 +413,7 @@ class Environment(dm_env.EnvironmentBase):
       # bring the columns up to date with the running episodes first.
       for j, pending in self._pending_info().items():
         self._info[j] += pending
+      self._clear_pending_info()
     explicit_count = max_count is not None
     if max_count is None:
       max_count = 10 ** 18
@@ -603,6 +604,10 @@ class Environment(dm_env.EnvironmentBase):
     so far in columns that the kernel folds into `_info` only at episode ends (an exact function of
     the lane's step counter; see cartpole / mountain_car).  Empty for every other family."""
     return {}
+
+  def _clear_pending_info(self):
+    """Subclass hook: called once `_pending_info()` has been added to the columns (enable_logging), for families
+    that keep the pending amount in state bits of their own (catch) rather than deriving it from a step counter."""
 
   def _info_columns(self) -> torch.Tensor:
     """The f64 [K, B] bsuite_info accumulators as the reference would report them right now."""

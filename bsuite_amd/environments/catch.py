@@ -36,6 +36,9 @@ class Catch(base.Environment):
     # 2 * 127 to the total_regret column once per 127 misses (csrc/catch_fam.h); a miss costs regret 2 (catch.py:92-94).
     return {0: 2.0 * ((self._state['state'] >> 25) & 0x7F).to(torch.float64)}
 
+  def _clear_pending_info(self):
+    self._state['state'] &= 0x01FFFFFF      # the misses just folded into the column (the Logging kernels never count here)
+
   _abi_name = 'catch'
   _supports_delta = True
   _pipelined_rollout = True
