@@ -151,3 +151,57 @@ def test_reward_wrapper_around_logging_is_refused():
   with pytest.raises(NotImplementedError):
     wrappers.RewardScale(logged, reward_scale=2.0, seed=1)
   wrappers.Logging(wrappers.RewardNoise(eu.make_env('catch', {}, batch=64, lane_offset=0, seed=1), noise_scale=0.5, seed=1), None)
+
+
+@pytest.mark.parametrize('family,kwargs,na', [('catch', {}, 3), ('mountain_car', dict(max_steps=15), 3)])
+def test_logging_wrapped_mid_run_takes_over_the_folded_info_columns(family, kwargs, na):
+  """Families that keep part of a bsuite_info column outside it while no Logging wrapper runs — catch counts its
+  misses in spare bits of the packed state and folds them once per 127, mountain_car / cartpole fold at episode ends —
+  hand the column over exactly when the wrapper arrives mid-run: bsuite_info() is the oracle's before, at, and after
+  the hand-over, and the rows logged afterwards carry the reference's values."""
+  B, seed = 700, 12
+  env = eu.make_env(family, kwargs, batch=B, lane_offset=3, seed=seed)
+  orc = coracle.OracleEnv(family, kwargs, np.arange(3, 3 + B, dtype=np.uint64), seed=seed)
+  rng = np.random.default_rng(4)
+  phys = family == 'mountain_car'
+
+  def run(e, t0, n):
+    for t in range(t0, t0 + n):
+      a = rng.integers(0, na, size=B).astype(np.int32)
+      if phys and t > 0:
+        eu.teacher_force(eu.raw(env), orc, family)
+      e.step(torch.from_numpy(a).cuda())
+      orc.call(a, t)
+      if t % 37 == 0 or t == t0 + n - 1:
+        for k, v in orc.bsuite_info().items():
+          np.testing.assert_array_equal(eu.raw(env).bsuite_info()[k].cpu().numpy(), v, err_msg=f'{family} {k} t={t}')
+
+  run(env, 0, 420)                       # > 127 misses for many catch lanes? no: ~38 episodes; the fold path runs in the fuzz
+  if family == 'catch':
+    assert int(((eu.raw(env)._state['state'] >> 25) & 0x7F).max()) > 0       # something is pending outside the column
+  logged = wrappers.Logging(env, None)
+  if family == 'catch':
+    assert int(((eu.raw(env)._state['state'] >> 25) & 0x7F).max()) == 0       # ... and has been handed over
+  for k, v in orc.bsuite_info().items():
+    np.testing.assert_array_equal(eu.raw(env).bsuite_info()[k].cpu().numpy(), v, err_msg=f'{family} {k} at the hand-over')
+  run(logged, 420, 200)
+  rows = logged.all_rows()               # snapshot rows have been written since, on every lane
+  assert len(rows) == B and all(len(r) > 0 for r in rows)
+
+
+def test_catch_folds_total_regret_once_per_127_misses():
+  """The fold itself: always-left on a 2-row board (an episode every 2 calls, the ball lands anywhere in 5 columns) runs
+  several hundred misses per lane through the 7-bit counter; total_regret equals the oracle's at every check."""
+  B, seed = 300, 5
+  kwargs = dict(rows=2, columns=5)
+  env = eu.make_env('catch', kwargs, batch=B, lane_offset=0, seed=seed)
+  orc = coracle.OracleEnv('catch', kwargs, np.arange(B, dtype=np.uint64), seed=seed)
+  a = np.zeros(B, np.int32)
+  folded = False
+  for t in range(900):
+    env.step(torch.from_numpy(a).cuda())
+    orc.call(a, t)
+    if t % 50 == 49:
+      np.testing.assert_array_equal(env.bsuite_info()['total_regret'].cpu().numpy(), orc.bsuite_info()['total_regret'])
+      folded |= bool((eu.raw(env)._info[0] >= 254.0).any())
+  assert folded                           # the column itself has received at least one batch of 127 misses
