@@ -24,6 +24,10 @@ struct catch_fam {
     bsx_timestep_t out;
     double* info;        // [1,B]: total_regret
     int32_t rows, columns;
+    // a segment of a whole-sweep group whose boards phase 0 writes itself (the fused tile of bsx_fused_tile_kernel)
+    // instead of leaving them to the phase-1 store stream: the magic of rows*columns, 0 = not fused
+    uint32_t tile_cells_magic;
+    int32_t _pad;
   };
   struct shared { int unused; };
   __device__ static __forceinline__ void stage(const args&, shared&) {}

@@ -48,7 +48,8 @@ int bsx_small_mixed_launch(bsx_group* g, int phase, hipStream_t st) {
 __device__ __forceinline__ void sweep_phase0_body(const uint8_t* __restrict__ table, const int32_t* __restrict__ tags,
                                                   const bsx_group_index& gi, uint64_t* counter, uint32_t* ticket,
                                                   const uint32_t block, const uint32_t n_blocks, float* s_obs,
-                                                  unsigned int* s_cnt, deep_sea_fam::shared& s_ds, catch_fam::shared& s_ca) {
+                                                  unsigned int* s_cnt, deep_sea_fam::shared& s_ds, catch_fam::shared& s_ca,
+                                                  int32_t* s_tile_state) {
   const bsx_group_slot w = bsx_group_find(gi, (int)block);
   const int tag = w.tag >= 0 ? w.tag : tags[w.seg];  // uniform per workgroup
   const uint32_t blk = w.block;
@@ -64,8 +65,15 @@ __device__ __forceinline__ void sweep_phase0_body(const uint8_t* __restrict__ ta
     }
     case BSX_FAM_CATCH: {
       const catch_fam::args& a = *reinterpret_cast<const catch_fam::args*>(slot);
-      if (bsx_ctl_lean(a.ctl)) bsx_advance_body<catch_fam, true>(a, blk, s_ca, s_cnt);
-      else bsx_advance_body<catch_fam, false>(a, blk, s_ca, s_cnt);
+      int32_t* tile = a.tile_cells_magic != 0u ? s_tile_state : nullptr;      // uniform: boards written right here
+      if (bsx_ctl_lean(a.ctl)) bsx_advance_body<catch_fam, true>(a, blk, s_ca, s_cnt, tile);
+      else bsx_advance_body<catch_fam, false>(a, blk, s_ca, s_cnt, tile);
+      if (tile != nullptr) {                   // (the advance ended with a barrier: the tile's states are complete)
+        const int64_t lane0 = (int64_t)blk * BSX_BLOCK, left = a.ctl.n_lanes - lane0;
+        const uint32_t cells = (uint32_t)(a.rows * a.columns);
+        bsx_tile_stream(a.out.observation + lane0 * (int64_t)cells, tile, left < BSX_BLOCK ? (int)left : BSX_BLOCK, cells,
+                        a.tile_cells_magic, catch_hot{a.rows, a.columns});
+      }
       break;
     }
     case BSX_FAM_MNIST: mnist_advance_body(*reinterpret_cast<const mnist_args*>(slot), blk, s_cnt); break;
@@ -106,8 +114,9 @@ __global__ void __launch_bounds__(BSX_BLOCK) __attribute__((amdgpu_waves_per_eu(
   __shared__ unsigned int s_cnt[2];
   __shared__ deep_sea_fam::shared s_ds;
   __shared__ catch_fam::shared s_ca;
+  __shared__ int32_t s_tile_state[BSX_BLOCK];
   if (trace != nullptr && threadIdx.x == 0) trace[3 * blockIdx.x] = wall_clock64();        // bsx_group_trace
-  sweep_phase0_body(table, tags, gi, counter, ticket, blockIdx.x, gridDim.x, s_obs, s_cnt, s_ds, s_ca);
+  sweep_phase0_body(table, tags, gi, counter, ticket, blockIdx.x, gridDim.x, s_obs, s_cnt, s_ds, s_ca, s_tile_state);
   if (trace != nullptr && threadIdx.x == 0) {
     trace[3 * blockIdx.x + 1] = wall_clock64();
     trace[3 * blockIdx.x + 2] = (uint64_t)tags[bsx_group_find(gi, (int)blockIdx.x).seg];
@@ -135,8 +144,9 @@ __global__ void __launch_bounds__(BSX_BLOCK) __attribute__((amdgpu_waves_per_eu(
   __shared__ deep_sea_fam::shared s_ds;
   __shared__ catch_fam::shared s_ca;
   __shared__ float s_lut[256];
+  __shared__ int32_t s_tile_state[BSX_BLOCK];
   const bsx_pipe_role r = bsx_pipe_role_of(blockIdx.x, gridDim.x, adv_blocks, place);   // uniform per workgroup
-  if (r.adv) sweep_phase0_body(adv_table, adv_tags, adv_gi, counter, ticket, r.index, adv_blocks, s_obs, s_cnt, s_ds, s_ca);
+  if (r.adv) sweep_phase0_body(adv_table, adv_tags, adv_gi, counter, ticket, r.index, adv_blocks, s_obs, s_cnt, s_ds, s_ca, s_tile_state);
   else pair_mixed_stream_body(str_table, str_tags, str_gi, r.index, s_lut);
 }
 
