@@ -39,8 +39,8 @@ import sys,json; d=json.loads(sys.stdin.read()); r=d['roofline']; print('%-18s e
   timeout 400 python tools/strong_scaling_proxy.py $out/strong_scaling_proxy.json > $out/strong_scaling_proxy.log 2>&1
   BSX_BENCH_BACKEND=gloo BSX_BENCH_SINGLE_DEVICE=1 timeout 400 python bench.py --gpus 2 --no-cpu-baseline 2>/dev/null | grep '^{' > $out/bench_2ranks_on_one_gpu_gloo.json
   timeout 300 python tools/physics_error.py > $out/physics_error.log 2>&1; cp gpurun_out/physics_error.json $out/ 2>/dev/null
-  timeout 240 python tools/fuzz_gpu.py --seconds 120 --seed 3 > $out/fuzz_gpu.log 2>&1; tail -1 $out/fuzz_gpu.log
-  # the engine against the UNMODIFIED reference, live: 8 x 250 random cases (families, kwargs, wrappers, resets, policies)
-  ( BSX_LIVE_CASES=250 timeout 600 python -m pytest tests/test_gpu_vs_reference_live.py -q -m gpu ) > $out/live_reference_2000_cases.log 2>&1; tail -2 $out/live_reference_2000_cases.log
+  timeout 400 python tools/fuzz_gpu.py --seconds 300 --seed 11 > $out/fuzz_gpu_300s.log 2>&1; tail -1 $out/fuzz_gpu_300s.log
+  # the engine against the UNMODIFIED reference, live: 8 x 1000 random cases (families, kwargs, wrappers, resets, policies)
+  ( BSX_LIVE_CASES=1000 timeout 900 python -m pytest tests/test_gpu_vs_reference_live.py -q -m gpu ) > $out/live_reference_8000_cases.log 2>&1; tail -2 $out/live_reference_8000_cases.log
 fi
 ls -la $out
