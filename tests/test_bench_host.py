@@ -76,3 +76,22 @@ def test_self_launch_refuses_when_devices_are_missing():
   p = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2'], env=env, stdout=subprocess.PIPE,
                      stderr=subprocess.PIPE, text=True, timeout=300)
   assert p.returncode != 0 and 'HIP device' in (p.stderr + p.stdout)
+
+
+def test_committed_pmc_passes_feed_the_roofline_fields():
+  """`roofline.traffic` / the `valu` roofline of the bench line come from committed rocprofv3 PMC passes
+  (tools/pmc.py → profiles/rNN/): every BASELINE config has one, each with a non-empty FETCH pass, and the HBM traffic
+  stays within 15 % of the algorithmic bytes (more would mean wasted re-reads, less a broken pass)."""
+  for w, alg in (('deep_sea', 3621), ('catch', 221), ('cartpole', 85), ('mountain_car', 49)):
+    hbm, src = bench.pmc_traffic(w, 1 << 20)
+    assert hbm is not None and src.startswith('profiles/r'), w
+    assert 0.9 < hbm / (alg * (1 << 20)) < 1.15, (w, hbm)
+  for w in ('sweep_closed', 'sweep_pipelined'):
+    hbm, src = bench.pmc_traffic(w, 1 << 20)
+    assert hbm is not None and 0.95 < hbm / 885.58e6 < 1.1, (w, hbm)
+  assert bench.pmc_traffic('deep_sea', 1 << 19) == (None, None)          # measured at 2^20 lanes only
+  for w in ('cartpole', 'mountain_car'):
+    v = bench.pmc_valu(w, 'rollout16', 1 << 20)
+    assert v is not None and v['insts'] > 1e7 and 0.2 < v['busy'] < 1.0, (w, v)
+  # VALU issue peak: 256 CUs x 4 SIMDs, one wave64 instruction per 2 cycles at 2.4 GHz
+  assert abs(bench.VALU_PEAK_GINSTR - 1228.8) < 1e-9
