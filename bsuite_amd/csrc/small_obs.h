@@ -67,6 +67,13 @@ struct bsx_bit_sink {
 // AND lgkmcnt and drags a full `s_waitcnt vmcnt(0)` (a drain of the wave's stores) in front of its first use.
 typedef const float __attribute__((address_space(3)))* bsx_lds_table;
 
+// Reset values of a workgroup's lanes, computed by a few threads on behalf of their owners (small_obs_regs_rollout).
+struct bsx_reset_pool {
+  float vals[6][BSX_BLOCK];          // [value][owner thread]
+  unsigned short list[BSX_BLOCK];    // the threads whose lane begins an episode at this step, in arrival order
+  unsigned int n[2];                 // how many; [step parity]
+};
+
 // A lane's own thread stores its short row (<= 8 floats).  A wave's 64 rows are one contiguous range, written by
 // back-to-back instructions that the L2 merges line by line.
 __device__ __forceinline__ void small_obs_store_row(float* __restrict__ dst, const float* o, int numel) {
@@ -87,6 +94,32 @@ __device__ __forceinline__ void small_obs_store_row(float* __restrict__ dst, con
   }
 }
 
+// The 64 rows of a full wave, through a wave-private LDS staging area, as 16-byte chunks: row-per-lane stores of a
+// 24-byte row are 8-byte pieces at stride 24 — every store instruction touches all of the wave's 64-byte segments with
+// a third of their bytes, three write requests per segment where one would do, and the fused rollouts of the physics
+// families turned out to be bound by exactly that (profiles/r03/exp_store_ablation.log: without the row stores
+// cartpole's step takes 8.1 us instead of 13.3).  No workgroup barrier: LDS serves a wave's accesses in order.
+// dst = row of the wave's first lane (16-byte aligned: the caller checks), s_wave = 64 * 8 floats, wl = lane in the wave.
+__device__ __forceinline__ void small_obs_store_rows_wave(float* __restrict__ dst, const float* o, int numel, float* s_wave, int wl) {
+  float* mine = s_wave + wl * numel;
+  if ((numel & 1) == 0) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+      if (2 * k < numel) *reinterpret_cast<float2*>(mine + 2 * k) = make_float2(o[2 * k], o[2 * k + 1]);
+  } else {
+#pragma unroll
+    for (int k = 0; k < 7; ++k)
+      if (k < numel) mine[k] = o[k];
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  const int chunks = 16 * numel;                                 // 64 rows x numel floats / 4
+  for (int c = wl; c < chunks; c += 64)
+    reinterpret_cast<float4*>(dst)[c] = reinterpret_cast<const float4*>(s_wave)[c];
+  __builtin_amdgcn_wave_barrier();                               // (the next step's rows are written after these reads)
+}
+
 // Fused T-step rollout of a family whose lane state fits in registers (cartpole, swing-up, mountain_car): ONE launch,
 // and nothing inside the step loop ever waits for memory —
 //  * the state AND the bsuite_info accumulators of the lane live in registers for the T steps (without the Logging
@@ -97,12 +130,21 @@ __device__ __forceinline__ void small_obs_store_row(float* __restrict__ dst, con
 //  * cartpole's time-fraction table sits in LDS (lgkmcnt) when it fits.
 // r02 (prefetch + in-loop RMW): 70 % of the wave cycles were waits, cartpole 15.1 us per step at 53 % VALU-busy
 // (profiles/r03/cartpole_rollout16_before_pmc_sq.json).
-template <class Env, int LOG, int NOISE, int MT, bool TAB>
+template <class Env, int LOG, int NOISE, int MT, bool TAB, bool BIG>
 __device__ __forceinline__ void small_obs_regs_rollout(const typename Env::args& a, const int n_steps, const uint32_t block_id,
-                                                       float* s_dyn, unsigned int* s_cnt) {
+                                                       float* s_dyn, unsigned int* s_cnt, bsx_reset_pool* s_pool, float* s_rows) {
   constexpr bool IREGS = LOG == 0;
+  // BIG: the launch fills the chip several times over (launch_small_obs) — the loop is then bound by throughput (vector
+  // instructions, write requests) and pools the resets / stages the rows; a small launch is bound by the latency of a
+  // wave's own step, to which the pool's two barriers and the LDS round trip only add (2^17 lanes: cartpole 2.1 -> 2.5 us
+  // per step, profiles/r03/ab_rows_small_batches.log).
+  constexpr bool POOL = BIG && Env::POOLED_RESETS && MT == 0;
+  constexpr bool ROWS = BIG && Env::ROWS_VIA_LDS;
   constexpr int RUN = 8;
-  if (threadIdx.x < 2) s_cnt[threadIdx.x] = 0;
+  if (threadIdx.x < 2) {
+    s_cnt[threadIdx.x] = 0;
+    if constexpr (POOL) s_pool->n[threadIdx.x] = 0;
+  }
   // TAB: the family's table is staged in LDS (a compile-time fact inside the loop: were the source of a value
   // decided at run time, the compiler would wait for the global load it MIGHT have been — vmcnt — at every use)
   bsx_lds_table s_tab = (bsx_lds_table)0;
@@ -114,6 +156,10 @@ __device__ __forceinline__ void small_obs_regs_rollout(const typename Env::args&
   const bool mine = i < B;
   const uint64_t lane = a.ctl.lane_offset + (uint64_t)i;
   const uint64_t step0 = bsx_step_of(a.ctl);
+  // rows leave through the wave's LDS staging area when every row of the wave exists and every step's block of rows
+  // starts on a 16-byte boundary (wave-uniform)
+  const int wl = (int)(threadIdx.x & 63u);
+  const bool rows_via_lds = ROWS && (((int64_t)B * numel) & 3) == 0 && (i - wl + 64) <= B;
   typename Env::regs rg;
   if (mine) {
     Env::load(a, i, rg);
@@ -138,13 +184,35 @@ __device__ __forceinline__ void small_obs_regs_rollout(const typename Env::args&
       int act = acts[0];
 #pragma unroll
       for (int q = 1; q < RUN; ++q) act = j == q ? acts[q] : act;
+      if constexpr (POOL) {
+        // The lanes that begin an episode at this step hand the draws of their reset to a pool: some lane of a
+        // wave does on 4 steps in 10 (cartpole, random actions), and then the whole wave walks through two Philox
+        // blocks and four f64 uniforms for its sake — ~230 vector instructions beside the step's ~150.  Pooled, ONE
+        // wave of the workgroup computes all of them in one pass, two threads per lane (a Philox block each), and
+        // the waves take turns at it step by step so that the work lands on every SIMD: 306 -> ~215 vector
+        // instructions per wave and step, 77 -> 63 VGPRs (profiles/r03/ab_pooled_resets.log).
+        const int par = t & 1;
+        if (mine && t < n_steps && Env::wants_reset(a, rg)) {
+          const unsigned slot = atomicAdd(&s_pool->n[par], 1u);
+          s_pool->list[slot] = (unsigned short)threadIdx.x;
+        }
+        __syncthreads();
+        const unsigned n2 = 2u * s_pool->n[par];
+        if (threadIdx.x == 0) s_pool->n[par ^ 1] = 0;
+        for (unsigned h = (threadIdx.x + 64u * ((unsigned)t + block_id)) & (BSX_BLOCK - 1u); h < n2; h += BSX_BLOCK) {
+          const unsigned e = s_pool->list[h >> 1];
+          Env::reset_part(a, a.ctl.lane_offset + (uint64_t)block_id * BSX_BLOCK + e, step0 + (uint64_t)t, (int)(h & 1u), e, s_pool);
+        }
+        __syncthreads();
+      }
       if (mine && t < n_steps) {
         const int64_t oi = (int64_t)t * B + i;
         double reward = 0.0;
         float o[8];
-        type = Env::template core<LOG, MT, IREGS, TAB>(a, rg, act, i, lane, step0 + (uint64_t)t, o, reward, s_tab);
+        type = Env::template core<LOG, MT, IREGS, TAB, POOL>(a, rg, act, i, lane, step0 + (uint64_t)t, o, reward, s_tab, s_pool);
         bsx_emit_at<LOG, NOISE>(a.ctl, a.out, i, oi, lane, step0 + (uint64_t)t, type, reward);
-        small_obs_store_row(a.out.observation + oi * (int64_t)numel, o, numel);
+        if (rows_via_lds) small_obs_store_rows_wave(a.out.observation + (oi - wl) * (int64_t)numel, o, numel, s_rows + (threadIdx.x - wl) * 8, wl);
+        else small_obs_store_row(a.out.observation + oi * (int64_t)numel, o, numel);
       }
       if (t < n_steps) bsx_count_types(a.ctl, type, s_cnt);             // uniform
     }
@@ -157,13 +225,23 @@ __device__ __forceinline__ void small_obs_regs_rollout(const typename Env::args&
   bsx_flush_counts(a.ctl, s_cnt, block_id);
 }
 
-template <class Env, bool ROLLOUT, int LOG, int NOISE, int MT, bool DIRECT_ARG>
+template <class Env, bool ROLLOUT, int LOG, int NOISE, int MT, bool DIRECT_ARG, bool BIG = false>
 __device__ __forceinline__ void small_obs_body(const typename Env::args& a, const int n_steps_arg,
                                                const uint32_t block_id, float* s_obs, unsigned int* s_cnt) {
   constexpr bool DIRECT = DIRECT_ARG || !Env::PACKED;
   if constexpr (ROLLOUT && Env::HAS_REGS) {
-    if (Env::table_fits(a)) small_obs_regs_rollout<Env, LOG, NOISE, MT, true>(a, n_steps_arg, block_id, s_obs, s_cnt);   // uniform
-    else small_obs_regs_rollout<Env, LOG, NOISE, MT, false>(a, n_steps_arg, block_id, s_obs, s_cnt);
+    bsx_reset_pool* pool = nullptr;
+    float* rows = nullptr;
+    if constexpr (BIG && Env::POOLED_RESETS && MT == 0) {
+      __shared__ bsx_reset_pool s_pool;
+      pool = &s_pool;
+    }
+    if constexpr (BIG && Env::ROWS_VIA_LDS) {
+      __shared__ __attribute__((aligned(16))) float s_rows[BSX_BLOCK * 8];         // 64 rows of <= 8 floats per wave
+      rows = s_rows;
+    }
+    if (Env::table_fits(a)) small_obs_regs_rollout<Env, LOG, NOISE, MT, true, BIG>(a, n_steps_arg, block_id, s_obs, s_cnt, pool, rows);   // uniform
+    else small_obs_regs_rollout<Env, LOG, NOISE, MT, false, BIG>(a, n_steps_arg, block_id, s_obs, s_cnt, pool, rows);
     return;
   }
   const int n_steps = ROLLOUT ? n_steps_arg : 1;   // the single-step instantiation has no loop: keeping
@@ -281,11 +359,11 @@ __device__ __forceinline__ void small_obs_body(const typename Env::args& a, cons
   bsx_flush_counts(a.ctl, s_cnt, block_id);
 }
 
-template <class Env, bool ROLLOUT, int LOG, int NOISE, int MT, bool DIRECT>
+template <class Env, bool ROLLOUT, int LOG, int NOISE, int MT, bool DIRECT, bool BIG = false>
 __global__ void __launch_bounds__(BSX_BLOCK) small_obs_kernel(const typename Env::args a, const int n_steps) {
   extern __shared__ __attribute__((aligned(16))) float s_obs[];
   __shared__ unsigned int s_cnt[2];
-  small_obs_body<Env, ROLLOUT, LOG, NOISE, MT, DIRECT>(a, n_steps, blockIdx.x, s_obs, s_cnt);
+  small_obs_body<Env, ROLLOUT, LOG, NOISE, MT, DIRECT, BIG>(a, n_steps, blockIdx.x, s_obs, s_cnt);
 }
 
 // Dynamic LDS of one workgroup stepping `a`.
@@ -376,6 +454,13 @@ static int small_obs_group_put(bsx_group* g, int32_t family, int32_t index, cons
   return 0;
 }
 
+// does the family's fused rollout have a variant for big launches (small_obs_regs_rollout, BIG)?
+template <class Env>
+static constexpr bool small_obs_has_big() {
+  if constexpr (Env::HAS_REGS) return Env::POOLED_RESETS || Env::ROWS_VIA_LDS;
+  else return false;
+}
+
 template <class Env>
 static int launch_small_obs(const typename Env::args& a, int n_steps, void* hip_stream) {
   hipStream_t st = (hipStream_t)hip_stream;
@@ -386,6 +471,9 @@ static int launch_small_obs(const typename Env::args& a, int n_steps, void* hip_
   if (blocks > 0x7FFFFFFF) return BSX_EINVAL;
   const size_t lds = n_steps > 1 ? small_obs_rollout_lds<Env>(a) : small_obs_lds<Env>(a);
   const dim3 g((unsigned)blocks), b(BSX_BLOCK);
+  // the register-resident families' fused rollout: pooled resets / staged rows from 2^19 lanes (8 workgroups per CU) up
+  static const int big_min_blocks = bsx_env_int("BSX_REGS_ROLLOUT_BIG_MIN_BLOCKS", 2048);
+  const bool big = small_obs_has_big<Env>() && blocks >= big_min_blocks;
   // Per-thread stores (4-byte / 12-byte / 8-byte stores, each wave writing one contiguous range) against
   // an f32 LDS tile, measured on bandit, discounting_chain, cartpole, mountain_car, memory_len: eager equal
   // or 2-4 % faster, fused rollout 3-15 % faster (profiles/r02/ab_small_direct_stores.log).  Three 4-byte
@@ -398,6 +486,7 @@ static int launch_small_obs(const typename Env::args& a, int n_steps, void* hip_
     else if (logging && noise) small_obs_kernel<Env, true, 1, 1, -1, D><<<g, b, lds, st>>>(a, n_steps);    \
     else if (logging) small_obs_kernel<Env, true, 1, 0, -1, D><<<g, b, lds, st>>>(a, n_steps);             \
     else if (noise) small_obs_kernel<Env, true, 0, 1, -1, D><<<g, b, lds, st>>>(a, n_steps);               \
+    else if (lean && big) small_obs_kernel<Env, true, 0, 0, 0, D, small_obs_has_big<Env>()><<<g, b, lds, st>>>(a, n_steps); \
     else if (lean) small_obs_kernel<Env, true, 0, 0, 0, D><<<g, b, lds, st>>>(a, n_steps);                 \
     else small_obs_kernel<Env, true, 0, 0, -1, D><<<g, b, lds, st>>>(a, n_steps);                          \
   }
@@ -640,8 +729,29 @@ struct cartpole_env {
   };
   // The lane's state in registers: step() = load + core + store; the fused rollout loads once, runs core
   // T times and stores once (small_obs_body), instead of a round trip through L2 every step.
-  static constexpr bool HAS_REGS = true, PACKED = false;
+  static constexpr bool HAS_REGS = true, PACKED = false, POOLED_RESETS = true, ROWS_VIA_LDS = true;
   struct regs { float x, xd, th, thd; int32_t sk; double inf[4]; };     // inf: the info columns in a fused rollout
+  __device__ static __forceinline__ bool wants_reset(const args& a, const regs& r) { return a.ctl.force_reset || (r.sk & CP_RESET_BIT); }
+  // Half of a lane's reset (cartpole.py:118-128), counter-based stream only: part 0 = x, x_dot from words 0..3 of
+  // the (lane, step) stream, part 1 = theta, theta_dot from words 4..7 and the new angle's sine / cosine — the same
+  // words, the same arithmetic as core()'s in-line reset, one Philox block per part.
+  __device__ static __forceinline__ void reset_part(const args& a, uint64_t lane, uint64_t step, int part, unsigned owner,
+                                                    bsx_reset_pool* pool) {
+    BSX_NO_CONTRACT
+    const bsx_cartpole_t& g = a.cfg;
+    bsx_draws d;
+    bsx_draws_init(&d, a.ctl.seed, lane, step, BSX_STREAM_ENV);
+    d.next = 4u * (uint32_t)part;
+    const double lo = -g.init_range, hi = g.init_range;
+    const double w0 = lo + (hi - lo) * bsx_uniform(&d);
+    const double w1 = lo + (hi - lo) * bsx_uniform(&d);
+    const float v0 = (float)(part ? g.theta_offset + w0 : w0), v1 = (float)w1;
+    float si, co;
+    bsx_sincosf(v0, &si, &co);
+    pool->vals[2 * part][owner] = v0;
+    pool->vals[2 * part + 1][owner] = v1;
+    if (part) { pool->vals[4][owner] = si; pool->vals[5][owner] = co; }
+  }
   // Fused rollouts keep the time-fraction table in LDS when it is small (the default 1002 entries: 4 KiB)
   static constexpr int TABLE_MAX_BYTES = 16384;
   __host__ __device__ static bool table_fits(const args& a) { return ((int64_t)a.cfg.last_step + 1) * 4 <= TABLE_MAX_BYTES; }
@@ -683,9 +793,11 @@ struct cartpole_env {
   }
   // IREGS: the info columns are rg.inf[] (fused rollout without Logging), else read-modify-written in HBM.
   // s_tf: the time-fraction table in LDS, or nullptr (-> g.time_frac in device memory).
-  template <int LOG, int MT, bool IREGS = false, bool TAB = false>
+  // POOL: the reset values were computed by the workgroup's pool (reset_part) and wait in s_pool.
+  template <int LOG, int MT, bool IREGS = false, bool TAB = false, bool POOL = false>
   __device__ static __forceinline__ int core(const args& a, regs& rg, const int act, int64_t i, uint64_t lane, uint64_t step,
-                                             float* o, double& reward, bsx_lds_table s_tf = (bsx_lds_table)0) {
+                                             float* o, double& reward, bsx_lds_table s_tf = (bsx_lds_table)0,
+                                             const bsx_reset_pool* s_pool = nullptr) {
     BSX_NO_CONTRACT
     const int64_t B = a.ctl.n_lanes;
     const bsx_cartpole_t& g = a.cfg;
@@ -701,19 +813,25 @@ struct cartpole_env {
       // lanes one at a time with wave-uniform inputs puts the Philox rounds on the scalar unit and cuts the vector
       // instructions by 19 %, but the ~200-instruction dependent scalar chain per resetting lane stalls the wave
       // longer than the divergent branch did: fused rollout 12.5 -> 14.7 us per step.)
-      bsx_draws d;
-      bsx_draws_begin<MT>(&d, a.ctl, i, lane, step);
-      const double lo = -g.init_range, hi = g.init_range;
-      x = (float)(lo + (hi - lo) * bsx_uniform(&d));
-      xd = (float)(lo + (hi - lo) * bsx_uniform(&d));
-      th = (float)(g.theta_offset + (lo + (hi - lo) * bsx_uniform(&d)));
-      thd = (float)(lo + (hi - lo) * bsx_uniform(&d));
-      bsx_draws_end<MT>(&d, a.ctl, i);
+      if constexpr (POOL) {
+        const unsigned me = threadIdx.x;
+        x = s_pool->vals[0][me]; xd = s_pool->vals[1][me]; th = s_pool->vals[2][me]; thd = s_pool->vals[3][me];
+        si = s_pool->vals[4][me]; co = s_pool->vals[5][me];
+      } else {
+        bsx_draws d;
+        bsx_draws_begin<MT>(&d, a.ctl, i, lane, step);
+        const double lo = -g.init_range, hi = g.init_range;
+        x = (float)(lo + (hi - lo) * bsx_uniform(&d));
+        xd = (float)(lo + (hi - lo) * bsx_uniform(&d));
+        th = (float)(g.theta_offset + (lo + (hi - lo) * bsx_uniform(&d)));
+        thd = (float)(lo + (hi - lo) * bsx_uniform(&d));
+        bsx_draws_end<MT>(&d, a.ctl, i);
+        bsx_sincosf(th, &si, &co);                             // |theta_offset| + init_range <= 32 (cartpole_make)
+      }
       // an explicit reset() in mid-episode abandons it: the k rewards of 1 it has paid stay in raw_return
       if (!per_step_info && !(sk & CP_RESET_BIT) && k > 0) info_set(0, info_get(0) + (double)k);
       k = 0;
       if (per_step_info) info_set(2, 0.0);                      // _episode_return = 0
-      bsx_sincosf(th, &si, &co);                               // |theta_offset| + init_range <= 32 (cartpole_make)
       type = BSX_FIRST;
     } else {
       x = rg.x; xd = rg.xd; th = rg.th; thd = rg.thd;
@@ -803,8 +921,12 @@ struct mountain_car_env {
     bsx_ctl ctl; const int32_t* action; float* state; int32_t* steps; bsx_timestep_t out;
     double* info; int32_t obs_numel; int32_t max_steps;
   };
-  static constexpr bool HAS_REGS = true, PACKED = false;
+  // (resets are rare — 1000-step episodes — and one Philox block: not pooled; the 12-byte rows of a wave are one dense
+  // 768-byte range already: staging them gained nothing, profiles/r03/ab_rows_via_lds.log)
+  static constexpr bool HAS_REGS = true, PACKED = false, POOLED_RESETS = false, ROWS_VIA_LDS = false;
   struct regs { float pos, vel; int32_t sk; double inf0; };             // inf0: raw_return in a fused rollout
+  __device__ static __forceinline__ bool wants_reset(const args&, const regs&) { return false; }
+  __device__ static __forceinline__ void reset_part(const args&, uint64_t, uint64_t, int, unsigned, bsx_reset_pool*) {}
   __host__ __device__ static bool table_fits(const args&) { return false; }
   static size_t table_bytes(const args&) { return 0; }
   __device__ static __forceinline__ bsx_lds_table stage_tables(const args&, float*) { return (bsx_lds_table)0; }
@@ -825,9 +947,10 @@ struct mountain_car_env {
     store(a, i, r);
     return type;
   }
-  template <int LOG, int MT, bool IREGS = false, bool TAB = false>
+  template <int LOG, int MT, bool IREGS = false, bool TAB = false, bool POOL = false>
   __device__ static __forceinline__ int core(const args& a, regs& rg, const int act, int64_t i, uint64_t lane, uint64_t step,
-                                             float* o, double& reward, bsx_lds_table = (bsx_lds_table)0) {
+                                             float* o, double& reward, bsx_lds_table = (bsx_lds_table)0,
+                                             const bsx_reset_pool* = nullptr) {
     BSX_NO_CONTRACT
     const int32_t sk = rg.sk;
     int t = sk & 0x3FFFFFFF;

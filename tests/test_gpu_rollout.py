@@ -61,6 +61,58 @@ def test_rollout_equals_steps(family, kwargs, wrap, na, batch):
   assert eu.raw(a).step_index == eu.raw(b).step_index == 5 + T + 1
 
 
+@pytest.mark.parametrize('family,na', [('cartpole', 3), ('cartpole_swingup', 3), ('mountain_car', 3)])
+@pytest.mark.parametrize('batch,T', [(1, 40), (333, 300), (5000, 300), (70000, 64), ((1 << 19) + 1000, 12), ((1 << 19) + 333, 12)])
+def test_lean_fused_rollout_equals_steps(family, na, batch, T):
+  """No wrapper at all: the lean instantiation of the fused rollout.  From 2^19 lanes up (2048 workgroups) the launch
+  takes the BIG variant, in which cartpole's resetting lanes hand their draws to the workgroup's pool and full waves
+  stage their rows in LDS (small_obs.h; an odd batch keeps row-per-lane stores, both have a ragged last workgroup);
+  test_big_launch_variant_at_small_shapes runs the small shapes through that variant too.  The first rollout starts
+  on a fresh environment — all 256 lanes of every workgroup reset at once — the second one carries state, and
+  episodes end at every step of it."""
+  seed = 5
+  g = torch.Generator(device='cuda'); g.manual_seed(11)
+  acts = torch.randint(na, (2 * T, batch), generator=g, device='cuda', dtype=torch.int32)
+  a = eu.make_env(family, {}, batch=batch, lane_offset=7, seed=seed)
+  b = eu.make_env(family, {}, batch=batch, lane_offset=7, seed=seed)
+  n_first = 0
+  for half in range(2):
+    part = acts[half * T:(half + 1) * T]
+    ro = a.rollout(part)
+    got = [x.clone() for x in (ro.step_type, ro.reward, ro.discount, ro.observation)]
+    for t in range(T):
+      ts = b.step(part[t])
+      for name, x, y in zip(('step_type', 'reward', 'discount', 'observation'), got,
+                            (ts.step_type, ts.reward, ts.discount, ts.observation)):
+        assert torch.equal(x[t], y), f'{family} {name} half={half} t={t}'
+    n_first += int((got[0][1:] == 0).sum())
+  if family == 'cartpole' and T >= 300:
+    assert n_first > batch                                    # episodes did end, all over the rollout
+  for k, v in a.bsuite_info().items():
+    torch.testing.assert_close(v, b.bsuite_info()[k], rtol=0, atol=0)
+  torch.testing.assert_close(a.episode_counters(), b.episode_counters(), rtol=0, atol=0)
+  ta, tb = a.step(acts[0]), b.step(acts[0])
+  assert torch.equal(ta.observation, tb.observation)
+
+
+@pytest.mark.timeout(900)
+def test_big_launch_variant_at_small_shapes():
+  """The BIG variant of the register-resident fused rollout (pooled resets, rows staged in LDS) is what a launch of
+  2048+ workgroups runs; here the small and ragged shapes of the parity tests go through it as well: a subprocess
+  against the tuning build of the library with BSX_REGS_ROLLOUT_BIG_MIN_BLOCKS=1."""
+  import os, subprocess, sys
+  from bsuite_amd import build as _build
+  root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+  env = dict(os.environ, BSX_NATIVE_LIB=_build.build(tuning=True), BSX_REGS_ROLLOUT_BIG_MIN_BLOCKS='1', PYTHONPATH=root)
+  p = subprocess.run([sys.executable, '-m', 'pytest', '-q', '-x', '-m', 'gpu', '-p', 'no:cacheprovider',
+                      'tests/test_gpu_rollout.py', 'tests/test_gpu_oracle_batch.py', 'tests/test_gpu_golden.py',
+                      '-k', '(cartpole or mountain_car) and not big_launch'],
+                     cwd=root, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=800)
+  tail = p.stdout[-3000:]
+  assert p.returncode == 0, tail
+  assert ' passed' in tail and 'failed' not in tail, tail
+
+
 @pytest.mark.parametrize('family,kwargs,na', [('deep_sea', dict(size=6, deterministic=False, mapping_seed=1), 2),
                                                ('deep_sea', dict(size=10, mapping_seed=42), 2),
                                                ('catch', dict(), 3)])
