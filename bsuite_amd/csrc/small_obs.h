@@ -271,7 +271,9 @@ __device__ __forceinline__ void small_obs_body(const typename Env::args& a, cons
         bsx_emit_at<LOG, NOISE>(a.ctl, a.out, i, oi, lane, step0 + (uint64_t)t, type, reward);
         // (row-per-lane stores also in a big launch: staging the rows like the fused rollout does left the eager step
         // where it was — 17.5 / 17.5 vs 18.0 / 17.4 us at 2^20 lanes — and cost 4 % at 2^18,
-        // profiles/r03/ab_eager_rows_via_lds.log: one memory round trip per launch bounds it, not the write requests)
+        // profiles/r03/ab_eager_rows_via_lds.log: one memory round trip per launch bounds it, not the write requests;
+        // pooled resets in the eager step: 17.6 -> 19.1-19.6 us, the barriers wait for the slowest wave's loads,
+        // profiles/r03/ab_eager_pooled_resets.log)
         small_obs_store_row(a.out.observation + oi * (int64_t)numel, o, numel);
       }
       bsx_count_types(a.ctl, type, s_cnt);
