@@ -140,7 +140,7 @@ __device__ __forceinline__ void small_obs_regs_rollout(const typename Env::args&
   // per step, profiles/r03/ab_rows_small_batches.log).
   constexpr bool POOL = BIG && Env::POOLED_RESETS && MT == 0;
   constexpr bool ROWS = BIG && Env::ROWS_VIA_LDS;
-  constexpr int RUN = 8;
+  constexpr int RUN = 8;                // (16: no drain inside a T=16 launch at all, and 3-7 % slower — profiles/r03/ab_rollout_run16.log)
   if (threadIdx.x < 2) {
     s_cnt[threadIdx.x] = 0;
     if constexpr (POOL) s_pool->n[threadIdx.x] = 0;
