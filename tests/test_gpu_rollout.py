@@ -62,7 +62,8 @@ def test_rollout_equals_steps(family, kwargs, wrap, na, batch):
 
 
 @pytest.mark.parametrize('family,na', [('cartpole', 3), ('cartpole_swingup', 3), ('mountain_car', 3)])
-@pytest.mark.parametrize('batch,T', [(1, 40), (333, 300), (5000, 300), (70000, 64), ((1 << 19) + 1000, 12), ((1 << 19) + 333, 12)])
+@pytest.mark.parametrize('batch,T', [(1, 40), (333, 300), (5000, 300), (70000, 64), ((1 << 19) + 1000, 12), ((1 << 19) + 333, 12),
+                                     (1 << 20, 16)])        # the last one: as benched (`cartpole/0 r16`)
 def test_lean_fused_rollout_equals_steps(family, na, batch, T):
   """No wrapper at all: the lean instantiation of the fused rollout.  From 2^19 lanes up (2048 workgroups) the launch
   takes the BIG variant, in which cartpole's resetting lanes hand their draws to the workgroup's pool and full waves
