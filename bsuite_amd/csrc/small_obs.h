@@ -210,9 +210,20 @@ __device__ __forceinline__ void small_obs_regs_rollout(const typename Env::args&
         double reward = 0.0;
         float o[8];
         type = Env::template core<LOG, MT, IREGS, TAB, POOL>(a, rg, act, i, lane, step0 + (uint64_t)t, o, reward, s_tab, s_pool);
+#if !defined(BSX_ABLATE_STORES)
         bsx_emit_at<LOG, NOISE>(a.ctl, a.out, i, oi, lane, step0 + (uint64_t)t, type, reward);
         if (rows_via_lds) small_obs_store_rows_wave(a.out.observation + (oi - wl) * (int64_t)numel, o, numel, s_rows + (threadIdx.x - wl) * 8, wl);
         else small_obs_store_row(a.out.observation + oi * (int64_t)numel, o, numel);
+#else
+        // Measurement builds only (tools/ablate_stores.sh; never the product library): the loop without its observation
+        // rows (bit 0), without reward / discount / step_type (bit 1) — the conditions are never true, the stores
+        // stay reachable so that the arithmetic feeding them is not compiled away.
+        if (!(BSX_ABLATE_STORES & 2) || (reward == 123.0 && type == 7)) bsx_emit_at<LOG, NOISE>(a.ctl, a.out, i, oi, lane, step0 + (uint64_t)t, type, reward);
+        if (!(BSX_ABLATE_STORES & 1) || (o[0] == 123.0f && o[1] == 5.0f && o[2] == 7.0f)) {
+          if (rows_via_lds) small_obs_store_rows_wave(a.out.observation + (oi - wl) * (int64_t)numel, o, numel, s_rows + (threadIdx.x - wl) * 8, wl);
+          else small_obs_store_row(a.out.observation + oi * (int64_t)numel, o, numel);
+        }
+#endif
       }
       if (t < n_steps) bsx_count_types(a.ctl, type, s_cnt);             // uniform
     }
