@@ -1,0 +1,77 @@
+"""CPU: register / LDS / scratch budgets of the built kernels, read from the code objects' metadata
+(tools/kernel_resources.py: clang-offload-bundler + llvm-readelf, no GPU).  The hot kernels are latency- or
+throughput-bound through their occupancy — a change that pushes one of them over a VGPR step (64 -> 7 waves per SIMD,
+72 -> 6 at 80, ...) or into scratch shows up here before it shows up as a slower bench line."""
+import os
+import shutil
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, 'tools'))
+import kernel_resources as kr  # noqa: E402
+
+pytestmark = pytest.mark.skipif(not os.path.exists(os.path.join(kr.LLVM, 'clang-offload-bundler')) or shutil.which('c++filt') is None,
+                                reason='needs the ROCm LLVM tools')
+
+
+@pytest.fixture(scope='module')
+def kernels():
+  from bsuite_amd import build
+  ks = kr.kernels(build.build())
+  return {k['name'].split('(')[0]: k for k in ks}
+
+
+# kernel -> most VGPRs it may use (the step below the next occupancy loss, with a little slack)
+BUDGET = {
+    # BASELINE configs 1/2: deep_sea / catch lane advance + observation store stream (eager and pipelined rollout)
+    'bsx_hot_stream_kernel<deep_sea_hot, 4, 256>': 32,
+    'bsx_hot_stream_kernel<catch_hot, 2, 256>': 32,
+    'bsx_advance_kernel<deep_sea_fam, true>': 64,
+    'bsx_advance_kernel<catch_fam, true>': 32,
+    'bsx_pipelined_kernel<deep_sea_fam, true, deep_sea_hot, 4>': 64,
+    'bsx_pipelined_kernel<catch_fam, true, catch_hot, 2>': 32,
+    'bsx_fused_tile_kernel<catch_fam, true, catch_hot>': 32,
+    # configs 3/4: the physics families, eager and fused rollout (lean instantiations)
+    'small_obs_kernel<cartpole_env, false, 0, 0, 0, true, false>': 40,
+    'small_obs_kernel<cartpole_env, true, 0, 0, 0, true, false>': 80,
+    'small_obs_kernel<cartpole_env, true, 0, 0, 0, true, true>': 72,          # BIG: pooled resets, staged rows — 7 waves
+    'small_obs_kernel<mountain_car_env, false, 0, 0, 0, true, false>': 32,
+    'small_obs_kernel<mountain_car_env, true, 0, 0, 0, true, false>': 64,
+    # config 5: the whole sweep as one launch group
+    'sweep_phase0_kernel': 64,
+    'sweep_pipelined_kernel': 64,
+    'pair_mixed_stream_kernel': 32,
+    'small_obs_mixed_group_kernel': 80,
+}
+# scratch that is not a spill: a dynamically indexed per-thread array in two non-lean instantiations
+KNOWN_SCRATCH = {'small_obs_kernel<umbrella_chain_env, false, -1, -1, -1, true, false>',
+                 'bsx_fused_rollout_kernel<deep_sea_fam, false, deep_sea_hot>'}
+
+
+def test_hot_kernels_stay_inside_their_register_budgets(kernels):
+  for name, most in BUDGET.items():
+    assert name in kernels, f'{name} is not in the library any more: update BUDGET'
+    k = kernels[name]
+    assert k['vgpr_count'] <= most, f'{name}: {k["vgpr_count"]} VGPRs > {most} ({k["waves_per_simd"]} waves per SIMD)'
+    assert k['agpr_count'] == 0 and k['private_segment_fixed_size'] == 0 and k['vgpr_spill_count'] == 0, (name, k)
+
+
+def test_no_kernel_spills_vector_registers(kernels):
+  assert len(kernels) > 150
+  for name, k in kernels.items():
+    assert k['vgpr_spill_count'] == 0, f'{name} spills {k["vgpr_spill_count"]} VGPRs'
+    if name not in KNOWN_SCRATCH:
+      assert k['private_segment_fixed_size'] == 0, f'{name} uses {k["private_segment_fixed_size"]} B of scratch'
+    assert k['max_flat_workgroup_size'] in (64, 128, 256, 512, 1024)
+    assert k['group_segment_fixed_size'] <= 16 * 1024, f'{name}: {k["group_segment_fixed_size"]} B of static LDS'
+
+
+def test_lean_instantiations_keep_full_occupancy(kernels):
+  """The common call (no Logging wrapper, no RewardNoise, counter-based draws) of every eager small-observation
+  kernel fits 8 waves per SIMD."""
+  lean = [k for n, k in kernels.items() if n.startswith('small_obs_kernel<') and ', false, 0, 0, 0,' in n]
+  assert len(lean) >= 8
+  for k in lean:
+    assert k['vgpr_count'] <= 64, (k['name'], k['vgpr_count'])
