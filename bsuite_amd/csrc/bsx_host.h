@@ -285,7 +285,9 @@ static int bsx_pair_call(const typename Fam::args& a0, const bsx_call_t* call, c
   // decoupled pair / the pipelined rollout, steady within 2 % everywhere, keep that size (profiles/r03/
   // ab_fused_tile*.log, ab_fused_crossover.log); deep_sea N=30 (900 cells, 0.9 MiB tiles) never fuses.  The tile start
   // block*256*cells*4 is always 16-byte aligned when the slice is.  (A barrier-free variant — every wave its own
-  // 64 lanes, neighbour states through ds_bpermute — measured 1-9 % slower: profiles/r03/ab_fused_wave.log.)
+  // 64 lanes, neighbour states through ds_bpermute — measured 1-9 % slower: profiles/r03/ab_fused_wave.log; two tiles
+  // per workgroup with both tiles' inputs loaded up front, i.e. one dispatch round at 2^20 lanes: 42.7-45.2 vs
+  // 41.1-41.7 us for the pair, profiles/r03/ab_fused_tiles_per_wg.log.)
   static const int fused_cells = bsx_env_int("BSX_FUSED_TILE_MAX_CELLS", 128);
   static const int fused_step_mib = bsx_env_int("BSX_FUSED_TILE_MAX_MIB", 128);
   static const int fused_roll_mib = bsx_env_int("BSX_FUSED_ROLLOUT_MAX_MIB", 128);
