@@ -17,6 +17,7 @@ WRAP_NONE, WRAP_SCALE, WRAP_NOISE, WRAP_SCALE_NOISE, WRAP_NOISE_SCALE = 0, 1, 2,
 COUNTER_SHARDS, COUNTER_STRIDE = 256, 16
 DEEP_SEA_MAX_SIZE = 64
 BANDIT_MAX_ACTIONS = 32
+FUSED_CATCH_MAX_CELLS = 128   # BSX_FUSED_CATCH_MAX_CELLS (include/bsuite_amd.h)
 
 
 class NativeLibraryError(RuntimeError):

@@ -28,6 +28,8 @@ struct bsx_ctl {
   uint64_t* counters;
   double wrap_param;
   double wrap_param2;       // stacked wrappers: the outer wrapper's parameter
+  double wrap_mul;          // RewardScale alone: its scale; no wrapper: 1.0 (x * 1.0 == x bit for bit) — the NOISE = 0
+                            // instantiations multiply unconditionally instead of branching on wrap_kind
   uint64_t wrap_seed;
   int32_t wrap_kind;
   int32_t force_reset;
@@ -46,9 +48,10 @@ struct bsx_ctl {
   bsx_logging_t log;        // log.steps == nullptr: logging off
 };
 
-// No Logging wrapper, no RewardNoise, counter-based draws: the call the lean instantiations serve.
+// No Logging wrapper, no RewardNoise, counter-based draws, no f64 reward copy (the scalar dm_env view's): the call
+// the lean instantiations serve.
 __host__ __device__ __forceinline__ bool bsx_ctl_lean(const bsx_ctl& c) {
-  return c.log.steps == nullptr && c.wrap_kind < BSX_WRAP_NOISE && c.mt_state == nullptr;
+  return c.log.steps == nullptr && c.wrap_kind < BSX_WRAP_NOISE && c.mt_state == nullptr && c.reward_f64 == nullptr;
 }
 
 __device__ __forceinline__ uint64_t bsx_step_of(const bsx_ctl& c) {
@@ -93,6 +96,7 @@ template <int NOISE = -1>
 __device__ __forceinline__ double bsx_wrap_reward(const bsx_ctl& c, int64_t i, uint64_t lane, uint64_t step,
                                                   double reward) {
   BSX_NO_CONTRACT
+  if (NOISE == 0) return reward * c.wrap_mul;        // RewardScale or nothing: no branch (bsx_ctl.wrap_mul)
   if (c.wrap_kind == BSX_WRAP_SCALE) return reward * c.wrap_param;
   if (NOISE != 0 && c.wrap_kind >= BSX_WRAP_NOISE) {
     // RewardNoise alone, or stacked with RewardScale in either order (each wrapper acts on what the one
@@ -166,7 +170,8 @@ __device__ __forceinline__ void bsx_track(const bsx_ctl& c, int64_t i, int type,
 // The scalar TimeStep fields of one lane: wrapper epilogue + Logging bookkeeping, values only.
 // LOG: -1 decide at run time (c.log.steps != nullptr), 0 logging compiled out, 1 always track.
 // `oi` is the output element (== i for step(); t*B + i inside a fused rollout).
-template <int LOG = -1, int NOISE = -1>
+// F64 = false: the lean instantiations (bsx_ctl_lean: reward_f64 == nullptr) compile the f64 reward copy out.
+template <int LOG = -1, int NOISE = -1, bool F64 = true>
 __device__ __forceinline__ void bsx_emit_values(const bsx_ctl& c, int64_t i, int64_t oi, uint64_t lane, uint64_t step,
                                                 int type, double reward, float& r, float& d) {
   r = 0.0f; d = 1.0f;         // FIRST: dm_env.restart has reward/discount None -> 0 / 1 in a batch
@@ -176,17 +181,17 @@ __device__ __forceinline__ void bsx_emit_values(const bsx_ctl& c, int64_t i, int
     r = (float)wrapped;
     d = (type == BSX_LAST) ? 0.0f : 1.0f;
   }
-  if (c.reward_f64 != nullptr) c.reward_f64[oi] = wrapped;
+  if (F64 && c.reward_f64 != nullptr) c.reward_f64[oi] = wrapped;
   if (LOG == 1 || (LOG == -1 && c.log.steps != nullptr)) bsx_track(c, i, type, wrapped);
 }
 
 // Writes the scalar TimeStep fields of one lane (coalesced: lane i -> element oi of each column;
 // oi == i for step(), oi == t*B + i inside a fused T-step rollout).
-template <int LOG = -1, int NOISE = -1>
+template <int LOG = -1, int NOISE = -1, bool F64 = true>
 __device__ __forceinline__ void bsx_emit_at(const bsx_ctl& c, const bsx_timestep_t& out, int64_t i, int64_t oi,
                                             uint64_t lane, uint64_t step, int type, double reward) {
   float r, d;
-  bsx_emit_values<LOG, NOISE>(c, i, oi, lane, step, type, reward, r, d);
+  bsx_emit_values<LOG, NOISE, F64>(c, i, oi, lane, step, type, reward, r, d);
   out.reward[oi] = r;
   out.discount[oi] = d;
   out.step_type[oi] = (int8_t)type;
@@ -295,7 +300,7 @@ __device__ __forceinline__ void bsx_advance_body(const typename Fam::args& a, ui
     type = Fam::template advance<LEAN>(a, s_fam, i, lane, step, st, act, nst, reward);
     a.state[i] = nst;
     if (s_state != nullptr) s_state[threadIdx.x] = nst;     // fused small-batch step: the tile streamer reads it from LDS
-    if (LEAN) bsx_emit_at<0, 0>(a.ctl, a.out, i, i, lane, step, type, reward);
+    if (LEAN) bsx_emit_at<0, 0, false>(a.ctl, a.out, i, i, lane, step, type, reward);
     else bsx_emit(a.ctl, a.out, i, lane, step, type, reward);
   }
   bsx_count_types(a.ctl, type, s_cnt);
@@ -527,7 +532,7 @@ __global__ void __launch_bounds__(BSX_BLOCK) bsx_fused_rollout_kernel(const type
       type = Fam::template advance<LEAN>(a, s_fam, i, lane, step0 + (uint64_t)t, st, act, nst, reward);
       st = nst;
       s_state[t & 1][threadIdx.x] = nst;
-      if (LEAN) bsx_emit_at<0, 0>(a.ctl, a.out, i, (int64_t)t * B + i, lane, step0 + (uint64_t)t, type, reward);
+      if (LEAN) bsx_emit_at<0, 0, false>(a.ctl, a.out, i, (int64_t)t * B + i, lane, step0 + (uint64_t)t, type, reward);
       else bsx_emit_at(a.ctl, a.out, i, (int64_t)t * B + i, lane, step0 + (uint64_t)t, type, reward);
     }
     bsx_count_types(a.ctl, type, s_cnt);

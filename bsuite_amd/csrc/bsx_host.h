@@ -55,6 +55,7 @@ static inline bsx_ctl bsx_make_ctl(const bsx_call_t* call) {
   c.wrap_param2 = call->wrap.param2;
   c.wrap_seed = call->wrap.seed;
   c.wrap_kind = call->wrap.kind;
+  c.wrap_mul = call->wrap.kind == BSX_WRAP_SCALE ? call->wrap.param : 1.0;
   c.force_reset = call->force_reset;
   c.action_ring_mask = call->action_ring > 1 ? (uint32_t)call->action_ring - 1u : 0u;
   c._pad = 0;
@@ -99,8 +100,7 @@ static inline int bsx_launch_advance(const typename Fam::args& a, hipStream_t st
   const int64_t blocks = (a.ctl.n_lanes + BSX_BLOCK - 1) / BSX_BLOCK;
   if (blocks > 0x7FFFFFFF) return BSX_EINVAL;
   static const int lean_env = bsx_env_int("BSX_ADVANCE_LEAN", 1);
-  const bool lean = lean_env != 0 && a.ctl.log.steps == nullptr && a.ctl.wrap_kind < BSX_WRAP_NOISE &&
-                    a.ctl.mt_state == nullptr;
+  const bool lean = lean_env != 0 && bsx_ctl_lean(a.ctl);
   if (lean) bsx_advance_kernel<Fam, true><<<dim3((unsigned)blocks), dim3(BSX_BLOCK), 0, st>>>(a);
   else bsx_advance_kernel<Fam, false><<<dim3((unsigned)blocks), dim3(BSX_BLOCK), 0, st>>>(a);
   return 0;
@@ -182,6 +182,9 @@ struct bsx_group {
   bsx_group_index index2() const { bsx_group_index gi; gi.start = d_start2; gi.map = d_map2; gi.n = n; return gi; }
   int64_t total_blocks = 0, total_blocks2 = 0;
   bool committed = false;
+  // a two-kernel segment that has store-stream workgroups but one state column only: fine for {advance, stream} in
+  // order, a race in the pipelined launch (the stream of step s would read the column the advance of s+1 writes)
+  bool stream_without_alt = false;
   // launch(g, phase, stream): phase 0 = the first kernel (the lane advance of a two-kernel family, or the
   // whole step of a small-observation group), phase 1 = the observation stream kernel of a two-kernel
   // family (depends on phase 0 of the same group only), phase < 0 = both in order.
@@ -295,7 +298,7 @@ static int bsx_pair_call(const typename Fam::args& a0, const bsx_call_t* call, c
   const bool fusable = call->obs_paint == nullptr && cells >= 4u && (int)cells <= fused_cells &&
                        (((uint64_t)B * cells) & 3ull) == 0 && (reinterpret_cast<uintptr_t>(out.observation) & 15u) == 0;
   const bool fused = fusable && step_bytes <= ((int64_t)(T > 1 ? fused_roll_mib : fused_step_mib) << 20);
-  const bool lean_f = a0.ctl.log.steps == nullptr && a0.ctl.wrap_kind < BSX_WRAP_NOISE && a0.ctl.mt_state == nullptr;
+  const bool lean_f = bsx_ctl_lean(a0.ctl);
   if (fused && T > 1) {
     const dim3 grid((unsigned)((B + BSX_BLOCK - 1) / BSX_BLOCK)), block(BSX_BLOCK);
     if (lean_f) bsx_fused_rollout_kernel<Fam, true, HotFn><<<grid, block, 0, st>>>(a0, T, out.observation, cells, magic, fn);
@@ -325,7 +328,7 @@ static int bsx_pair_call(const typename Fam::args& a0, const bsx_call_t* call, c
   const uint64_t str_blocks = ((uint64_t)B * cells + (uint64_t)K * 4 * BSX_BLOCK - 1) / ((uint64_t)K * 4 * BSX_BLOCK);
   if (adv_blocks + str_blocks > 0x7FFFFFFFull) return BSX_EINVAL;
   const bsx_div64 dv = bsx_make_div64(cells);
-  const bool lean = a0.ctl.log.steps == nullptr && a0.ctl.wrap_kind < BSX_WRAP_NOISE && a0.ctl.mt_state == nullptr;
+  const bool lean = bsx_ctl_lean(a0.ctl);
   typename Fam::args s = at(0);
   s.ctl.state_in = state; s.state = W(0);
   rc = bsx_launch_advance<Fam>(s, st);

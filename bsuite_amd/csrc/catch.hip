@@ -54,8 +54,10 @@ extern "C" int bsx_group_set_catch(bsx_group_t* g, int32_t index, const bsx_catc
     // Whole-sweep group, small boards, one state column (no state_alt): phase 0 — latency-bound, its memory pipe
     // idle — writes the segment's boards itself as fused tiles; the segment leaves the phase-1 store stream, where
     // its 8 KiB runs went at 3.7 TB/s (tools/sweep_stream_parts.py: 27 MB in 7.3 us of a 145 us stream).
-    const bool fused = g->family == BSX_FAM_SWEEP_MIXED && call->state_alt == nullptr && cells <= 128u &&
-                       (((uint64_t)a.ctl.n_lanes * cells) & 3ull) == 0;
+    // (any lane count: the tile of workgroup b starts b*256*cells floats into the 16-byte-aligned array, and
+    // bsx_tile_stream writes the < 4 floats behind the last whole chunk one by one.  The predicate is the one
+    // sweep_batch.prepare_groups uses to decide whether the segment gets a second state column: BSX_FUSED_CATCH_MAX_CELLS.)
+    const bool fused = g->family == BSX_FAM_SWEEP_MIXED && call->state_alt == nullptr && cells <= BSX_FUSED_CATCH_MAX_CELLS;
     if (fused) a.tile_cells_magic = sg.cells_magic;
     return bsx_mixed_put(g, BSX_FAM_CATCH, index, call, &a, sizeof(a), &sg, sizeof(sg),
                               (uint64_t)(a.ctl.n_lanes + BSX_BLOCK - 1) / BSX_BLOCK,

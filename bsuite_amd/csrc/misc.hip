@@ -189,6 +189,7 @@ extern "C" int bsx_group_step_pipelined(bsx_group_t* streams_of, bsx_group_t* ad
       advances_of->family != BSX_FAM_SWEEP_MIXED || streams_of->n != advances_of->n ||
       streams_of->shared_counter != advances_of->shared_counter)
     return BSX_EINVAL;
+  if (streams_of->stream_without_alt || advances_of->stream_without_alt) return BSX_EMODE;
   return bsx_sweep_launch_pipelined(streams_of, advances_of, (hipStream_t)hip_stream);
 }
 

@@ -89,6 +89,7 @@ int bsx_mixed_put(bsx_group* g, int32_t family, int32_t index, const bsx_call_t*
   if (g->tags.empty()) g->tags.assign((size_t)g->n, -1);
   g->tags[index] = family;
   g->blocks[index] = (int32_t)blocks1; g->blocks2[index] = (int32_t)blocks2;
+  if (str != nullptr && blocks2 > 0 && call->state_alt == nullptr) g->stream_without_alt = true;
   if (lds > g->lds_bytes) g->lds_bytes = lds;
   g->is_set[index] = 1;
   g->launch = g->family == BSX_FAM_SWEEP_MIXED ? sweep_mixed_launch : pair_mixed_launch;

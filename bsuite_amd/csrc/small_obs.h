@@ -94,6 +94,25 @@ __device__ __forceinline__ void small_obs_store_row(float* __restrict__ dst, con
   }
 }
 
+// An element `off` BYTES (32 bits, per lane) behind a wave-uniform base: the address add is the memory instruction's
+// (global_store ... v_off, v_data, s[base:base+1]), not three or four 64-bit VALU instructions per access.
+// The pointer is typed as GLOBAL memory (address_space(1)): the slab pointers pass through an opaque asm statement
+// every step (see the loop), after which the compiler no longer knows where a generic pointer leads and would emit
+// FLAT accesses — which count in vmcnt AND lgkmcnt and have no scalar-base form.
+#if defined(__HIP_DEVICE_COMPILE__)
+#define BSX_GLOBAL __attribute__((address_space(1)))
+#else
+#define BSX_GLOBAL              /* (the host pass only parses the device functions) */
+#endif
+template <class T>
+__device__ __forceinline__ BSX_GLOBAL T* bsx_at_off(T* base, uint32_t off) {
+  return (BSX_GLOBAL T*)((BSX_GLOBAL char*)base + off);
+}
+template <class T>
+__device__ __forceinline__ const BSX_GLOBAL T* bsx_at_off(const T* base, uint32_t off) {
+  return (const BSX_GLOBAL T*)((const BSX_GLOBAL char*)base + off);
+}
+
 // The 64 rows of a full wave, through a wave-private LDS staging area, as 16-byte chunks: row-per-lane stores of a
 // 24-byte row are 8-byte pieces at stride 24 — every store instruction touches all of the wave's 64-byte segments with
 // a third of their bytes, three write requests per segment where one would do, and the fused rollouts of the physics
@@ -119,6 +138,32 @@ __device__ __forceinline__ void small_obs_store_rows_wave(float* __restrict__ ds
     reinterpret_cast<float4*>(dst)[c] = reinterpret_cast<const float4*>(s_wave)[c];
   __builtin_amdgcn_wave_barrier();                               // (the next step's rows are written after these reads)
 }
+// ... the same with the destination as {uniform slab pointer, byte offset of the wave's first row}
+__device__ __forceinline__ void small_obs_store_rows_wave_off(float* slab, uint32_t wave_off, const float* o, int numel, float* s_wave, int wl) {
+  float* mine = s_wave + wl * numel;
+  if ((numel & 1) == 0) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+      if (2 * k < numel) *reinterpret_cast<float2*>(mine + 2 * k) = make_float2(o[2 * k], o[2 * k + 1]);
+  } else {
+#pragma unroll
+    for (int k = 0; k < 7; ++k)
+      if (k < numel) mine[k] = o[k];
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  const int chunks = 16 * numel;
+  for (int c = wl; c < chunks; c += 64)
+    *bsx_at_off(reinterpret_cast<float4*>(slab), wave_off + 16u * (uint32_t)c) = reinterpret_cast<const float4*>(s_wave)[c];
+  __builtin_amdgcn_wave_barrier();
+}
+
+// The same value, opaque to the optimiser: what is computed from it stays where it is written (no hoisting out of loops).
+__device__ __forceinline__ uint32_t bsx_fresh(uint32_t v) {
+  asm volatile("" : "+v"(v));
+  return v;
+}
 
 // Fused T-step rollout of a family whose lane state fits in registers (cartpole, swing-up, mountain_car): ONE launch,
 // and nothing inside the step loop ever waits for memory —
@@ -130,7 +175,14 @@ __device__ __forceinline__ void small_obs_store_rows_wave(float* __restrict__ ds
 //  * cartpole's time-fraction table sits in LDS (lgkmcnt) when it fits.
 // r02 (prefetch + in-loop RMW): 70 % of the wave cycles were waits, cartpole 15.1 us per step at 53 % VALU-busy
 // (profiles/r03/cartpole_rollout16_before_pmc_sq.json).
-template <class Env, int LOG, int NOISE, int MT, bool TAB, bool BIG>
+// V: the family's variant as a compile-time constant (Env::numel_of(V) floats per row, cartpole: 0 classic / 1 swing-up),
+// or -1 = read obs_numel / the flags from the arguments.  With the row length a run-time value every `2*k < numel` of
+// the row store became a loop-invariant 64-bit condition mask of its own: 119 SGPR spills and ~90 v_readlane reloads
+// in each copy of the step loop (r03 build; profiles/r04/cartpole_rollout_loop_isa_before.txt).
+// V >= 0 also promises (launch_regs_rollout) that a [B, numel] slab is shorter than 4 GiB: every output of step t is
+// then addressed as {uniform slab pointer, advanced once per step on the scalar unit} + {the lane's 32-bit byte offset,
+// loop-invariant}, and no 64-bit index t*B + i is formed per step and array.
+template <class Env, int LOG, int NOISE, int MT, bool TAB, bool BIG, int V = -1>
 __device__ __forceinline__ void small_obs_regs_rollout(const typename Env::args& a, const int n_steps, const uint32_t block_id,
                                                        float* s_dyn, unsigned int* s_cnt, bsx_reset_pool* s_pool, float* s_rows) {
   constexpr bool IREGS = LOG == 0;
@@ -140,6 +192,7 @@ __device__ __forceinline__ void small_obs_regs_rollout(const typename Env::args&
   // per step, profiles/r03/ab_rows_small_batches.log).
   constexpr bool POOL = BIG && Env::POOLED_RESETS && MT == 0;
   constexpr bool ROWS = BIG && Env::ROWS_VIA_LDS;
+  constexpr bool OFF32 = V >= 0;
   constexpr int RUN = 8;                // (16: no drain inside a T=16 launch at all, and 3-7 % slower — profiles/r03/ab_rollout_run16.log)
   if (threadIdx.x < 2) {
     s_cnt[threadIdx.x] = 0;
@@ -150,9 +203,13 @@ __device__ __forceinline__ void small_obs_regs_rollout(const typename Env::args&
   bsx_lds_table s_tab = (bsx_lds_table)0;
   if constexpr (TAB) s_tab = Env::stage_tables(a, s_dyn);
   __syncthreads();
-  const int numel = a.obs_numel;
+  const int numel = V >= 0 ? Env::numel_of(V) : a.obs_numel;
+  constexpr bool F64 = !(LOG == 0 && NOISE == 0 && MT == 0);       // bsx_ctl_lean: no f64 reward copy
   const int64_t B = a.ctl.n_lanes;
   const int64_t i = (int64_t)block_id * BSX_BLOCK + threadIdx.x;
+  const uint32_t iu0 = (uint32_t)i;
+  // (Tried: BIG variants for whole workgroups only, i.e. no `mine` mask in the loop — fewer scalar registers, but the
+  // scheduler then interleaves across the former block boundary: 65 -> 71 VGPRs for cartpole, 68 -> 85 for swing-up.)
   const bool mine = i < B;
   const uint64_t lane = a.ctl.lane_offset + (uint64_t)i;
   const uint64_t step0 = bsx_step_of(a.ctl);
@@ -160,16 +217,55 @@ __device__ __forceinline__ void small_obs_regs_rollout(const typename Env::args&
   // starts on a 16-byte boundary (wave-uniform)
   const int wl = (int)(threadIdx.x & 63u);
   const bool rows_via_lds = ROWS && (((int64_t)B * numel) & 3) == 0 && (i - wl + 64) <= B;
+  // LAST lanes are counted per thread and pooled once per launch (the per-step wave ballots + LDS atomics of
+  // bsx_count_types were ~12 instructions and two LDS round trips of every wave-step); FIRST steps follow from them:
+  // every LAST is followed by a FIRST except one at the launch's final step, and a lane that arrives with its reset
+  // pending begins with one (no force_reset inside a rollout).
+  uint32_t n_last = 0;
   typename Env::regs rg;
+  Env::clear(rg);
   if (mine) {
     Env::load(a, i, rg);
-    if constexpr (IREGS) Env::load_info(a, i, rg);
+    if constexpr (IREGS) Env::template load_info<V>(a, i, rg);
   }
+  const uint32_t pending_in = Env::reset_pending(rg) ? 1u : 0u;
+  // the slabs of the step under way (OFF32): [B] reward / discount / step_type, [B, numel] observation, [B] action
+  float* rp = a.out.reward;
+  float* dp = a.out.discount;
+  int8_t* sp = a.out.step_type;
+  float* op = a.out.observation;
+  const int32_t* ap = a.action;
 #pragma unroll 1
   for (int t0 = 0; t0 < n_steps; t0 += RUN) {
-    int acts[RUN];
+    const int run = n_steps - t0 < RUN ? n_steps - t0 : RUN;             // uniform
+    // The run's actions: eight registers for eight 2-bit values were what stood between the pooled cartpole loop and
+    // 64 VGPRs (8 waves per SIMD), and picking act[j] cost 7 selects per step.  OFF32 packs them, 4 bits each, into
+    // ONE register (unpacked by one v_bfe_u32 with a scalar shift).  Any int32 is a legal action of these families
+    // (the reference computes (action - 1) * force with whatever it gets, cartpole.py:48): a run in which some lane
+    // of the wave holds an action outside 0..15 re-reads its actions from memory step by step instead (wave-uniform
+    // branch; the wait it needs drains the wave's stores — slow, exact, and never taken by in-spec actions).
+    int acts[OFF32 ? 1 : RUN];
+    uint32_t packed = 0;
+    bool wide = false;
+    const int32_t* const ap_run = ap;
+    if constexpr (OFF32) {
+      if (mine) {
+        // (rows beyond the run re-read its last row: no per-row condition, no table of row strides in scalar registers)
+        const uint32_t off = bsx_fresh(iu0) * 4u;
 #pragma unroll
-    for (int j = 0; j < RUN; ++j) acts[j] = (mine && t0 + j < n_steps) ? a.action[(int64_t)(t0 + j) * B + i] : 0;
+        for (int j = 0; j < RUN; ++j) {
+          const uint32_t aj = (uint32_t)*bsx_at_off(ap, off);
+          packed |= (aj & 15u) << (4 * j);
+          wide |= aj > 15u;
+          if (j + 1 < run) ap += B;                                      // uniform
+        }
+        ap += B;
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < RUN; ++j) acts[j] = (mine && j < run) ? a.action[(int64_t)(t0 + j) * B + i] : 0;
+    }
+    const bool wide_run = OFF32 && __ballot(wide) != 0ull;               // uniform
     // Everything loaded so far has landed before the run starts (vmcnt(0) lgkmcnt(0)): the compiler's wait insertion
     // then knows that no register is waiting for memory inside the run — otherwise every first use of a
     // conditionally loaded value (the swing-up info columns) gets its own vmcnt(0), and on gfx9 that is a drain of
@@ -178,12 +274,21 @@ __device__ __forceinline__ void small_obs_regs_rollout(const typename Env::args&
     // (a ROLLED loop: unrolled, the scheduler interleaves the steps and the kernel needs 140 VGPRs instead of ~75 —
     // half the waves per SIMD, no gain, profiles/r03/ab_regs_rollout.log; the run's action is picked by selects)
 #pragma unroll 1
-    for (int j = 0; j < RUN; ++j) {
+    for (int j = 0; j < run; ++j) {
       const int t = t0 + j;
       int type = -1;
-      int act = acts[0];
+      int act;
+      if constexpr (OFF32) {
+        act = (int)((packed >> (4 * j)) & 15u);
+        if (wide_run) {
+          act = mine ? *bsx_at_off(ap_run + (int64_t)j * B, bsx_fresh(iu0) * 4u) : 0;
+          __builtin_amdgcn_s_waitcnt(0x0070);                            // landed: nothing pends beyond this block
+        }
+      } else {
+        act = acts[0];
 #pragma unroll
-      for (int q = 1; q < RUN; ++q) act = j == q ? acts[q] : act;
+        for (int q = 1; q < RUN; ++q) act = j == q ? acts[q] : act;
+      }
       if constexpr (POOL) {
         // The lanes that begin an episode at this step hand the draws of their reset to a pool: some lane of a
         // wave does on 4 steps in 10 (cartpole, random actions), and then the whole wave walks through two Philox
@@ -192,7 +297,7 @@ __device__ __forceinline__ void small_obs_regs_rollout(const typename Env::args&
         // the waves take turns at it step by step so that the work lands on every SIMD: 306 -> ~215 vector
         // instructions per wave and step, 77 -> 63 VGPRs (profiles/r03/ab_pooled_resets.log).
         const int par = t & 1;
-        if (mine && t < n_steps && Env::wants_reset(a, rg)) {
+        if (mine && Env::template wants_reset<true>(a, rg)) {
           const unsigned slot = atomicAdd(&s_pool->n[par], 1u);
           s_pool->list[slot] = (unsigned short)threadIdx.x;
         }
@@ -205,38 +310,70 @@ __device__ __forceinline__ void small_obs_regs_rollout(const typename Env::args&
         }
         __syncthreads();
       }
-      if (mine && t < n_steps) {
-        const int64_t oi = (int64_t)t * B + i;
+      if (mine) {
+        // (the lane's byte offsets are formed HERE, from a value the compiler cannot trace to the loop's outside: hoisted
+        // out of the loop they are four more live registers, and — zero-extended in another basic block — they no longer
+        // match the {scalar base + 32-bit vector offset} addressing mode, so every access paid a 64-bit add again)
+        const uint32_t iu = bsx_fresh(iu0);
+        const int64_t oi = (int64_t)t * B + i;                           // (dead in the lean instantiations)
         double reward = 0.0;
         float o[8];
-        type = Env::template core<LOG, MT, IREGS, TAB, POOL>(a, rg, act, i, lane, step0 + (uint64_t)t, o, reward, s_tab, s_pool);
-#if !defined(BSX_ABLATE_STORES)
-        bsx_emit_at<LOG, NOISE>(a.ctl, a.out, i, oi, lane, step0 + (uint64_t)t, type, reward);
-        if (rows_via_lds) small_obs_store_rows_wave(a.out.observation + (oi - wl) * (int64_t)numel, o, numel, s_rows + (threadIdx.x - wl) * 8, wl);
-        else small_obs_store_row(a.out.observation + oi * (int64_t)numel, o, numel);
+        type = Env::template core<LOG, MT, IREGS, TAB, POOL, V, true>(a, rg, act, i, lane, step0 + (uint64_t)t, o, reward, s_tab, s_pool);
+        // Measurement builds only (-DBSX_ABLATE_STORES, tools/ablate_stores.sh; never the product library): the loop
+        // without its observation rows (bit 0), without reward / discount / step_type (bit 1) — the conditions are
+        // never true, the stores stay reachable so that the arithmetic feeding them is not compiled away.
+#if defined(BSX_ABLATE_STORES)
+        const bool scalars = !(BSX_ABLATE_STORES & 2) || (reward == 123.0 && type == 7);
+        const bool rows = !(BSX_ABLATE_STORES & 1) || (o[0] == 123.0f && o[1] == 5.0f && o[2] == 7.0f);
 #else
-        // Measurement builds only (tools/ablate_stores.sh; never the product library): the loop without its observation
-        // rows (bit 0), without reward / discount / step_type (bit 1) — the conditions are never true, the stores
-        // stay reachable so that the arithmetic feeding them is not compiled away.
-        if (!(BSX_ABLATE_STORES & 2) || (reward == 123.0 && type == 7)) bsx_emit_at<LOG, NOISE>(a.ctl, a.out, i, oi, lane, step0 + (uint64_t)t, type, reward);
-        if (!(BSX_ABLATE_STORES & 1) || (o[0] == 123.0f && o[1] == 5.0f && o[2] == 7.0f)) {
-          if (rows_via_lds) small_obs_store_rows_wave(a.out.observation + (oi - wl) * (int64_t)numel, o, numel, s_rows + (threadIdx.x - wl) * 8, wl);
-          else small_obs_store_row(a.out.observation + oi * (int64_t)numel, o, numel);
-        }
+        constexpr bool scalars = true, rows = true;
 #endif
+        if (scalars) {
+          if constexpr (OFF32) {
+            float r, d;
+            bsx_emit_values<LOG, NOISE, F64>(a.ctl, i, oi, lane, step0 + (uint64_t)t, type, reward, r, d);
+            *bsx_at_off(rp, iu * 4u) = r;
+            *bsx_at_off(dp, iu * 4u) = d;
+            *bsx_at_off(sp, iu) = (int8_t)type;
+          } else {
+            bsx_emit_at<LOG, NOISE, F64>(a.ctl, a.out, i, oi, lane, step0 + (uint64_t)t, type, reward);
+          }
+        }
+        if (rows) {
+          if constexpr (OFF32) {
+            if (rows_via_lds) small_obs_store_rows_wave_off(op, (iu - (uint32_t)wl) * (uint32_t)(numel * 4), o, numel, s_rows + (threadIdx.x - wl) * 8, wl);
+            else small_obs_store_row(bsx_at_off(op, iu * (uint32_t)(numel * 4)), o, numel);
+          } else {
+            if (rows_via_lds) small_obs_store_rows_wave(a.out.observation + (oi - wl) * (int64_t)numel, o, numel, s_rows + (threadIdx.x - wl) * 8, wl);
+            else small_obs_store_row(a.out.observation + oi * (int64_t)numel, o, numel);
+          }
+        }
       }
-      if (t < n_steps) bsx_count_types(a.ctl, type, s_cnt);             // uniform
+      rp += B; dp += B; sp += B; op += B * (int64_t)numel;                // uniform: the scalar unit's
+      if constexpr (OFF32) {
+        // (opaque, or loop strength reduction folds the four pointers into ONE running offset t*B*4 and every address
+        // becomes base + (offset + lane): not the {scalar base, vector offset} form any more)
+        asm volatile("" : "+s"(rp), "+s"(dp), "+s"(sp), "+s"(op));
+      }
+      n_last += (type == BSX_LAST) ? 1u : 0u;
     }
   }
+  const uint32_t n_first = n_last + pending_in - (Env::reset_pending(rg) ? 1u : 0u);
   if (mine) {
     Env::store(a, i, rg);
-    if constexpr (IREGS) Env::store_info(a, i, rg);
+    if constexpr (IREGS) Env::template store_info<V>(a, i, rg);
+  }
+  if (a.ctl.counters != nullptr) {
+    if (n_last) atomicAdd(&s_cnt[0], n_last);
+    if (n_first) atomicAdd(&s_cnt[1], n_first);
   }
   __syncthreads();
   bsx_flush_counts(a.ctl, s_cnt, block_id);
 }
 
-template <class Env, bool ROLLOUT, int LOG, int NOISE, int MT, bool DIRECT_ARG, bool BIG = false>
+// TABSEL: the register-resident families' table (cartpole's time fractions) is staged in LDS (1) or read from device
+// memory (0) — the launcher knows; -1 = both loops in the kernel, chosen per launch by table_fits().
+template <class Env, bool ROLLOUT, int LOG, int NOISE, int MT, bool DIRECT_ARG, bool BIG = false, int V = -1, int TABSEL = -1>
 __device__ __forceinline__ void small_obs_body(const typename Env::args& a, const int n_steps_arg,
                                                const uint32_t block_id, float* s_obs, unsigned int* s_cnt) {
   constexpr bool DIRECT = DIRECT_ARG || !Env::PACKED;
@@ -251,10 +388,13 @@ __device__ __forceinline__ void small_obs_body(const typename Env::args& a, cons
       __shared__ __attribute__((aligned(16))) float s_rows[BSX_BLOCK * 8];         // 64 rows of <= 8 floats per wave
       rows = s_rows;
     }
-    if (Env::table_fits(a)) small_obs_regs_rollout<Env, LOG, NOISE, MT, true, BIG>(a, n_steps_arg, block_id, s_obs, s_cnt, pool, rows);   // uniform
-    else small_obs_regs_rollout<Env, LOG, NOISE, MT, false, BIG>(a, n_steps_arg, block_id, s_obs, s_cnt, pool, rows);
+    if constexpr (TABSEL == 1) small_obs_regs_rollout<Env, LOG, NOISE, MT, true, BIG, V>(a, n_steps_arg, block_id, s_obs, s_cnt, pool, rows);
+    else if constexpr (TABSEL == 0) small_obs_regs_rollout<Env, LOG, NOISE, MT, false, BIG, V>(a, n_steps_arg, block_id, s_obs, s_cnt, pool, rows);
+    else if (Env::table_fits(a)) small_obs_regs_rollout<Env, LOG, NOISE, MT, true, BIG, V>(a, n_steps_arg, block_id, s_obs, s_cnt, pool, rows);   // uniform
+    else small_obs_regs_rollout<Env, LOG, NOISE, MT, false, BIG, V>(a, n_steps_arg, block_id, s_obs, s_cnt, pool, rows);
     return;
   }
+  constexpr bool F64 = !(LOG == 0 && NOISE == 0 && MT == 0);       // bsx_ctl_lean: no f64 reward copy
   const int n_steps = ROLLOUT ? n_steps_arg : 1;   // the single-step instantiation has no loop: keeping
                                                     // every kernarg live across iterations costs ~120 VGPRs
   if (threadIdx.x < 2) s_cnt[threadIdx.x] = 0;
@@ -279,7 +419,7 @@ __device__ __forceinline__ void small_obs_body(const typename Env::args& a, cons
         double reward = 0.0;
         float o[8];
         type = Env::template step<LOG, MT>(a, i, oi, lane, step0 + (uint64_t)t, o, reward);
-        bsx_emit_at<LOG, NOISE>(a.ctl, a.out, i, oi, lane, step0 + (uint64_t)t, type, reward);
+        bsx_emit_at<LOG, NOISE, F64>(a.ctl, a.out, i, oi, lane, step0 + (uint64_t)t, type, reward);
         // (row-per-lane stores also in a big launch: staging the rows like the fused rollout does left the eager step
         // where it was — 17.5 / 17.5 vs 18.0 / 17.4 us at 2^20 lanes — and cost 4 % at 2^18,
         // profiles/r03/ab_eager_rows_via_lds.log: one memory round trip per launch bounds it, not the write requests;
@@ -308,7 +448,7 @@ __device__ __forceinline__ void small_obs_body(const typename Env::args& a, cons
         float head[HEAD];
         const bsx_bit_sink sink{planes, stride, (uint32_t)((int)threadIdx.x * numel + HEAD)};
         type = Env::template step<LOG, MT, true>(a, i, oi, lane, step0 + (uint64_t)t, head, reward, &sink);
-        bsx_emit_at<LOG, NOISE>(a.ctl, a.out, i, oi, lane, step0 + (uint64_t)t, type, reward);
+        bsx_emit_at<LOG, NOISE, F64>(a.ctl, a.out, i, oi, lane, step0 + (uint64_t)t, type, reward);
 #pragma unroll
         for (int k = 0; k < HEAD; ++k) s_head[threadIdx.x * HEAD + k] = head[k];
         if (t == 0) {
@@ -375,11 +515,26 @@ __device__ __forceinline__ void small_obs_body(const typename Env::args& a, cons
   bsx_flush_counts(a.ctl, s_cnt, block_id);
 }
 
-template <class Env, bool ROLLOUT, int LOG, int NOISE, int MT, bool DIRECT, bool BIG = false>
+template <class Env, bool ROLLOUT, int LOG, int NOISE, int MT, bool DIRECT>
 __global__ void __launch_bounds__(BSX_BLOCK) small_obs_kernel(const typename Env::args a, const int n_steps) {
   extern __shared__ __attribute__((aligned(16))) float s_obs[];
   __shared__ unsigned int s_cnt[2];
-  small_obs_body<Env, ROLLOUT, LOG, NOISE, MT, DIRECT, BIG>(a, n_steps, blockIdx.x, s_obs, s_cnt);
+  small_obs_body<Env, ROLLOUT, LOG, NOISE, MT, DIRECT>(a, n_steps, blockIdx.x, s_obs, s_cnt);
+}
+
+// The lean fused rollout of a register-resident family (no Logging wrapper, no RewardNoise, counter-based draws):
+// one instantiation per (big launch, variant, table in LDS) — everything the step loop would otherwise carry as
+// run-time conditions in scalar registers.
+// (Tried: holding the pooled cartpole loop, 65 VGPRs, to 64 = 8 waves per SIMD, so that the 16 workgroups a CU runs at
+// 2^20 lanes are 8 + 8 instead of 7 + 7 + 2.  amdgpu_waves_per_eu(8, 8) also caps the SCALAR registers at 80 of the
+// 102 — the attribute that made sweep_phase0_kernel spill 157 of them in r03 — and the ~35 reloads per step it costs
+// here cancel the gain: 10.2-10.3 vs 10.0-10.1 us per step, profiles/r04/ab_rollout_8_waves.log; amdgpu_num_vgpr(64)
+// is ignored by this compiler.)
+template <class Env, bool BIG, int V, bool TAB>
+__global__ void __launch_bounds__(BSX_BLOCK) small_obs_lean_rollout_kernel(const typename Env::args a, const int n_steps) {
+  extern __shared__ __attribute__((aligned(16))) float s_obs[];
+  __shared__ unsigned int s_cnt[2];
+  small_obs_body<Env, true, 0, 0, 0, true, BIG, V, TAB ? 1 : 0>(a, n_steps, blockIdx.x, s_obs, s_cnt);
 }
 
 // Dynamic LDS of one workgroup stepping `a`.
@@ -470,6 +625,13 @@ static int small_obs_group_put(bsx_group* g, int32_t family, int32_t index, cons
   return 0;
 }
 
+// variant 1 of a register-resident family that has one (else the instantiation is the same kernel as variant 0's)
+template <class Env>
+static constexpr int small_obs_v1() {
+  if constexpr (Env::HAS_REGS) return Env::N_VARIANTS > 1 ? 1 : 0;
+  else return -1;
+}
+
 // does the family's fused rollout have a variant for big launches (small_obs_regs_rollout, BIG)?
 template <class Env>
 static constexpr bool small_obs_has_big() {
@@ -477,12 +639,38 @@ static constexpr bool small_obs_has_big() {
   else return false;
 }
 
+// Launches the lean fused rollout of a register-resident family (small_obs_lean_rollout_kernel).
+template <class Env>
+static void launch_regs_rollout(const typename Env::args& a, int n_steps, int v, bool big, dim3 g, dim3 b, size_t lds, hipStream_t st) {
+  if constexpr (Env::HAS_REGS) {
+    constexpr bool HB = small_obs_has_big<Env>();
+    constexpr int V1 = small_obs_v1<Env>();
+    const bool tab = Env::table_fits(a);
+#define REGS_ROLLOUT(BIGV, VV)                                                                                     \
+    {                                                                                                              \
+      if (tab) small_obs_lean_rollout_kernel<Env, BIGV, VV, true><<<g, b, lds, st>>>(a, n_steps);                  \
+      else small_obs_lean_rollout_kernel<Env, BIGV, VV, false><<<g, b, lds, st>>>(a, n_steps);                     \
+    }
+    if (v == 1 && big) REGS_ROLLOUT(HB, V1)
+    else if (v == 1) REGS_ROLLOUT(false, V1)
+    else if (big) REGS_ROLLOUT(HB, 0)
+    else REGS_ROLLOUT(false, 0)
+#undef REGS_ROLLOUT
+  }
+}
+
 template <class Env>
 static int launch_small_obs(const typename Env::args& a, int n_steps, void* hip_stream) {
   hipStream_t st = (hipStream_t)hip_stream;
   if (n_steps < 1) return BSX_EINVAL;
   const bool logging = a.ctl.log.steps != nullptr, noise = a.ctl.wrap_kind >= BSX_WRAP_NOISE;
-  const bool lean = !logging && !noise && a.ctl.mt_state == nullptr;
+  const bool lean = bsx_ctl_lean(a.ctl);
+  // the register-resident families' lean rollouts are compiled per variant (row length, swing-up): -1 = none
+  // (and address every [B, numel] slab with 32-bit byte offsets: a slab of 4 GiB or more takes the generic loop)
+  int regs_v = -1;
+  if constexpr (Env::HAS_REGS) {
+    if (a.ctl.n_lanes * (int64_t)a.obs_numel * 4 < ((int64_t)1 << 32)) regs_v = Env::variant_of(a);
+  }
   const int64_t blocks = (a.ctl.n_lanes + BSX_BLOCK - 1) / BSX_BLOCK;
   if (blocks > 0x7FFFFFFF) return BSX_EINVAL;
   const size_t lds = n_steps > 1 ? small_obs_rollout_lds<Env>(a) : small_obs_lds<Env>(a);
@@ -502,7 +690,7 @@ static int launch_small_obs(const typename Env::args& a, int n_steps, void* hip_
     else if (logging && noise) small_obs_kernel<Env, true, 1, 1, -1, D><<<g, b, lds, st>>>(a, n_steps);    \
     else if (logging) small_obs_kernel<Env, true, 1, 0, -1, D><<<g, b, lds, st>>>(a, n_steps);             \
     else if (noise) small_obs_kernel<Env, true, 0, 1, -1, D><<<g, b, lds, st>>>(a, n_steps);               \
-    else if (lean && big) small_obs_kernel<Env, true, 0, 0, 0, D, small_obs_has_big<Env>()><<<g, b, lds, st>>>(a, n_steps); \
+    else if (lean && regs_v >= 0) launch_regs_rollout<Env>(a, n_steps, regs_v, big, g, b, lds, st);        \
     else if (lean) small_obs_kernel<Env, true, 0, 0, 0, D><<<g, b, lds, st>>>(a, n_steps);                 \
     else small_obs_kernel<Env, true, 0, 0, -1, D><<<g, b, lds, st>>>(a, n_steps);                          \
   }
@@ -746,8 +934,16 @@ struct cartpole_env {
   // The lane's state in registers: step() = load + core + store; the fused rollout loads once, runs core
   // T times and stores once (small_obs_body), instead of a round trip through L2 every step.
   static constexpr bool HAS_REGS = true, PACKED = false, POOLED_RESETS = true, ROWS_VIA_LDS = true;
+  // compile-time variants of the lean fused rollout (small_obs_regs_rollout, V): 0 = classic, 1 = swing-up
+  static constexpr int N_VARIANTS = 2;
+  __host__ __device__ static constexpr int numel_of(int v) { return v == 1 ? 8 : 6; }
+  static int variant_of(const args& a) { return a.cfg.swingup ? 1 : 0; }
   struct regs { float x, xd, th, thd; int32_t sk; double inf[4]; };     // inf: the info columns in a fused rollout
-  __device__ static __forceinline__ bool wants_reset(const args& a, const regs& r) { return a.ctl.force_reset || (r.sk & CP_RESET_BIT); }
+  // NOFORCE: inside a rollout (n_steps > 1 excludes force_reset: bsx_check_call)
+  template <bool NOFORCE = false>
+  __device__ static __forceinline__ bool wants_reset(const args& a, const regs& r) { return (!NOFORCE && a.ctl.force_reset) || (r.sk & CP_RESET_BIT); }
+  __device__ static __forceinline__ void clear(regs& r) { r.sk = 0; }
+  __device__ static __forceinline__ bool reset_pending(const regs& r) { return (r.sk & CP_RESET_BIT) != 0; }
   // Half of a lane's reset (cartpole.py:118-128), counter-based stream only: part 0 = x, x_dot from words 0..3 of
   // the (lane, step) stream, part 1 = theta, theta_dot from words 4..7 and the new angle's sine / cosine — the same
   // words, the same arithmetic as core()'s in-line reset, one Philox block per part.
@@ -777,16 +973,18 @@ struct cartpole_env {
     for (int k = threadIdx.x; k < n; k += BSX_BLOCK) s_dyn[k] = a.cfg.time_frac[k];
     return (bsx_lds_table)s_dyn;
   }
+  template <int V = -1>
   __device__ static __forceinline__ void load_info(const args& a, int64_t i, regs& r) {
     const int64_t B = a.ctl.n_lanes;
     r.inf[0] = a.info[i]; r.inf[1] = a.info[B + i];
-    if (a.cfg.swingup) { r.inf[2] = a.info[2 * B + i]; r.inf[3] = a.info[3 * B + i]; }
+    if (V >= 0 ? V == 1 : (bool)a.cfg.swingup) { r.inf[2] = a.info[2 * B + i]; r.inf[3] = a.info[3 * B + i]; }
     else { r.inf[2] = 0.0; r.inf[3] = 0.0; }
   }
+  template <int V = -1>
   __device__ static __forceinline__ void store_info(const args& a, int64_t i, const regs& r) {
     const int64_t B = a.ctl.n_lanes;
     a.info[i] = r.inf[0]; a.info[B + i] = r.inf[1];
-    if (a.cfg.swingup) { a.info[2 * B + i] = r.inf[2]; a.info[3 * B + i] = r.inf[3]; }
+    if (V >= 0 ? V == 1 : (bool)a.cfg.swingup) { a.info[2 * B + i] = r.inf[2]; a.info[3 * B + i] = r.inf[3]; }
   }
   __device__ static __forceinline__ void load(const args& a, int64_t i, regs& r) {
     const int64_t B = a.ctl.n_lanes;
@@ -810,21 +1008,23 @@ struct cartpole_env {
   // IREGS: the info columns are rg.inf[] (fused rollout without Logging), else read-modify-written in HBM.
   // s_tf: the time-fraction table in LDS, or nullptr (-> g.time_frac in device memory).
   // POOL: the reset values were computed by the workgroup's pool (reset_part) and wait in s_pool.
-  template <int LOG, int MT, bool IREGS = false, bool TAB = false, bool POOL = false>
+  // V: -1 = swing-up or not is a.cfg.swingup, 0 / 1 = known at compile time.  NOFORCE: see wants_reset.
+  template <int LOG, int MT, bool IREGS = false, bool TAB = false, bool POOL = false, int V = -1, bool NOFORCE = false>
   __device__ static __forceinline__ int core(const args& a, regs& rg, const int act, int64_t i, uint64_t lane, uint64_t step,
                                              float* o, double& reward, bsx_lds_table s_tf = (bsx_lds_table)0,
                                              const bsx_reset_pool* s_pool = nullptr) {
     BSX_NO_CONTRACT
     const int64_t B = a.ctl.n_lanes;
     const bsx_cartpole_t& g = a.cfg;
+    const bool swingup = V >= 0 ? V == 1 : (bool)g.swingup;
     auto info_get = [&](int col) -> double { if constexpr (IREGS) return rg.inf[col]; else return a.info[(int64_t)col * B + i]; };
     auto info_set = [&](int col, double v) { if constexpr (IREGS) rg.inf[col] = v; else a.info[(int64_t)col * B + i] = v; };
     const int32_t sk = rg.sk;
-    const bool per_step_info = g.swingup || LOG == 1 || (LOG == -1 && a.ctl.log.steps != nullptr);
+    const bool per_step_info = swingup || LOG == 1 || (LOG == -1 && a.ctl.log.steps != nullptr);
     int k = sk & 0x3FFFFFFF;
     float x, xd, th, thd, si, co;
     int type;
-    if (a.ctl.force_reset || (sk & CP_RESET_BIT)) {             // cartpole.py:118-128 / swingup:81-91
+    if ((!NOFORCE && a.ctl.force_reset) || (sk & CP_RESET_BIT)) {   // cartpole.py:118-128 / swingup:81-91
       // (Tried, not adopted — profiles/r03/ab_regs_rollout_scalar_reset_draws.log: walking the wave's few resetting
       // lanes one at a time with wave-uniform inputs puts the Philox rounds on the scalar unit and cuts the vector
       // instructions by 19 %, but the ~200-instruction dependent scalar chain per resetting lane stalls the wave
@@ -882,7 +1082,7 @@ struct cartpole_env {
       const bool timeout = k >= g.last_step;                    // time_elapsed > max_time
       bool end;
       double r;
-      if (!g.swingup) {                                         // cartpole.py:142-153
+      if (!swingup) {                                           // cartpole.py:142-153
         const bool ok = (co > g.height_threshold) && (fabsf(x) < g.x_threshold);
         r = ok ? 1.0 : 0.0;
         end = timeout || !ok;
@@ -920,7 +1120,7 @@ struct cartpole_env {
     const int kf = k < g.last_step ? k : g.last_step;
     if constexpr (TAB) o[5] = s_tf[kf];                         // the fused rollout's LDS copy
     else o[5] = g.time_frac[kf];
-    if (g.swingup) {                                            // swingup:147-149
+    if (swingup) {                                              // swingup:147-149
       o[6] = (fabsf(x) < g.x_reward_threshold) ? 1.0f : -1.0f;
       o[7] = (fabsf(thd) < g.theta_dot_threshold) ? 1.0f : -1.0f;
     }
@@ -940,13 +1140,27 @@ struct mountain_car_env {
   // (resets are rare — 1000-step episodes — and one Philox block: not pooled; the 12-byte rows of a wave are one dense
   // 768-byte range already: staging them gained nothing, profiles/r03/ab_rows_via_lds.log)
   static constexpr bool HAS_REGS = true, PACKED = false, POOLED_RESETS = false, ROWS_VIA_LDS = false;
+  static constexpr int N_VARIANTS = 1;
+  __host__ __device__ static constexpr int numel_of(int) { return 3; }
+  static int variant_of(const args&) { return 0; }
   struct regs { float pos, vel; int32_t sk; double inf0; };             // inf0: raw_return in a fused rollout
+  template <bool NOFORCE = false>
   __device__ static __forceinline__ bool wants_reset(const args&, const regs&) { return false; }
+  __device__ static __forceinline__ void clear(regs& r) { r.sk = 0; }
+  __device__ static __forceinline__ bool reset_pending(const regs& r) { return (r.sk & CP_RESET_BIT) != 0; }
   __device__ static __forceinline__ void reset_part(const args&, uint64_t, uint64_t, int, unsigned, bsx_reset_pool*) {}
-  __host__ __device__ static bool table_fits(const args&) { return false; }
-  static size_t table_bytes(const args&) { return 0; }
-  __device__ static __forceinline__ bsx_lds_table stage_tables(const args&, float*) { return (bsx_lds_table)0; }
+  // Fused rollouts read the time fraction t / max_steps (an f32 division: 11 of the step's ~95 vector instructions)
+  // from a table in LDS that the workgroup fills once per launch with that same division.
+  static constexpr int TABLE_MAX_BYTES = 16384;
+  __host__ __device__ static bool table_fits(const args& a) { return ((int64_t)a.max_steps + 1) * 4 <= TABLE_MAX_BYTES; }
+  static size_t table_bytes(const args& a) { return table_fits(a) ? ((size_t)a.max_steps + 1) * 4 : 0; }
+  __device__ static __forceinline__ bsx_lds_table stage_tables(const args& a, float* s_dyn) {
+    for (int k = threadIdx.x; k <= a.max_steps; k += BSX_BLOCK) s_dyn[k] = (float)k / (float)a.max_steps;
+    return (bsx_lds_table)s_dyn;
+  }
+  template <int V = -1>
   __device__ static __forceinline__ void load_info(const args& a, int64_t i, regs& r) { r.inf0 = a.info[i]; }
+  template <int V = -1>
   __device__ static __forceinline__ void store_info(const args& a, int64_t i, const regs& r) { a.info[i] = r.inf0; }
   __device__ static __forceinline__ void load(const args& a, int64_t i, regs& r) {
     r.sk = a.steps[i]; r.pos = a.state[i]; r.vel = a.state[a.ctl.n_lanes + i];
@@ -963,9 +1177,9 @@ struct mountain_car_env {
     store(a, i, r);
     return type;
   }
-  template <int LOG, int MT, bool IREGS = false, bool TAB = false, bool POOL = false>
+  template <int LOG, int MT, bool IREGS = false, bool TAB = false, bool POOL = false, int V = -1, bool NOFORCE = false>
   __device__ static __forceinline__ int core(const args& a, regs& rg, const int act, int64_t i, uint64_t lane, uint64_t step,
-                                             float* o, double& reward, bsx_lds_table = (bsx_lds_table)0,
+                                             float* o, double& reward, bsx_lds_table s_tf = (bsx_lds_table)0,
                                              const bsx_reset_pool* = nullptr) {
     BSX_NO_CONTRACT
     const int32_t sk = rg.sk;
@@ -973,7 +1187,7 @@ struct mountain_car_env {
     auto info_add = [&](double v) { if constexpr (IREGS) rg.inf0 += v; else a.info[i] += v; };
     float pos, vel;
     int type;
-    if (a.ctl.force_reset || (sk & CP_RESET_BIT)) {             // mountain_car.py:66-71
+    if ((!NOFORCE && a.ctl.force_reset) || (sk & CP_RESET_BIT)) {   // mountain_car.py:66-71
       bsx_draws d;
       bsx_draws_begin<MT>(&d, a.ctl, i, lane, step);
       // an explicit reset() in mid-episode abandons it: its t rewards of -1 stay in raw_return
@@ -1002,7 +1216,8 @@ struct mountain_car_env {
     rg.sk = t | (type == BSX_LAST ? CP_RESET_BIT : 0);
     o[0] = pos;                                                 // :62-64
     o[1] = vel;
-    o[2] = (float)t / (float)a.max_steps;                       // both exact in f32; correctly rounded quotient
+    if constexpr (TAB) o[2] = s_tf[t];                          // (t <= max_steps)
+    else o[2] = (float)t / (float)a.max_steps;                  // both exact in f32; correctly rounded quotient
     return type;
   }
 };

@@ -215,7 +215,7 @@ class SweepBatch:
           numel_k = int(np.prod(raw_k.observation_spec().shape))
           # (small catch boards are written by phase 0 itself, 200 bytes per lane: they belong with the heavy ones)
           small_k = (raw_k._abi_name not in ('deep_sea', 'catch', 'mnist') or  # pylint: disable=protected-access
-                     (raw_k._abi_name == 'catch' and numel_k <= 128))  # pylint: disable=protected-access
+                     (raw_k._abi_name == 'catch' and numel_k <= _native.FUSED_CATCH_MAX_CELLS))  # pylint: disable=protected-access
           return -numel_k if small_k else 1
         members = sorted(members, key=weight)
       def build(parity):
@@ -231,7 +231,7 @@ class SweepBatch:
             # (small catch boards are written by phase 0 itself — fused tiles, csrc/catch.hip — so in a pipelined pair
             # of groups they behave like a small-observation family: one state column, an observation buffer per group)
             pair = (raw._abi_name in ('deep_sea', 'mnist') or  # pylint: disable=protected-access
-                    (raw._abi_name == 'catch' and int(np.prod(raw.observation_spec().shape)) > 128))  # pylint: disable=protected-access
+                    (raw._abi_name == 'catch' and int(np.prod(raw.observation_spec().shape)) > _native.FUSED_CATCH_MAX_CELLS))  # pylint: disable=protected-access
             if pair:
               if k not in self._state_alt:
                 self._state_alt[k] = raw._state['state'].clone()  # pylint: disable=protected-access

@@ -189,6 +189,12 @@ typedef struct {
   int32_t _pad2;
 } bsx_call_t;
 
+/* A catch segment of a BSX_FAM_SWEEP_MIXED group whose board has at most this many cells and that was set WITHOUT
+ * state_alt has its boards written by phase 0 itself (one fused tile per workgroup) and takes no part in the phase-1
+ * store stream: in a pipelined pair of groups it needs one state column and an observation buffer per group, like a
+ * small-observation family.  Larger boards are two-kernel segments and need state_alt there. */
+#define BSX_FUSED_CATCH_MAX_CELLS 128
+
 /* ---- deep_sea : bsuite/environments/deep_sea.py:51-155 ------------------------------------ */
 #define BSX_DEEP_SEA_MAX_SIZE 64
 typedef struct {
@@ -406,7 +412,9 @@ int bsx_group_step_phase(bsx_group_t* g, int32_t phase, void* hip_stream);
  *     bsx_group_step_pipelined(E, O)                   stream of step 0 | advance of step 1
  *     bsx_group_step_pipelined(O, E)                   stream of step 1 | advance of step 2 ...
  * After launch s the TimeStep of step s is complete in the buffers of group (s even ? E : O); the lanes
- * are one advance ahead of it. */
+ * are one advance ahead of it.
+ * BSX_EMODE: a two-kernel segment of either group keeps workgroups in the store stream but was set without
+ * state_alt — the stream of step s would read the column the advance of step s+1 is writing. */
 int bsx_group_step_pipelined(bsx_group_t* streams_of, bsx_group_t* advances_of, void* hip_stream);
 /* Diagnostics (ABI v9): with a device buffer of `capacity` >= 3 * (phase-0 workgroups) uint64 (BSX_EINVAL if
  * smaller; the group must be committed), every phase-0 workgroup of a BSX_FAM_SWEEP_MIXED group records

@@ -96,6 +96,35 @@ def test_lean_fused_rollout_equals_steps(family, na, batch, T):
   assert torch.equal(ta.observation, tb.observation)
 
 
+@pytest.mark.parametrize('family', ['cartpole', 'cartpole_swingup', 'mountain_car'])
+@pytest.mark.parametrize('batch,T', [(1000, 40), ((1 << 19) + 256, 19)])
+def test_lean_fused_rollout_with_actions_outside_the_action_spec(family, batch, T):
+  """Any int32 is a legal action of these families (the reference computes (action - 1) * force with whatever it is
+  given, cartpole.py:48 / mountain_car.py:79).  The lean fused rollout keeps a run of eight actions packed 4 bits each
+  and re-reads a run from memory step by step as soon as some lane of the wave holds an action outside 0..15
+  (small_obs_regs_rollout): here a third of the waves see such runs — negative, large and INT_MIN / INT_MAX actions
+  sprinkled over [T, B] — and the result still equals T step() calls, which never pack."""
+  g = torch.Generator(device='cuda'); g.manual_seed(4)
+  acts = torch.randint(3, (T, batch), generator=g, device='cuda', dtype=torch.int32)
+  odd = torch.tensor([-1, -7, 16, 15, 1000, -2**31, 2**31 - 1, 255], device='cuda', dtype=torch.int64)
+  where = torch.rand((T, batch), generator=g, device='cuda') < 0.002
+  pick = torch.randint(len(odd), (T, batch), generator=g, device='cuda')
+  acts = torch.where(where, odd[pick].to(torch.int32), acts)
+  acts[:, : batch // 2] = acts[:, : batch // 2].clamp(0, 2)         # ... and half of the batch stays in-spec (packed path)
+  a = eu.make_env(family, {}, batch=batch, lane_offset=3, seed=8)
+  b = eu.make_env(family, {}, batch=batch, lane_offset=3, seed=8)
+  ro = a.rollout(acts)
+  for t in range(T):
+    ts = b.step(acts[t])
+    for name, x, y in zip(('step_type', 'reward', 'discount', 'observation'),
+                          (ro.step_type[t], ro.reward[t], ro.discount[t], ro.observation[t]),
+                          (ts.step_type, ts.reward, ts.discount, ts.observation)):
+      assert torch.equal(x, y, ), f'{family} {name} t={t}'
+  for k, v in a.bsuite_info().items():
+    torch.testing.assert_close(v, b.bsuite_info()[k], rtol=0, atol=0)
+  torch.testing.assert_close(a.episode_counters(), b.episode_counters(), rtol=0, atol=0)
+
+
 @pytest.mark.timeout(900)
 def test_big_launch_variant_at_small_shapes():
   """The BIG variant of the register-resident fused rollout (pooled resets, rows staged in LDS) is what a launch of

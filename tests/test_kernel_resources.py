@@ -34,11 +34,14 @@ BUDGET = {
     'bsx_pipelined_kernel<catch_fam, true, catch_hot, 2>': 32,
     'bsx_fused_tile_kernel<catch_fam, true, catch_hot>': 32,
     # configs 3/4: the physics families, eager and fused rollout (lean instantiations)
-    'small_obs_kernel<cartpole_env, false, 0, 0, 0, true, false>': 40,
-    'small_obs_kernel<cartpole_env, true, 0, 0, 0, true, false>': 80,
-    'small_obs_kernel<cartpole_env, true, 0, 0, 0, true, true>': 72,          # BIG: pooled resets, staged rows — 7 waves
-    'small_obs_kernel<mountain_car_env, false, 0, 0, 0, true, false>': 32,
-    'small_obs_kernel<mountain_car_env, true, 0, 0, 0, true, false>': 64,
+    'small_obs_kernel<cartpole_env, false, 0, 0, 0, true>': 40,
+    'small_obs_kernel<mountain_car_env, false, 0, 0, 0, true>': 32,
+    # ... their lean fused rollouts: <family, BIG (pooled resets, staged rows), variant, table in LDS>
+    'small_obs_lean_rollout_kernel<cartpole_env, true, 0, true>': 64,       # 8 waves: 16 workgroups per CU at 2^20 lanes = 8 + 8
+    'small_obs_lean_rollout_kernel<cartpole_env, true, 1, true>': 72,       # swing-up (8-float rows, per-step info): 7 waves
+    'small_obs_lean_rollout_kernel<cartpole_env, false, 0, true>': 64,
+    'small_obs_lean_rollout_kernel<cartpole_env, false, 1, true>': 64,
+    'small_obs_lean_rollout_kernel<mountain_car_env, false, 0, true>': 64,
     # config 5: the whole sweep as one launch group
     'sweep_phase0_kernel': 64,
     'sweep_pipelined_kernel': 64,

@@ -60,9 +60,14 @@ def kernels(lib):
 
 
 def main():
-  args = [a for a in sys.argv[1:] if not a.startswith('--')]
+  argv = sys.argv[1:]
+  flt = ''
+  if '--filter' in argv:
+    k = argv.index('--filter')
+    flt = argv[k + 1]
+    del argv[k:k + 2]
+  args = [a for a in argv if not a.startswith('--')]
   lib = args[0] if args else os.path.join(ROOT, 'bsuite_amd', '_lib', 'libbsuite_amd.so')
-  flt = sys.argv[sys.argv.index('--filter') + 1] if '--filter' in sys.argv else ''
   ks = [k for k in kernels(lib) if flt in k['name']]
   if '--json' in sys.argv:
     print(json.dumps(ks, indent=1))

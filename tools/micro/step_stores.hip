@@ -1,0 +1,112 @@
+// Which of a step's output streams is expensive?  Every lane of a [T, B] rollout writes, per step, a reward (4 B), a
+// discount (4 B), a step_type (1 B) and an observation row (12 B: mountain_car; 24 B: cartpole) into four [T, B, ...]
+// arrays and reads an action (4 B) — per-lane stores exactly as the fused rollout kernels issue them, no arithmetic.
+// Variants switch streams off one at a time, replace the byte stream by a dword stream, and write the scalars as
+// 16-byte chunks staged through the wave's LDS.
+// Build: hipcc --offload-arch=gfx950 -O2 -Wno-unused-value tools/micro/step_stores.hip -o tools/ab/step_stores
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdint>
+
+struct row3 { float a, b, c; } __attribute__((packed, aligned(4)));
+
+// MASK bits: 1 reward, 2 discount, 4 step_type (byte), 8 observation row, 16 action load, 32 step_type as dword,
+// 64 reward/discount/step_type staged per wave and written as 16-byte chunks
+template <int MASK, int ROWF, int F = 0>
+__global__ void __launch_bounds__(256) k(const int32_t* __restrict__ act, float* __restrict__ rew, float* __restrict__ dis,
+                                          int8_t* __restrict__ typ, float* __restrict__ obs, int T, size_t B) {
+  __shared__ __attribute__((aligned(16))) float s_stage[4][64 * 3];
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  const int wl = threadIdx.x & 63, w = threadIdx.x >> 6;
+  float v = (float)threadIdx.x;
+  int a = 0;
+  float r0 = v, r1 = v * 1.5f, r2 = v + 2.f, r3 = v - 3.f;
+  const float m = 1.0000001f, c = 1e-9f;
+  for (int t = 0; t < T; ++t) {
+    const size_t oi = (size_t)t * B + i;
+#pragma unroll
+    for (int f = 0; f < F / 4; ++f) {
+      asm volatile("v_fma_f32 %0, %0, %4, %5\n\tv_fma_f32 %1, %1, %4, %5\n\tv_fma_f32 %2, %2, %4, %5\n\tv_fma_f32 %3, %3, %4, %5"
+                   : "+v"(r0), "+v"(r1), "+v"(r2), "+v"(r3) : "v"(m), "v"(c));
+    }
+    if (F) v = r0 + r1 + r2 + r3;
+    if (MASK & 16) a += act[oi];
+    if (MASK & 64) {
+      s_stage[w][wl] = v; s_stage[w][64 + wl] = v + 1.f;
+      reinterpret_cast<int8_t*>(&s_stage[w][128])[wl] = (int8_t)(t & 3);
+      __builtin_amdgcn_wave_barrier();
+      const size_t w0 = oi - wl;                       // the wave's first element
+      if (wl < 16) reinterpret_cast<float4*>(rew + w0)[wl] = reinterpret_cast<float4*>(&s_stage[w][0])[wl];
+      else if (wl < 32) reinterpret_cast<float4*>(dis + w0)[wl - 16] = reinterpret_cast<float4*>(&s_stage[w][64])[wl - 16];
+      else if (wl < 36) reinterpret_cast<float4*>(typ + w0)[wl - 32] = reinterpret_cast<float4*>(&s_stage[w][128])[wl - 32];
+      __builtin_amdgcn_wave_barrier();
+    } else {
+      if (MASK & 1) rew[oi] = v;
+      if (MASK & 2) dis[oi] = v + 1.f;
+      if (MASK & 4) typ[oi] = (int8_t)(t & 3);
+      if (MASK & 32) reinterpret_cast<int32_t*>(typ)[oi] = t & 3;
+    }
+    if (MASK & 8) {
+      if (ROWF == 3) { row3 r; r.a = v; r.b = v; r.c = v; *reinterpret_cast<row3*>(obs + oi * 3) = r; }
+      else { float2* d = reinterpret_cast<float2*>(obs + oi * 6); d[0] = make_float2(v, v); d[1] = make_float2(v, v); d[2] = make_float2(v, v); }
+    }
+    v += 1.f;
+  }
+  if (a == 123456789) rew[i] = 0.f;
+}
+
+static int32_t* g_act; static float *g_rew, *g_dis, *g_obs; static int8_t* g_typ;
+
+template <int MASK, int ROWF, int F = 0>
+static void run(const char* what, int T, size_t B) {
+  hipEvent_t e0, e1;
+  hipEventCreate(&e0); hipEventCreate(&e1);
+  k<MASK, ROWF, F><<<(unsigned)(B / 256), 256>>>(g_act, g_rew, g_dis, g_typ, g_obs, T, B);
+  hipDeviceSynchronize();
+  hipEventRecord(e0);
+  for (int r = 0; r < 10; ++r) k<MASK, ROWF, F><<<(unsigned)(B / 256), 256>>>(g_act, g_rew, g_dis, g_typ, g_obs, T, B);
+  hipEventRecord(e1);
+  hipEventSynchronize(e1);
+  float ms = 0;
+  hipEventElapsedTime(&ms, e0, e1);
+  const double us = ms / 10 * 1e3;
+  double bytes = 0;
+  if (MASK & 1) bytes += 4; if (MASK & 2) bytes += 4; if (MASK & 4) bytes += 1; if (MASK & 32) bytes += 4;
+  if (MASK & 64) bytes += 9; if (MASK & 8) bytes += 4 * ROWF; if (MASK & 16) bytes += 4;
+  printf("  %-58s %7.2f us per step  %5.2f TB/s (%2.0f B per lane-step)\n", what, us / T, bytes * B * T / us / 1e6, bytes);
+}
+
+template <int ROWF>
+static void table(int T, size_t B) {
+  printf("rows of %d floats, %zu lanes, T = %d\n", ROWF, B, T);
+  run<1 | 2 | 4 | 8 | 16, ROWF>("all five streams (the rollout kernels)", T, B);
+  run<1 | 2 | 4 | 8, ROWF>("without the action loads", T, B);
+  run<1 | 2 | 8 | 16, ROWF>("without step_type", T, B);
+  run<1 | 2 | 32 | 8 | 16, ROWF>("step_type as a dword stream", T, B);
+  run<4 | 8 | 16, ROWF>("without reward / discount", T, B);
+  run<1 | 2 | 4 | 16, ROWF>("without the observation rows", T, B);
+  run<8, ROWF>("observation rows only", T, B);
+  run<1, ROWF>("reward only", T, B);
+  run<4, ROWF>("step_type only", T, B);
+  run<64 | 8 | 16, ROWF>("scalars staged per wave, 16-byte chunks", T, B);
+  run<64, ROWF>("staged scalars only", T, B);
+  run<0, ROWF, 128>("128 FMAs per step, no memory traffic", T, B);
+  run<1 | 2 | 4 | 8, ROWF, 128>("128 FMAs per step + the four store streams", T, B);
+  run<0, ROWF, 256>("256 FMAs per step, no memory traffic", T, B);
+  run<1 | 2 | 4 | 8, ROWF, 256>("256 FMAs per step + the four store streams", T, B);
+  run<0, ROWF, 512>("512 FMAs per step, no memory traffic", T, B);
+  run<1 | 2 | 4 | 8, ROWF, 512>("512 FMAs per step + the four store streams", T, B);
+  run<8, ROWF, 256>("256 FMAs per step + observation rows only", T, B);
+  run<1 | 2 | 4, ROWF, 256>("256 FMAs per step + the three scalar streams", T, B);
+}
+
+int main() {
+  const size_t B = (size_t)1 << 20;
+  const int T = 16;
+  hipMalloc(&g_act, B * T * 4); hipMalloc(&g_rew, B * T * 4); hipMalloc(&g_dis, B * T * 4); hipMalloc(&g_typ, B * T * 4);
+  hipMalloc(&g_obs, B * T * 24);
+  hipMemset(g_act, 0, B * T * 4);
+  table<3>(T, B);
+  table<6>(T, B);
+  return 0;
+}
