@@ -43,6 +43,7 @@ HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICR
 WORKLOADS = {
     'deep_sea': ('deep_sea/10', 'deep_sea', dict(size=30, mapping_seed=42), 900, 8, 31),
     'catch': ('catch/0', 'catch', dict(), 50, 8, 10),
+    'catch_noise': ('catch_noise/0', 'catch', dict(), 50, 8, 10),     # RewardNoise(0.1): the non-lean kernel instantiations
     'cartpole': ('cartpole/0', 'cartpole', dict(), 6, 48, 128),
     'mountain_car': ('mountain_car/0', 'mountain_car', dict(), 3, 24, 1001),
     'bandit': ('bandit/0', 'bandit', dict(mapping_seed=0), 1, 8, 2),
@@ -417,8 +418,10 @@ class Rank:
         for t in range(n_steps):
           env.step(actions[t % n_act])
 
+    run(warmup)                                   # (untimed; the LAST / FIRST counts below are those of the timed steps only)
+    torch.cuda.synchronize(self.dev)
     before = _raw(env).episode_counters().clone()
-    wall, kernel_ms = self.timed(run, steps, warmup)
+    wall, kernel_ms = self.timed(run, steps, 0)
     ended = (_raw(env).episode_counters() - before).to(torch.float64)
 
     # end-of-rollout summary: the only collective on the path (RCCL all-gather over xGMI)
@@ -447,6 +450,50 @@ class Rank:
                 info_sums={k: v for k, v in summary.items()
                            if k not in ('lanes', 'episodes_finished', 'episodes_started', 'timed_last', 'timed_first')},
                 timed_mix=dict(last=summary['timed_last'] / calls, first=summary['timed_first'] / calls))
+
+  def measure_sustained(self, workload, lanes, seconds, window_s=0.5):
+    """Eager step() calls for at least `seconds` of GPU time, a HIP event on the launch stream every ~window_s:
+    ms per step of every window -> min / median / max.  Says whether the 20-step figure of the headline (12 ms of
+    GPU time) holds once clocks, power state and the memory system have seen seconds of the same work; it also puts
+    seconds of GPU activity into the run for whoever samples it from outside."""
+    torch = self.torch
+    bsuite_id, family, okw, obs_numel, state_bytes, period = WORKLOADS[workload]
+    env = self.bsuite_amd.load_from_id(bsuite_id, batch=lanes, device=self.dev, seed=42, lane_offset=self.rank * lanes, num_buffers=2)
+    num_actions = env.action_spec().num_values
+    actions = synthetic_actions(torch, num_actions, 32, self.rank * lanes, lanes, self.dev)
+    stagger_phases(env, actions, period)
+    for t in range(20):
+      env.step(actions[t % 32])
+    torch.cuda.synchronize(self.dev)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for t in range(20):
+      env.step(actions[t % 32])
+    e1.record()
+    torch.cuda.synchronize(self.dev)
+    per_window = max(20, int(window_s * 1e3 / (e0.elapsed_time(e1) / 20)))
+    n_windows = max(4, int(round(seconds / window_s)))
+    events = [torch.cuda.Event(enable_timing=True) for _ in range(n_windows + 1)]
+    t0 = time.perf_counter()
+    events[0].record()
+    t = 0
+    for w in range(n_windows):
+      for _ in range(per_window):
+        env.step(actions[t & 31])
+        t += 1
+      events[w + 1].record()
+      if w >= 2:
+        events[w - 1].synchronize()            # the host stays at most two windows ahead of the GPU
+    torch.cuda.synchronize(self.dev)
+    wall = time.perf_counter() - t0
+    ms = sorted(events[w].elapsed_time(events[w + 1]) / per_window for w in range(n_windows))
+    med = ms[len(ms) // 2]
+    bytes_per_step = algorithmic_bytes_per_step(obs_numel, state_bytes)
+    del env, actions
+    torch.cuda.empty_cache()
+    return {'steps': n_windows * per_window, 'seconds': wall, 'windows': n_windows, 'steps_per_window': per_window,
+            'ms_per_step': {'min': ms[0], 'median': med, 'max': ms[-1]}, 'value': lanes * self.world / (med * 1e-3),
+            'roofline_frac_median': bytes_per_step * lanes / (med * 1e-3) / 1e9 / HBM_PEAK_GBPS, 'mode': 'e', 'lanes_per_gpu': lanes}
 
   def store_ceiling(self):
     """Pure-store ceiling of THIS box (one 16-B store per thread over 2 GiB, no other work): context for
@@ -617,6 +664,13 @@ class Rank:
 
       also['catch/0'] = sub('catch', lanes)                      # the other half of BASELINE.json's metric
       if world == 1:
+        # seconds, not milliseconds, of the two headline workloads (HIP-event time per half-second window); they also sit
+        # between the short timed regions above and the CPU legs below, so that the run's GPU activity is not one burst
+        also['deep_sea/10 sustained'] = self.guarded('sustained', lambda: self.measure_sustained('deep_sea', lanes, args.sustained))
+        also['catch/0 sustained'] = self.guarded('sustained', lambda: self.measure_sustained('catch', lanes, args.sustained * 0.4))
+        # the wrapped path (every *_noise id, every recorded run): the non-lean kernel instantiations
+        also['catch_noise/0'] = sub('catch_noise', lanes)
+        also['deep_sea/10 logging'] = self.guarded('logging', lambda: self.sub_record(self.measure('deep_sea', lanes, K, W, 'eager', 0, 'dense', True)))
         # rollout(actions[T,B]) of the two-kernel families: the open-loop form of the same metric, pipelined
         K32 = (K + 31) // 32 * 32
         also['catch/0 r32'] = sub('catch', lanes, 'rollout', 32, K32, 32)
@@ -679,6 +733,8 @@ def main():
   ap.add_argument('--weak', action='store_true', help='weak scaling: --lanes per GPU')
   ap.add_argument('--strong', action='store_true', help='(the default; kept for older command lines)')
   ap.add_argument('--no-cpu-baseline', action='store_true')
+  ap.add_argument('--sustained', type=float, default=5.0,
+                  help='seconds of eager deep_sea steps in the `also["deep_sea/10 sustained"]` record (catch: 0.4 x)')
   ap.add_argument('--no-also', action='store_true', help='only the main workload (no catch / cartpole / sweep sub-records)')
   ap.add_argument('--no-stagger', action='store_true', help='start all lanes in lock-step (fresh lanes, first call = reset)')
   ap.add_argument('--logging', action='store_true',

@@ -117,12 +117,12 @@ static inline bsx_div64 bsx_make_div64(uint32_t d) {
   return r;
 }
 
-// Launches the split-phase observation writer with K stores per thread (BSX_STREAM_K).
-template <class HotFn>
+// Launches the split-phase observation writer: K stores per thread, 256 threads per workgroup — each family's measured
+// optimum (profiles/r01/sweep_stream_*.log), the only shape the product library contains.  The tuning build compiles the
+// whole K x block-size matrix and picks by BSX_STREAM_K / BSX_STREAM_BS / BSX_STREAM_WAVE_CONTIG.
+template <class HotFn, int K>
 static inline int bsx_launch_hot_stream(float* obs, const int32_t* state, int64_t n_lanes, uint32_t cells,
-                                        uint32_t cells_magic, HotFn fn, hipStream_t st, int default_k) {
-  static const int k_env = bsx_env_int("BSX_STREAM_K", 0);
-  const int k = k_env > 0 ? k_env : default_k;
+                                        uint32_t cells_magic, HotFn fn, hipStream_t st) {
   const uint64_t total = (uint64_t)n_lanes * cells;
   // 4-byte stores for degenerate boards and for an observation slice that does not start on a 16-byte
   // boundary (rollout slice t of an odd B x cells: t*B*cells*4 bytes into the [T,B,cells] array)
@@ -132,6 +132,16 @@ static inline int bsx_launch_hot_stream(float* obs, const int32_t* state, int64_
     bsx_hot_stream_tiny_kernel<HotFn><<<dim3((unsigned)blocks), dim3(BSX_BLOCK), 0, st>>>(obs, state, n_lanes, cells, fn);
     return 0;
   }
+  const bsx_div64 dv = bsx_make_div64(cells);
+#ifndef BSX_TUNING
+  const uint64_t per_block = (uint64_t)K * 4 * BSX_BLOCK;
+  const uint64_t blocks = (total + per_block - 1) / per_block;
+  if (blocks > 0x7FFFFFFFull) return BSX_EINVAL;
+  bsx_hot_stream_kernel<HotFn, K, BSX_BLOCK><<<dim3((unsigned)blocks), dim3(BSX_BLOCK), 0, st>>>(obs, state, n_lanes, cells, cells_magic, dv, fn, 1);
+  return 0;
+#else
+  static const int k_env = bsx_env_int("BSX_STREAM_K", 0);
+  const int k = k_env > 0 ? k_env : K;
   static const int bs_env = bsx_env_int("BSX_STREAM_BS", 256);
   static const int ks[] = {1, 2, 3, 4, 5, 6, 8, 12, 16};
   int kk = 1;
@@ -140,7 +150,6 @@ static inline int bsx_launch_hot_stream(float* obs, const int32_t* state, int64_
   const uint64_t per_block = (uint64_t)kk * 4 * bs;
   const uint64_t blocks = (total + per_block - 1) / per_block;
   if (blocks > 0x7FFFFFFFull) return BSX_EINVAL;
-  const bsx_div64 dv = bsx_make_div64(cells);
   const dim3 g((unsigned)blocks);
   static const int wave_contig = bsx_env_int("BSX_STREAM_WAVE_CONTIG", 1);
 #define BSX_HS(KK, BS) case KK: bsx_hot_stream_kernel<HotFn, KK, BS><<<g, dim3(BS), 0, st>>>(obs, state, n_lanes, cells, cells_magic, dv, fn, wave_contig); break
@@ -153,6 +162,7 @@ static inline int bsx_launch_hot_stream(float* obs, const int32_t* state, int64_
 #undef BSX_HS_ALL
 #undef BSX_HS
   return 0;
+#endif
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -317,7 +327,7 @@ static int bsx_pair_call(const typename Fam::args& a0, const bsx_call_t* call, c
       } else {
         rc = bsx_launch_advance<Fam>(s, st);
         // stores/thread x 256 threads: a sharp optimum per family (profiles/r01/sweep_stream_*.log)
-        if (rc == 0) rc = bsx_launch_hot_stream(s.out.observation, state, B, cells, magic, fn, st, K);
+        if (rc == 0) rc = bsx_launch_hot_stream<HotFn, K>(s.out.observation, state, B, cells, magic, fn, st);
       }
     }
     return rc != 0 ? rc : bsx_launch_status();
@@ -340,7 +350,7 @@ static int bsx_pair_call(const typename Fam::args& a0, const bsx_call_t* call, c
     if (lean) bsx_pipelined_kernel<Fam, true, HotFn, K><<<grid, block, 0, st>>>(s, (uint32_t)adv_blocks, (uint32_t)place, obs_t, W(t), cells, magic, dv, fn);
     else bsx_pipelined_kernel<Fam, false, HotFn, K><<<grid, block, 0, st>>>(s, (uint32_t)adv_blocks, (uint32_t)place, obs_t, W(t), cells, magic, dv, fn);
   }
-  if (rc == 0) rc = bsx_launch_hot_stream(out.observation + (int64_t)(T - 1) * B * (int64_t)cells, state, B, cells, magic, fn, st, K);
+  if (rc == 0) rc = bsx_launch_hot_stream<HotFn, K>(out.observation + (int64_t)(T - 1) * B * (int64_t)cells, state, B, cells, magic, fn, st);
   return rc != 0 ? rc : bsx_launch_status();
 }
 

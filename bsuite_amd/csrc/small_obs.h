@@ -17,6 +17,8 @@
 #ifndef BSX_SMALL_OBS_H_
 #define BSX_SMALL_OBS_H_
 
+#include <type_traits>
+
 #include "bsx_host.h"
 #include "bsx_math.h"
 #include "catch_fam.h"
@@ -193,7 +195,10 @@ __device__ __forceinline__ void small_obs_regs_rollout(const typename Env::args&
   constexpr bool POOL = BIG && Env::POOLED_RESETS && MT == 0;
   constexpr bool ROWS = BIG && Env::ROWS_VIA_LDS;
   constexpr bool OFF32 = V >= 0;
-  constexpr int RUN = 8;                // (16: no drain inside a T=16 launch at all, and 3-7 % slower — profiles/r03/ab_rollout_run16.log)
+#ifndef BSX_RUN
+#define BSX_RUN 8
+#endif
+  constexpr int RUN = OFF32 ? BSX_RUN : 8;                // (16: no drain inside a T=16 launch at all, and 3-7 % slower — profiles/r03/ab_rollout_run16.log)
   if (threadIdx.x < 2) {
     s_cnt[threadIdx.x] = 0;
     if constexpr (POOL) s_pool->n[threadIdx.x] = 0;
@@ -245,7 +250,7 @@ __device__ __forceinline__ void small_obs_regs_rollout(const typename Env::args&
     // of the wave holds an action outside 0..15 re-reads its actions from memory step by step instead (wave-uniform
     // branch; the wait it needs drains the wave's stores — slow, exact, and never taken by in-spec actions).
     int acts[OFF32 ? 1 : RUN];
-    uint32_t packed = 0;
+    typename std::conditional<(RUN > 8), uint64_t, uint32_t>::type packed = 0;
     bool wide = false;
     const int32_t* const ap_run = ap;
     if constexpr (OFF32) {
@@ -254,8 +259,15 @@ __device__ __forceinline__ void small_obs_regs_rollout(const typename Env::args&
         const uint32_t off = bsx_fresh(iu0) * 4u;
 #pragma unroll
         for (int j = 0; j < RUN; ++j) {
+#if defined(BSX_ABLATE_STORES) && (BSX_ABLATE_STORES & 4)
+          const uint32_t aj = (iu0 + (uint32_t)(t0 + j)) % 3u;           // measurement builds: the loop without its action loads
+#elif defined(BSX_ABLATE_STORES) && (BSX_ABLATE_STORES & 8)
+          uint32_t aj = (uint32_t)*bsx_at_off(ap, off);                  // ... with the loads, but the same periodic actions
+          if (aj != 0x7FFFFFF0u) aj = (iu0 + (uint32_t)(t0 + j)) % 3u;
+#else
           const uint32_t aj = (uint32_t)*bsx_at_off(ap, off);
-          packed |= (aj & 15u) << (4 * j);
+#endif
+          packed |= (decltype(packed))(aj & 15u) << (4 * j);
           wide |= aj > 15u;
           if (j + 1 < run) ap += B;                                      // uniform
         }
@@ -265,7 +277,8 @@ __device__ __forceinline__ void small_obs_regs_rollout(const typename Env::args&
 #pragma unroll
       for (int j = 0; j < RUN; ++j) acts[j] = (mine && j < run) ? a.action[(int64_t)(t0 + j) * B + i] : 0;
     }
-    const bool wide_run = OFF32 && __ballot(wide) != 0ull;               // uniform
+    // (one scalar pair says both whether and where: the start of the run's actions, or null)
+    const int32_t* const ap_wide = (OFF32 && __ballot(wide) != 0ull) ? ap_run : nullptr;     // uniform
     // Everything loaded so far has landed before the run starts (vmcnt(0) lgkmcnt(0)): the compiler's wait insertion
     // then knows that no register is waiting for memory inside the run — otherwise every first use of a
     // conditionally loaded value (the swing-up info columns) gets its own vmcnt(0), and on gfx9 that is a drain of
@@ -279,9 +292,9 @@ __device__ __forceinline__ void small_obs_regs_rollout(const typename Env::args&
       int type = -1;
       int act;
       if constexpr (OFF32) {
-        act = (int)((packed >> (4 * j)) & 15u);
-        if (wide_run) {
-          act = mine ? *bsx_at_off(ap_run + (int64_t)j * B, bsx_fresh(iu0) * 4u) : 0;
+        act = (int)((uint32_t)(packed >> (4 * j)) & 15u);
+        if (ap_wide != nullptr) {
+          act = mine ? *bsx_at_off(ap_wide + (int64_t)j * B, bsx_fresh(iu0) * 4u) : 0;
           __builtin_amdgcn_s_waitcnt(0x0070);                            // landed: nothing pends beyond this block
         }
       } else {
@@ -320,7 +333,7 @@ __device__ __forceinline__ void small_obs_regs_rollout(const typename Env::args&
         float o[8];
         type = Env::template core<LOG, MT, IREGS, TAB, POOL, V, true>(a, rg, act, i, lane, step0 + (uint64_t)t, o, reward, s_tab, s_pool);
         // Measurement builds only (-DBSX_ABLATE_STORES, tools/ablate_stores.sh; never the product library): the loop
-        // without its observation rows (bit 0), without reward / discount / step_type (bit 1) — the conditions are
+        // without its observation rows (bit 0), without reward / discount / step_type (bit 1), without action loads (bit 2) — the conditions are
         // never true, the stores stay reachable so that the arithmetic feeding them is not compiled away.
 #if defined(BSX_ABLATE_STORES)
         const bool scalars = !(BSX_ABLATE_STORES & 2) || (reward == 123.0 && type == 7);
@@ -349,7 +362,14 @@ __device__ __forceinline__ void small_obs_regs_rollout(const typename Env::args&
           }
         }
       }
-      rp += B; dp += B; sp += B; op += B * (int64_t)numel;                // uniform: the scalar unit's
+      if constexpr (OFF32) {
+        // (a slab is shorter than 4 GiB: 32-bit strides — three scalar registers instead of three pairs)
+        const uint32_t b1 = (uint32_t)B;
+        rp = (float*)((char*)rp + b1 * 4u); dp = (float*)((char*)dp + b1 * 4u); sp += b1;
+        op = (float*)((char*)op + b1 * (uint32_t)(numel * 4));
+      } else {
+        rp += B; dp += B; sp += B; op += B * (int64_t)numel;              // uniform: the scalar unit's
+      }
       if constexpr (OFF32) {
         // (opaque, or loop strength reduction folds the four pointers into ONE running offset t*B*4 and every address
         // becomes base + (offset + lane): not the {scalar base, vector offset} form any more)
@@ -947,6 +967,10 @@ struct cartpole_env {
   // Half of a lane's reset (cartpole.py:118-128), counter-based stream only: part 0 = x, x_dot from words 0..3 of
   // the (lane, step) stream, part 1 = theta, theta_dot from words 4..7 and the new angle's sine / cosine — the same
   // words, the same arithmetic as core()'s in-line reset, one Philox block per part.
+  // (Tried: these parameters in LDS, read where they are used, instead of ten scalar registers live through the
+  // whole step loop — no spill reload left in any variant's loop, but either the Philox key schedule moves to the
+  // vector unit (80 VGPRs) or, with the words read back into scalar registers, the allocator still ends at 68-71
+  // VGPRs instead of 61-65: one reload per step is the cheaper price.)
   __device__ static __forceinline__ void reset_part(const args& a, uint64_t lane, uint64_t step, int part, unsigned owner,
                                                     bsx_reset_pool* pool) {
     BSX_NO_CONTRACT

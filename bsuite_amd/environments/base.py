@@ -406,6 +406,10 @@ class Environment(dm_env.EnvironmentBase):
     each row to its logger right after the step and reuses the buffer, so it never fills.  Rows past
     max_rows are counted, not stored, and `Logging.rows()` raises: pass max_rows / max_count for longer runs."""
     from bsuite_amd.utils import wrappers as _w  # pylint: disable=import-outside-toplevel
+    if getattr(self, '_grouped_by', None) is not None:
+      # (prepared groups hold this environment's column pointers — a pipelined pair of groups also a CLONE of the packed
+      # state column, pending-miss bits of catch included — and the kernels they launch were chosen without Logging)
+      raise RuntimeError('enable_logging() on a segment of prepared sweep groups: SweepBatch.release_groups() first')
     self._ensure_allocated()
     if self._logging is None:
       # Families that fold an info column only at episode ends (cartpole, mountain_car) switch to the

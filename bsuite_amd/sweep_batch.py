@@ -242,6 +242,7 @@ class SweepBatch:
                        observation=o['observation'] if pair else torch.empty_like(o['observation']))
               extra['out'] = o
           _native.check(raw._group_set(handle, idx, actions[k], **extra), f'bsx_group_set_{raw._abi_name}')  # pylint: disable=protected-access
+          raw._grouped_by = self  # pylint: disable=protected-access  (enable_logging refuses until release_groups())
           outs_of[parity][k] = dm_env.TimeStep(step_type=o['step_type'], reward=o['reward'], discount=o['discount'],
                                                observation=o['observation'])
         _native.check(_native.lib.bsx_group_commit(handle), 'bsx_group_commit')
@@ -468,6 +469,10 @@ class SweepBatch:
       self._pipelined, self._state_alt = False, {}
     for handle in self._groups:
       _native.lib.bsx_group_destroy(handle)
+    if self._groups:
+      for e in self.envs:
+        raw = e.raw_env if hasattr(e, 'raw_env') else e
+        raw._grouped_by = None  # pylint: disable=protected-access
     self._groups = []
     self._groups_by_cost = []
 

@@ -187,8 +187,20 @@ class Logging(_RewardWrapper):
     self._columns = raw.logging_columns()
 
   def flush(self):
+    self.check_overflow()
     if hasattr(self._logger, 'flush'):
       self._logger.flush()
+
+  def check_overflow(self):
+    """Raises as soon as some lane has logged more rows than its buffer holds (one 4-byte device-to-host read).  The
+    batched row buffer is sized for the log points within 100 x bsuite_num_episodes episodes (enable_logging); a run
+    beyond that horizon keeps counting rows but stores no more of them — call this (or flush(), or counters()) now
+    and then rather than learning it from rows() after the run; Logging(..., max_rows=...) sizes the buffer."""
+    cap = self._lg['rows'].shape[1]
+    worst = int(self._lg['n_rows'].max().item())
+    if worst > cap:
+      raise RuntimeError(f'a lane has logged {worst} rows but the buffer holds {cap}: rows are being dropped; '
+                         'construct Logging(..., max_rows=...) for the length of the run')
 
   def _forward_new_rows(self):
     if self._logger is None or not self._raw._scalar:  # pylint: disable=protected-access
@@ -264,7 +276,9 @@ class Logging(_RewardWrapper):
     return pd.DataFrame(self.rows(lane))
 
   def counters(self) -> Dict[str, Any]:
-    """The live per-lane accumulators as device tensors [B] (steps, episode, total_return, ...)."""
+    """The live per-lane accumulators as device tensors [B] (steps, episode, total_return, ...); raises if a lane's
+    row buffer has overflowed (check_overflow)."""
+    self.check_overflow()
     return {k: self._lg[k] for k in ('steps', 'episode', 'total_return', 'episode_len', 'episode_return')}
 
 

@@ -19,17 +19,42 @@ def _free_port():
   return p
 
 
+class _Shard:
+  """The part of the batched Environment surface local_summary() reads (environments/base.py: batch_size,
+  episode_counters(), bsuite_info()), on CPU tensors: lane i of the GLOBAL batch has finished an episode iff
+  i % 3 == 0 and carries total_regret i."""
+
+  def __init__(self, off, n):
+    self.batch_size = n
+    self._lanes = torch.arange(off, off + n, dtype=torch.float64)
+
+  def episode_counters(self):
+    return torch.tensor([int((self._lanes % 3 == 0).sum()), self.batch_size], dtype=torch.int64)
+
+  def bsuite_info(self):
+    return {'total_regret': self._lanes.clone()}
+
+
+class _Wrapped:
+  """... and behind a wrapper (utils/wrappers.py: raw_env + delegation), as bench.py hands it over."""
+
+  def __init__(self, raw):
+    self.raw_env = raw
+
+  def bsuite_info(self):
+    return self.raw_env.bsuite_info()
+
+
 def _worker(rank, world, port, total, q):
   os.environ['MASTER_ADDR'] = '127.0.0.1'
   os.environ['MASTER_PORT'] = str(port)
   dist.init_process_group('gloo', rank=rank, world_size=world)
   off, n = bdist.shard_lanes(total, rank, world)
-  # stand-in for local_summary(env): [lanes, episodes_finished, episodes_started, sum(info)]
-  lanes = torch.arange(off, off + n, dtype=torch.float64)
-  vec = torch.tensor([float(n), float((lanes % 3 == 0).sum()), float(n), float(lanes.sum())],
-                     dtype=torch.float64)
+  env = _Shard(off, n)
+  vec, names = bdist.local_summary(_Wrapped(env) if rank else env)   # the function the GPU path calls (bench.py, sweep_batch.py)
+  assert names == ('lanes', 'episodes_finished', 'episodes_started', 'total_regret')
   g = bdist.all_gather_summary(vec)
-  red = bdist.reduce_summary(g, ('lanes', 'episodes_finished', 'episodes_started', 'total_regret'))
+  red = bdist.reduce_summary(g, names)
   q.put((rank, off, n, g.tolist(), red))
   dist.barrier()
   dist.destroy_process_group()

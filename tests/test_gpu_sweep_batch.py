@@ -189,6 +189,68 @@ def test_pipelined_groups_refuse_the_other_schedules():
 
 
 @pytest.mark.gpu
+def test_pipelined_catch_segments_with_odd_lane_counts(tmp_path):
+  """Python and C must agree on WHICH catch segments phase 0 writes itself (fused tiles, one state column)
+  and which stay two-kernel segments of the store stream (second column needed): both now use
+  BSX_FUSED_CATCH_MAX_CELLS and nothing else, so an odd lane count — lanes x 50 floats not a multiple of 4 — is fused
+  like any other.  The segments are big enough (hundreds of workgroups) that a stream reading a column the next
+  step's advance is already rewriting would show: every step of every lane is compared with a stand-alone env."""
+  ids = ['catch/0', 'catch_noise/3', 'catch_scale/7', 'deep_sea/2', 'cartpole/0', 'bandit/1']
+  total, seed, reps = len(ids) * 60001, 5, 14
+  batch = sb.SweepBatch(ids, total, seed=seed)
+  assert all(lanes % 2 == 1 and (lanes * 50) % 4 != 0 for _, _, lanes in batch.segments[:3])
+  acts = batch.random_actions(seed=3, ring=4)
+  refs = []
+  for (bid, begin, lanes) in batch.segments:
+    ekw = {'seed': seed} if (sweep.SETTINGS[bid].get('seed', 0) is None or 'seed' not in sweep.SETTINGS[bid]) else {}
+    refs.append(bsuite_amd.load_from_id(bid, batch=lanes, lane_offset=begin, num_buffers=1, **ekw))
+  batch.prepare_groups(acts, pipelined=True)
+  for s in range(reps):
+    outs = batch.step_grouped()
+    batch.sync()
+    for (bid, begin, lanes), a, out, ref in zip(batch.segments, acts, outs, refs):
+      ts = ref.step(a[s % 4])
+      for x, y in zip(eu.to_np(out), eu.to_np(ts)):
+        np.testing.assert_array_equal(x, y, err_msg=f'{bid} step {s}')
+  batch.release_groups()
+
+
+@pytest.mark.gpu
+def test_step_pipelined_refuses_a_stream_segment_without_a_second_state_column():
+  """bsx_group_step_pipelined returns BSX_EMODE for a two-kernel segment that keeps workgroups in the store stream
+  but was set without state_alt (the stream of step s would read the column the advance of step s+1 writes)."""
+  import ctypes
+  from bsuite_amd import _native
+  env = bsuite_amd.load_from_id('deep_sea/2', batch=5000, device_step_counter=True)
+  acts = torch.zeros(5000, dtype=torch.int32, device='cuda')
+  groups = []
+  for _ in range(2):
+    h = ctypes.c_void_p()
+    _native.check(_native.lib.bsx_group_create(_native.FAMILY_IDS['sweep_mixed'], 1, ctypes.byref(h)), 'bsx_group_create')
+    _native.check(env._group_set(h, 0, acts), 'bsx_group_set_deep_sea')      # no state_alt
+    _native.check(_native.lib.bsx_group_commit(h), 'bsx_group_commit')
+    groups.append(h)
+  stream = torch.cuda.current_stream().cuda_stream
+  assert _native.lib.bsx_group_step_pipelined(groups[0], groups[1], stream) == _native.BSX_EMODE
+  _native.check(_native.lib.bsx_group_step(groups[0], stream), 'bsx_group_step')   # in order it is a valid group
+  torch.cuda.synchronize()
+  for h in groups:
+    _native.lib.bsx_group_destroy(h)
+
+
+@pytest.mark.gpu
+def test_enable_logging_refused_while_groups_are_prepared():
+  from bsuite_amd.utils import wrappers
+  batch = sb.SweepBatch(['catch/0', 'bandit/0'], 600, seed=1)
+  acts = batch.random_actions(seed=0)
+  batch.prepare_groups(acts, pipelined=True)
+  with pytest.raises(RuntimeError, match='release_groups'):
+    wrappers.Logging(batch.envs[0], None)
+  batch.release_groups()
+  wrappers.Logging(batch.envs[0], None)                      # fine afterwards
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize('pipelined', [False, True])
 def test_action_ring_feeds_fresh_actions_every_group_step(tmp_path, pipelined):
   """bsx_call_t.action_ring: every segment reads row (sweep step mod R) of a pre-generated [R, lanes] ring on the

@@ -49,7 +49,7 @@ BUDGET = {
     'small_obs_mixed_group_kernel': 80,
 }
 # scratch that is not a spill: a dynamically indexed per-thread array in two non-lean instantiations
-KNOWN_SCRATCH = {'small_obs_kernel<umbrella_chain_env, false, -1, -1, -1, true, false>',
+KNOWN_SCRATCH = {'small_obs_kernel<umbrella_chain_env, false, -1, -1, -1, true>',
                  'bsx_fused_rollout_kernel<deep_sea_fam, false, deep_sea_hot>'}
 
 
@@ -62,13 +62,30 @@ def test_hot_kernels_stay_inside_their_register_budgets(kernels):
 
 
 def test_no_kernel_spills_vector_registers(kernels):
-  assert len(kernels) > 150
+  assert 100 < len(kernels) < 160          # (the K x block-size matrix of stream kernels exists in the tuning build only)
   for name, k in kernels.items():
     assert k['vgpr_spill_count'] == 0, f'{name} spills {k["vgpr_spill_count"]} VGPRs'
     if name not in KNOWN_SCRATCH:
       assert k['private_segment_fixed_size'] == 0, f'{name} uses {k["private_segment_fixed_size"]} B of scratch'
     assert k['max_flat_workgroup_size'] in (64, 128, 256, 512, 1024)
     assert k['group_segment_fixed_size'] <= 16 * 1024, f'{name}: {k["group_segment_fixed_size"]} B of static LDS'
+
+
+def test_lean_rollout_step_loops_reload_no_spilled_scalars():
+  """the fused cartpole rollout carried ~90 v_readlane_b32 spill reloads in each copy of its step loop (119
+  SGPR spills: every `2*k < numel` of the row store was a loop-invariant 64-bit mask).  The lean rollouts are now
+  compiled per variant; what the allocator still spills belongs to the prologue / epilogue (state and info column
+  pointers), and the step loop — the inner of the two loops — reloads nothing."""
+  import kernel_isa as ki
+  src = os.path.join(ROOT, 'bsuite_amd', 'csrc', 'small_obs.hip')
+  # kernel -> most reloads in its step loop.  Swing-up (two more thresholds, an f64 move cost, per-step info columns in
+  # registers) still reloads ~20 scalars per step; taking them out cost 6-15 VGPRs in every variant tried (small_obs.h)
+  for want, most in (('small_obs_lean_rollout_kernel<cartpole_env, true, 0, true>', 0), ('small_obs_lean_rollout_kernel<cartpole_env, false, 0, true>', 0),
+                     ('small_obs_lean_rollout_kernel<mountain_car_env, false, 0, true>', 0),
+                     ('small_obs_lean_rollout_kernel<cartpole_env, true, 1, true>', 24), ('small_obs_lean_rollout_kernel<cartpole_env, false, 1, true>', 24)):
+    name, text = ki.kernel_text(src, want)
+    assert sum('v_' in l for l in text) > 300, name
+    assert ki.loop_spill_reloads(text, min_depth=2) <= most, (name, ki.loop_spill_reloads(text, min_depth=2))
 
 
 def test_lean_instantiations_keep_full_occupancy(kernels):

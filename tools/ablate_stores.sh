@@ -1,14 +1,14 @@
 #!/bin/bash
 # What bounds the fused physics rollouts: builds three measurement variants of the library into tools/ab/ (git-ignored,
 # carried to the GPU box) in which small_obs_regs_rollout leaves out its observation rows (1), its reward / discount /
-# step_type stores (2) or both (3) — the arithmetic stays — and prints the gpurun command that times them next to the
+# step_type stores (2) or both (3), its action loads (4: the only reads inside the loop; 7: no memory traffic in the loop at all) — the arithmetic stays — and prints the gpurun command that times them next to the
 # product library in ONE call (profiles/r03/exp_store_ablation.log).
 set -eu
 cd "$(git rev-parse --show-toplevel)"
 python -m bsuite_amd.build | tail -1
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fPIC -fno-fast-math -Iinclude -Ibsuite_amd/csrc"
 mkdir -p tools/ab
-for e in 1 2 3; do
+for e in ${ABLATE:-1 2 3}; do
   hipcc $FLAGS -DBSX_ABLATE_STORES=$e -c bsuite_amd/csrc/small_obs.hip -o /tmp/small_obs_ablate$e.o
   hipcc --offload-arch=gfx950 -shared -fPIC -o tools/ab/libbsx_ablate$e.so /tmp/small_obs_ablate$e.o $(ls bsuite_amd/_lib/*.o | grep -v small_obs.o)
 done

@@ -92,6 +92,38 @@ def census(text):
   return blocks
 
 
+def loop_spill_reloads(text, min_depth=2):
+  """SGPR spill reloads (v_readlane_b32 sN, vM, <constant lane>) inside loops nested at least `min_depth` deep — the
+  step loop of a fused rollout is the inner of two.  The block labels carry the compiler's loop comments."""
+  depth, n = 0, 0
+  for l in text:
+    m = re.match(r'^\.LBB\d+_\d+:\s*;(.*)$', l)
+    if m:
+      d = re.search(r'Depth=(\d+)', m.group(1))
+      depth = int(d.group(1)) if d else 0
+      continue
+    if re.match(r'^\.LBB\d+_\d+:', l) or l.startswith('; %bb.'):
+      d = re.search(r'Depth=(\d+)', l)
+      depth = int(d.group(1)) if d else 0
+      continue
+    if depth >= min_depth and re.search(r'v_readlane_b32 s\d+, v\d+, \d+', l):
+      n += 1
+  return n
+
+
+def kernel_text(src, want, defines=()):
+  """(demangled name, assembly lines) of the one kernel of `src` whose name contains `want`."""
+  lines = assembly(os.path.abspath(src), defines)
+  fns = functions(lines)
+  hits = [n for n in fns if want in n]
+  if len(hits) != 1:
+    hits = [n for n in hits if n == want]
+  if len(hits) != 1:
+    raise KeyError(f'{want!r} matches {len(hits)} kernels')
+  i, j = fns[hits[0]]
+  return hits[0], lines[i:j]
+
+
 def main():
   argv = sys.argv[1:]
   defines = [a for a in argv if a.startswith('-D')]
@@ -132,6 +164,7 @@ def main():
       total[k] = total.get(k, 0) + v
     print(f'{name:>12} ' + ' '.join(f'{cnt.get(c, 0):9d}' for c in cols))
   print(f'{"total":>12} ' + ' '.join(f'{total.get(c, 0):9d}' for c in cols))
+  print('SGPR spill reloads inside loops of depth >= 2:', loop_spill_reloads(text))
 
 
 if __name__ == '__main__':

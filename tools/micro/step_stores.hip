@@ -55,6 +55,7 @@ __global__ void __launch_bounds__(256) k(const int32_t* __restrict__ act, float*
   if (a == 123456789) rew[i] = 0.f;
 }
 
+static int g_rot = 1;
 static int32_t* g_act; static float *g_rew, *g_dis, *g_obs; static int8_t* g_typ;
 
 template <int MASK, int ROWF, int F = 0>
@@ -64,7 +65,9 @@ static void run(const char* what, int T, size_t B) {
   k<MASK, ROWF, F><<<(unsigned)(B / 256), 256>>>(g_act, g_rew, g_dis, g_typ, g_obs, T, B);
   hipDeviceSynchronize();
   hipEventRecord(e0);
-  for (int r = 0; r < 10; ++r) k<MASK, ROWF, F><<<(unsigned)(B / 256), 256>>>(g_act, g_rew, g_dis, g_typ, g_obs, T, B);
+  // g_rot > 1: every launch reads another copy of the action array (g_rot * 67 MB in rotation: no copy stays in the
+  // 256 MiB Infinity Cache from one launch to the next, the loads come from HBM)
+  for (int r = 0; r < 10; ++r) k<MASK, ROWF, F><<<(unsigned)(B / 256), 256>>>(g_act + (size_t)(r % g_rot) * B * T, g_rew, g_dis, g_typ, g_obs, T, B);
   hipEventRecord(e1);
   hipEventSynchronize(e1);
   float ms = 0;
@@ -72,7 +75,7 @@ static void run(const char* what, int T, size_t B) {
   const double us = ms / 10 * 1e3;
   double bytes = 0;
   if (MASK & 1) bytes += 4; if (MASK & 2) bytes += 4; if (MASK & 4) bytes += 1; if (MASK & 32) bytes += 4;
-  if (MASK & 64) bytes += 9; if (MASK & 8) bytes += 4 * ROWF; if (MASK & 16) bytes += 4;
+  if (MASK & 64) bytes += 9; if (MASK & 8) bytes += 4 * ROWF; if (MASK & (16 | 128 | 256)) bytes += 4;
   printf("  %-58s %7.2f us per step  %5.2f TB/s (%2.0f B per lane-step)\n", what, us / T, bytes * B * T / us / 1e6, bytes);
 }
 
@@ -81,6 +84,9 @@ static void table(int T, size_t B) {
   printf("rows of %d floats, %zu lanes, T = %d\n", ROWF, B, T);
   run<1 | 2 | 4 | 8 | 16, ROWF>("all five streams (the rollout kernels)", T, B);
   run<1 | 2 | 4 | 8, ROWF>("without the action loads", T, B);
+  run<1 | 2 | 4 | 8 | 128, ROWF>("action loads in runs of 8 (one wait per run)", T, B);
+  run<1 | 2 | 4 | 8 | 256, ROWF>("all action loads before the first store", T, B);
+  run<128, ROWF>("action loads only (runs of 8)", T, B);
   run<1 | 2 | 8 | 16, ROWF>("without step_type", T, B);
   run<1 | 2 | 32 | 8 | 16, ROWF>("step_type as a dword stream", T, B);
   run<4 | 8 | 16, ROWF>("without reward / discount", T, B);
@@ -103,10 +109,17 @@ static void table(int T, size_t B) {
 int main() {
   const size_t B = (size_t)1 << 20;
   const int T = 16;
-  hipMalloc(&g_act, B * T * 4); hipMalloc(&g_rew, B * T * 4); hipMalloc(&g_dis, B * T * 4); hipMalloc(&g_typ, B * T * 4);
+  hipMalloc(&g_act, B * T * 4 * 8); hipMalloc(&g_rew, B * T * 4); hipMalloc(&g_dis, B * T * 4); hipMalloc(&g_typ, B * T * 4);
   hipMalloc(&g_obs, B * T * 24);
-  hipMemset(g_act, 0, B * T * 4);
+  hipMemset(g_act, 0, B * T * 4 * 8);
   table<3>(T, B);
   table<6>(T, B);
+  g_rot = 8;
+  printf("the same with the actions read from HBM (8 copies in rotation)\n");
+  run<1 | 2 | 4 | 8 | 128, 3>("rows of 3: action loads in runs of 8", T, B);
+  run<1 | 2 | 4 | 8 | 256, 3>("rows of 3: all action loads before the first store", T, B);
+  run<128, 3>("rows of 3: action loads only (runs of 8)", T, B);
+  run<1 | 2 | 4 | 8 | 128, 6>("rows of 6: action loads in runs of 8", T, B);
+  run<1 | 2 | 4 | 8 | 128, 3, 128>("rows of 3: 128 FMAs + action loads in runs of 8", T, B);
   return 0;
 }
