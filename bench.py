@@ -521,7 +521,7 @@ class Rank:
     """HBM roofline of a record: algorithmic bytes per launch / launch time by HIP events.  Fused
     rollouts of the physics families also carry the VALU-issue roofline (`valu`: wave-instructions of the committed
     SQ pass / launch time against one wave64 instruction per 2 cycles and SIMD): their state stays in registers for
-    T steps, and neither ceiling is close — the record's `bound` is the nearer one (DESIGN §3.3 has the ablation:
+    T steps, and neither ceiling is close — the record's `bound` is the nearer one (DESIGN §3.3 has the ablations:
     cartpole 7.1 us of arithmetic + 5.1 us of stores at the fill rate, 10.6-11 us measured)."""
     out = {'bound': 'hbm', 'achieved': r['achieved'], 'peak': HBM_PEAK_GBPS, 'unit': 'GB/s',
            'frac': r['achieved'] / HBM_PEAK_GBPS, 'traffic': r['traffic']}

@@ -6,7 +6,7 @@ hipcc cross-compiles for gfx950 without a GPU.  The .so is built in-tree so that
 the repository snapshot to the GPU box (it is git-ignored, not gpurun-ignored).
 
 --tuning additionally builds libbsuite_amd_tuning.so: the same sources compiled with -DBSX_TUNING, the
-only build in which the A/B knobs of DESIGN §9 (BSX_STREAM_K, BSX_PIPELINED_PLACE, ...) are read from
+only build in which the A/B knobs of DESIGN §8 (BSX_STREAM_K, BSX_PIPELINED_PLACE, ...) are read from
 the environment.  The product library reads no environment variable; the A/B scripts under tools/ and the
 tests of the non-default settings load the tuning build through BSX_NATIVE_LIB.
 """

@@ -80,7 +80,7 @@ static inline int bsx_n_steps(const bsx_call_t* call) { return call->n_steps > 1
 // magic for q = n / d via __umulhi(n, magic): exact for n < 2^20, d <= 4096
 static inline uint32_t bsx_div_magic(uint32_t d) { return (uint32_t)((0x100000000ull / d) + 1ull); }
 
-// A/B knobs (DESIGN §9).  The product library never reads the environment: the knobs exist only in the
+// A/B knobs (DESIGN §8).  The product library never reads the environment: the knobs exist only in the
 // tuning build (`python -m bsuite_amd.build --tuning` -> libbsuite_amd_tuning.so, compiled with -DBSX_TUNING and
 // loaded through BSX_NATIVE_LIB by the A/B scripts under tools/ and by the tests that cover the non-default
 // settings); everywhere else every knob is its measured-best default, fixed at compile time.
@@ -119,7 +119,7 @@ static inline bsx_div64 bsx_make_div64(uint32_t d) {
 
 // Launches the split-phase observation writer: K stores per thread, 256 threads per workgroup — each family's measured
 // optimum (profiles/r01/sweep_stream_*.log), the only shape the product library contains.  The tuning build compiles the
-// whole K x block-size matrix and picks by BSX_STREAM_K / BSX_STREAM_BS / BSX_STREAM_WAVE_CONTIG (DESIGN §9).
+// whole K x block-size matrix and picks by BSX_STREAM_K / BSX_STREAM_BS / BSX_STREAM_WAVE_CONTIG (DESIGN §8).
 template <class HotFn, int K>
 static inline int bsx_launch_hot_stream(float* obs, const int32_t* state, int64_t n_lanes, uint32_t cells,
                                         uint32_t cells_magic, HotFn fn, hipStream_t st) {

@@ -13,7 +13,7 @@ independent, so:
   `bsx_<family>_step` takes — in a device-resident table (include/bsuite_amd.h `bsx_group_*`).  By
   default the whole sweep is ONE group (`BSX_FAM_SWEEP_MIXED`) and a sweep step is TWO launches: phase 0
   advances every lane of every family and bumps the shared call counter, phase 1 is the observation
-  store stream of deep_sea / catch / mnist (DESIGN.md §7b).  The finer-grained groups (one per family,
+  store stream of deep_sea / catch / mnist (DESIGN.md §3.5).  The finer-grained groups (one per family,
   mixed small families, mixed two-kernel families) and other schedules (`step_grouped_streams`,
   `capture_grouped`) are kept for A/B; the oldest path (`capture` / `replay`) spreads per-segment
   launches over HIP streams and replays them as one HIP graph.  Call indices of the draw stream live

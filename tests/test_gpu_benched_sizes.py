@@ -67,7 +67,7 @@ def test_config5_full_sweep_as_benched(tmp_path, pipelined):
       live = st != 0
       if fam in PHYSICS:
         # free-running f32 engine vs the f64 oracle (no teacher forcing inside a grouped launch): the lanes
-        # whose step types still agree stay within the drift DESIGN §5 reports for a few dozen calls
+        # whose step types still agree stay within the drift profiles/HISTORY.md §5 reports for a few dozen calls
         same &= gst == st
         assert same.mean() > 0.7, bid
         assert np.abs(go[same].astype(np.float64) - o[same]).max() <= 2e-4, (bid, s)

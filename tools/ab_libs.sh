@@ -4,7 +4,7 @@
 # to the GPU box like every other .so), to be loaded through BSX_NATIVE_LIB:
 #   bash tools/ab_libs.sh <git-rev>            -> tools/ab/libbsuite_amd_prev.so
 # then e.g.   gpurun -- 'for lib in tools/ab/libbsuite_amd_prev.so ""; do BSX_NATIVE_LIB=$lib python tools/lanes_sweep.py catch -- 2**17 2**20; done'
-# Tuning knobs (DESIGN §9) are read by the tuning build only: BSX_NATIVE_LIB=bsuite_amd/_lib/libbsuite_amd_tuning.so.
+# Tuning knobs (DESIGN §8) are read by the tuning build only: BSX_NATIVE_LIB=bsuite_amd/_lib/libbsuite_amd_tuning.so.
 set -eu
 rev=${1:-HEAD}
 root=$(git rev-parse --show-toplevel)
