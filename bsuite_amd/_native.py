@@ -90,7 +90,7 @@ class Call(ctypes.Structure):
               ('stream', Stream), ('wrap', RewardWrap), ('counters', ctypes.c_void_p),
               ('hip_stream', ctypes.c_void_p), ('logging', ctypes.POINTER(Logging)),
               ('obs_paint', ctypes.c_void_p), ('reward_f64', ctypes.c_void_p),
-              ('state_alt', ctypes.c_void_p), ('action_ring', ctypes.c_int32), ('_pad2', ctypes.c_int32)]
+              ('state_alt', ctypes.c_void_p), ('action_ring', ctypes.c_int32), ('flags', ctypes.c_int32)]
 
 
 class DeepSeaCfg(ctypes.Structure):
@@ -214,7 +214,8 @@ for _name, (_args, _res) in _SIGS.items():
   _fn.restype = _res
 if MISSING:
   raise NativeLibraryError(f'{SO_PATH} does not export {MISSING}; rebuild with `python -m bsuite_amd.build --force`')
-ABI_VERSION = 10
+ABI_VERSION = 11
+CALL_STATE_TAGGED = 1   # BSX_CALL_STATE_TAGGED
 if lib.bsx_abi_version() != ABI_VERSION:
   raise NativeLibraryError('ABI version mismatch between bsuite_amd/_native.py and libbsuite_amd.so')
 

@@ -7,6 +7,11 @@
 #include "bsx_device.h"
 
 #define DS_RESET_BIT (1 << 17)
+// Bit 18 of the packed state: the parity of the call index that will READ the word next — every advance writes
+// ((step + 1) & 1) there.  It costs nothing and lets the single-launch step (deep_sea_step1_kernel, deep_sea.hip) tell
+// a word its lane's writer has already advanced in this launch from one it has not; nobody else looks at it.
+#define DS_TAG_SHIFT 18
+#define DS_TAG_BIT (1 << DS_TAG_SHIFT)
 #define DS_MAP_WORDS (BSX_DEEP_SEA_MAX_SIZE * BSX_DEEP_SEA_MAX_SIZE / 32)
 
 struct deep_sea_fam {
@@ -31,12 +36,17 @@ struct deep_sea_fam {
 
   // One lane's reset()/step() (base.py:59-65 -> deep_sea.py:110-144).
   // LEAN: counter-based draws only (the MT19937-exact mode is compiled out)
-  template <bool LEAN = false>
+  // commit = false: compute the transition only, leave the bsuite_info columns alone (a thread of the single-launch
+  // step that needs the lane's new state but is not the lane's writer)
+  // DET = 1: the caller knows the environment is deterministic (and LEAN): no draw exists, the Philox block and the f64
+  // normal transform are compiled out — what the per-thread recomputation of the single-launch step can afford.
+  template <bool LEAN = false, int DET = -1>
   __device__ static __forceinline__ int advance(const args& a, const shared& s, int64_t i, uint64_t lane,
                                                 uint64_t step, int32_t st, int act, int32_t& nst,
-                                                double& reward) {
+                                                double& reward, const bool commit = true) {
     BSX_NO_CONTRACT
     const int N = a.size;
+    const bool deterministic = DET == 1 || a.deterministic;
     int row = st & 0xFF, col = (st >> 8) & 0xFF, bad = (st >> 16) & 1;
     int type;
     reward = 0.0;
@@ -51,18 +61,18 @@ struct deep_sea_fam {
       bsx_draws_begin<LEAN ? 0 : -1>(&d, a.ctl, i, lane, step);
       if (col == N - 1 && right) {                              // :121-123
         reward += 1.0;
-        a.info[a.ctl.n_lanes + i] += 1.0;
+        if (commit) a.info[a.ctl.n_lanes + i] += 1.0;
       }
-      if (!a.deterministic && row == N - 1 && (col == 0 || col == N - 1))   // :124-126
+      if (!deterministic && row == N - 1 && (col == 0 || col == N - 1))   // :124-126
         reward += bsx_normal(&d);
       if (right) {                                              // :129-132
         // The reference draws rand() here even when deterministic (the value is then unused).  The
         // counter-based stream restarts at every call, so an unused draw leaves no trace and is
         // skipped; the lane's own MT19937 generator (exact mode) must advance, so there it is drawn.
         bool moves = true;
-        if (!a.deterministic || (!LEAN && a.ctl.mt_state != nullptr)) {
+        if (!deterministic || (!LEAN && a.ctl.mt_state != nullptr)) {
           const double u = bsx_uniform(&d);
-          moves = (u > a.inv_size) || a.deterministic;
+          moves = (u > a.inv_size) || deterministic;
         }
         if (moves) col = col + 1 > N - 1 ? N - 1 : col + 1;
         reward -= a.move_cost;
@@ -73,13 +83,13 @@ struct deep_sea_fam {
       bsx_draws_end<LEAN ? 0 : -1>(&d, a.ctl, i);
       row += 1;                                                 // :137
       if (row == N) {                                           // :140-143
-        if (bad) a.info[i] += 1.0;
+        if (bad && commit) a.info[i] += 1.0;
         type = BSX_LAST;
       } else {
         type = BSX_MID;
       }
     }
-    nst = row | (col << 8) | (bad << 16) | (type == BSX_LAST ? DS_RESET_BIT : 0);
+    nst = row | (col << 8) | (bad << 16) | (type == BSX_LAST ? DS_RESET_BIT : 0) | (int32_t)(((uint32_t)(step + 1) & 1u) << DS_TAG_SHIFT);
     return type;
   }
 };

@@ -542,6 +542,49 @@ __global__ void __launch_bounds__(BSX_BLOCK) small_obs_kernel(const typename Env
   small_obs_body<Env, ROLLOUT, LOG, NOISE, MT, DIRECT>(a, n_steps, blockIdx.x, s_obs, s_cnt);
 }
 
+// Eager step of a register-resident family, TWO lanes per thread (lean calls of 2^19+ lanes): thread t of workgroup b
+// advances lanes b*512 + t and b*512 + 256 + t, the loads of BOTH issued before the first use.  At 2^20 lanes the
+// one-lane kernel is 4096 workgroups = two dispatch rounds of a launch whose every wave is one dependent chain
+// {column loads -> step -> stores}; this one is a single round with twice the bytes in flight per wave.
+template <class Env, int V>
+__global__ void __launch_bounds__(BSX_BLOCK) small_obs_eager2_kernel(const typename Env::args a) {
+  __shared__ unsigned int s_cnt[2];
+  if (threadIdx.x < 2) s_cnt[threadIdx.x] = 0;
+  __syncthreads();
+  const int numel = Env::numel_of(V);
+  const int64_t B = a.ctl.n_lanes;
+  const uint64_t step = bsx_step_of(a.ctl);
+  int64_t i[2];
+  bool mine[2];
+  typename Env::regs rg[2];
+  int act[2], type[2] = {-1, -1};
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    i[h] = (int64_t)blockIdx.x * (2 * BSX_BLOCK) + h * BSX_BLOCK + threadIdx.x;
+    mine[h] = i[h] < B;
+    Env::clear(rg[h]);
+    act[h] = 0;
+    if (mine[h]) {
+      Env::load(a, i[h], rg[h]);
+      if (!a.ctl.force_reset) act[h] = bsx_action(a.ctl, a.action, i[h], step);
+    }
+  }
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    if (mine[h]) {
+      double reward = 0.0;
+      float o[8];
+      type[h] = Env::template core<0, 0, false, false, false, V>(a, rg[h], act[h], i[h], a.ctl.lane_offset + (uint64_t)i[h], step, o, reward);
+      bsx_emit_at<0, 0, false>(a.ctl, a.out, i[h], i[h], a.ctl.lane_offset + (uint64_t)i[h], step, type[h], reward);
+      small_obs_store_row(a.out.observation + i[h] * (int64_t)numel, o, numel);
+      Env::store(a, i[h], rg[h]);
+    }
+    bsx_count_types(a.ctl, type[h], s_cnt);
+  }
+  __syncthreads();
+  bsx_flush_counts(a.ctl, s_cnt, blockIdx.x);
+}
+
 // The lean fused rollout of a register-resident family (no Logging wrapper, no RewardNoise, counter-based draws):
 // one instantiation per (big launch, variant, table in LDS) — everything the step loop would otherwise carry as
 // run-time conditions in scalar registers.
@@ -679,6 +722,19 @@ static void launch_regs_rollout(const typename Env::args& a, int n_steps, int v,
   }
 }
 
+// two lanes per thread from this many (one-lane) workgroups up; 0 = never
+#ifndef BSX_EAGER2_MIN_BLOCKS_DEFAULT
+#define BSX_EAGER2_MIN_BLOCKS_DEFAULT 0
+#endif
+template <class Env>
+static void launch_eager2(const typename Env::args& a, int v, hipStream_t st) {
+  if constexpr (Env::HAS_REGS) {
+    const dim3 g((unsigned)((a.ctl.n_lanes + 2 * BSX_BLOCK - 1) / (2 * BSX_BLOCK))), b(BSX_BLOCK);
+    if (v == 1) small_obs_eager2_kernel<Env, small_obs_v1<Env>()><<<g, b, 0, st>>>(a);
+    else small_obs_eager2_kernel<Env, 0><<<g, b, 0, st>>>(a);
+  }
+}
+
 template <class Env>
 static int launch_small_obs(const typename Env::args& a, int n_steps, void* hip_stream) {
   hipStream_t st = (hipStream_t)hip_stream;
@@ -687,9 +743,13 @@ static int launch_small_obs(const typename Env::args& a, int n_steps, void* hip_
   const bool lean = bsx_ctl_lean(a.ctl);
   // the register-resident families' lean rollouts are compiled per variant (row length, swing-up): -1 = none
   // (and address every [B, numel] slab with 32-bit byte offsets: a slab of 4 GiB or more takes the generic loop)
-  int regs_v = -1;
+  int regs_v = -1, Env_variant = 0;
+  bool eager2 = false;
   if constexpr (Env::HAS_REGS) {
-    if (a.ctl.n_lanes * (int64_t)a.obs_numel * 4 < ((int64_t)1 << 32)) regs_v = Env::variant_of(a);
+    Env_variant = Env::variant_of(a);
+    if (a.ctl.n_lanes * (int64_t)a.obs_numel * 4 < ((int64_t)1 << 32)) regs_v = Env_variant;
+    static const int eager2_min_blocks = bsx_env_int("BSX_EAGER2_MIN_BLOCKS", BSX_EAGER2_MIN_BLOCKS_DEFAULT);
+    eager2 = eager2_min_blocks > 0 && (a.ctl.n_lanes + BSX_BLOCK - 1) / BSX_BLOCK >= eager2_min_blocks;
   }
   const int64_t blocks = (a.ctl.n_lanes + BSX_BLOCK - 1) / BSX_BLOCK;
   if (blocks > 0x7FFFFFFF) return BSX_EINVAL;
@@ -705,7 +765,8 @@ static int launch_small_obs(const typename Env::args& a, int n_steps, void* hip_
   // faster.
 #define SMALL_OBS_LAUNCH(D)                                                                                \
   {                                                                                                        \
-    if (n_steps == 1 && lean) small_obs_kernel<Env, false, 0, 0, 0, D><<<g, b, lds, st>>>(a, 1);           \
+    if (n_steps == 1 && lean && eager2) launch_eager2<Env>(a, Env_variant, st);                            \
+    else if (n_steps == 1 && lean) small_obs_kernel<Env, false, 0, 0, 0, D><<<g, b, lds, st>>>(a, 1);      \
     else if (n_steps == 1) small_obs_kernel<Env, false, -1, -1, -1, D><<<g, b, lds, st>>>(a, 1);           \
     else if (logging && noise) small_obs_kernel<Env, true, 1, 1, -1, D><<<g, b, lds, st>>>(a, n_steps);    \
     else if (logging) small_obs_kernel<Env, true, 1, 0, -1, D><<<g, b, lds, st>>>(a, n_steps);             \

@@ -71,6 +71,30 @@ class DeepSea(base.Environment):
   _supports_delta = True
   _pipelined_rollout = True
 
+  # Bit 18 of the packed state word = the parity of the call index that reads it next (csrc/deep_sea_fam.h: every
+  # advance writes it).  This class keeps that true for words that arrive from elsewhere (load_state_dict), which is
+  # what BSX_CALL_STATE_TAGGED promises the library: a deterministic, un-wrapped step() is then ONE launch
+  # (deep_sea_step1_kernel) instead of lane advance + observation stream.
+  _TAG = 1 << 18
+
+  def _ensure_allocated(self):
+    fresh = not self._allocated
+    super()._ensure_allocated()
+    if fresh:
+      self._call_desc.flags = _native.CALL_STATE_TAGGED
+
+  def state_dict(self):
+    d = super().state_dict()
+    d['state'] &= ~self._TAG                 # (a dict is not tied to a call index)
+    return d
+
+  def load_state_dict(self, d):
+    super().load_state_dict(d)
+    st = self._state['state']
+    st &= ~self._TAG
+    if self._step_index & 1:
+      st |= self._TAG
+
   def _native_args(self, call, action_ptr, out):
     return (ctypes.byref(self._cfg), ctypes.byref(call), action_ptr, self._state['state'].data_ptr(), out, self._info.data_ptr())
 

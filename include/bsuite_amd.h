@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define BSX_ABI_VERSION 10
+#define BSX_ABI_VERSION 11
 
 #define BSX_FIRST 0
 #define BSX_MID 1
@@ -186,8 +186,18 @@ typedef struct {
                                arguments are static: the segments of a group (every group step then feeds
                                fresh actions with no host work) and captured hipGraphs.  Not a power of two:
                                BSX_EINVAL; with n_steps > 1 or obs_paint: BSX_EMODE.                 */
-  int32_t _pad2;
+  int32_t flags;            /* BSX_CALL_* bits (ABI v11; was padding, 0 = the v10 behaviour)                  */
 } bsx_call_t;
+
+/* bsx_call_t.flags */
+#define BSX_CALL_STATE_TAGGED 1 /* deep_sea: the caller guarantees that bit 18 of EVERY lane's packed state word equals
+                                  the parity of this call's index (stream.step_index + *step_base) — true for a
+                                  column that starts as (1<<17) | (index & 1) << 18 and is only ever advanced by
+                                  this library with consecutive call indices (every advance writes the next
+                                  parity).  A deterministic, un-wrapped single step()/reset() call is then ONE
+                                  launch instead of two: the threads of the observation store stream recompute the
+                                  transition of the lane whose row they write (deep_sea.hip).  Without the flag:
+                                  lane advance + store stream, as in v10.                                      */
 
 /* A catch segment of a BSX_FAM_SWEEP_MIXED group whose board has at most this many cells and that was set WITHOUT
  * state_alt has its boards written by phase 0 itself (one fused tile per workgroup) and takes no part in the phase-1
@@ -205,7 +215,8 @@ typedef struct {
   uint32_t mapping_bits[BSX_DEEP_SEA_MAX_SIZE * BSX_DEEP_SEA_MAX_SIZE / 32];
                                 /* action_mapping[row,col] bit (row*N+col), host-built (:77-85)   */
 } bsx_deep_sea_t;
-/* state: int32 [B] = row | col<<8 | bad_episode<<16 | reset_next<<17  (initialise to 1<<17)
+/* state: int32 [B] = row | col<<8 | bad_episode<<16 | reset_next<<17 | parity_of_next_call<<18  (initialise to 1<<17;
+ * bit 18 is maintained by the library, see BSX_CALL_STATE_TAGGED)
  * info : double [2,B] = total_bad_episodes, denoised_return (deep_sea.py:153-155)
  * obs  : float [B, N, N] */
 int bsx_deep_sea_step(const bsx_deep_sea_t* cfg /*host*/, const bsx_call_t* call /*host*/,

@@ -67,7 +67,7 @@ int main(void) {
 def test_argument_errors_without_touching_the_gpu():
   from bsuite_amd import _native
   lib = _native.lib
-  assert lib.bsx_abi_version() == 10
+  assert lib.bsx_abi_version() == 11
   assert lib.bsx_strerror(0) == b'ok'
   cfg = _native.DeepSeaCfg(size=10, deterministic=1, move_cost=0.001, inv_size=0.1)
   call = _native.Call(n_lanes=4)
