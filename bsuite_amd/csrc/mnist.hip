@@ -27,20 +27,20 @@ __global__ void __launch_bounds__(BSX_BLOCK) mnist_advance_group_kernel(const mn
 
 template <int K, int VAR>
 __global__ void __launch_bounds__(BSX_BLOCK) mnist_observe_kernel(const mnist_observe_args a) {
-  __shared__ float s_lut[256];
+  __shared__ float s_lut[MNIST_LUT_FLOATS];
   mnist_observe_body<K, VAR>(a, blockIdx.x, s_lut);
 }
 
 template <int K, int VAR>
 __global__ void __launch_bounds__(BSX_BLOCK) mnist_observe_group_kernel(const mnist_observe_args* __restrict__ table,
                                                                         const bsx_group_index gi) {
-  __shared__ float s_lut[256];
+  __shared__ float s_lut[MNIST_LUT_FLOATS];
   const bsx_group_slot w = bsx_group_find(gi, (int)blockIdx.x);
   mnist_observe_body<K, VAR>(table[w.seg], w.block, s_lut);
 }
 
 static int mnist_variant() {
-  static const int v = bsx_env_int("BSX_MNIST_VARIANT", 3) & 3;
+  static const int v = bsx_env_int("BSX_MNIST_VARIANT", 3) & 7;
   return v;
 }
 static int mnist_group_k() {
@@ -98,6 +98,7 @@ extern "C" int bsx_mnist_step(const bsx_mnist_t* cfg, const bsx_call_t* call, co
       case 1: mnist_observe_kernel<MNIST_K, 1><<<go, bo, 0, st>>>(o); break;
       case 2: mnist_observe_kernel<MNIST_K, 2><<<go, bo, 0, st>>>(o); break;
       case 3: mnist_observe_kernel<MNIST_K, 3><<<go, bo, 0, st>>>(o); break;
+      case 7: mnist_observe_kernel<MNIST_K, 7><<<go, bo, 0, st>>>(o); break;
       default: mnist_observe_kernel<MNIST_K, 0><<<go, bo, 0, st>>>(o); break;
     }
   }

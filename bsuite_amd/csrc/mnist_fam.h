@@ -69,10 +69,16 @@ struct mnist_observe_args {
 // (num_pixels % 4 == 0, so a 16-byte chunk never straddles two lanes).  VAR (A/B knob
 // BSX_MNIST_VARIANT): bit 0 = issue the state loads + image gathers BEFORE the LUT fill and its
 // barrier; bit 1 = each wave owns K consecutive KiB (the deep_sea stream order) instead of the
-// block-interleaved order.
+// block-interleaved order; bit 2 = no workgroup barrier at all: every WAVE keeps its own copy of the LUT
+// (s_lut: MNIST_LUT_FLOATS floats) and fills it only when one of its chunks shows an image — on the calls after the
+// guess, when every lane's observation is zeros (mnist.py:73), a workgroup's stores wait for nothing but the state
+// loads (r03: the mnist half of the sweep's stream ran at 5.0-5.2 TB/s even then, WAIT_ANY 68 % of the wave cycles:
+// the LUT load + barrier in front of every workgroup's stores, profiles/r03/stream_mnist_pmc_sq.json).
+#define MNIST_LUT_FLOATS (256 * (BSX_BLOCK / BSX_WAVE))
 template <int K, int VAR>
 __device__ __forceinline__ void mnist_observe_body(const mnist_observe_args& a, uint32_t block_id, float* s_lut) {
-  if (!(VAR & 1)) {
+  if (VAR & 4) s_lut += (threadIdx.x >> 6) * 256;          // this wave's copy
+  if (!(VAR & 1) && !(VAR & 4)) {
     s_lut[threadIdx.x] = a.lut[threadIdx.x];
     __syncthreads();
   }
@@ -102,7 +108,18 @@ __device__ __forceinline__ void mnist_observe_body(const mnist_observe_args& a, 
         px[u] = *reinterpret_cast<const uint32_t*>(a.images + (uint64_t)(s & 0x00FFFFFF) * cells + r0);
     }
   }
-  if (VAR & 1) {
+  if (VAR & 4) {
+    bool any_show = false;
+#pragma unroll
+    for (int u = 0; u < K; ++u) any_show |= show[u];
+    if (__ballot(any_show) != 0ull) {                          // wave-uniform
+#pragma unroll
+      for (int k = 0; k < 4; ++k) s_lut[wl + 64u * k] = a.lut[wl + 64u * k];
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+  } else if (VAR & 1) {
     s_lut[threadIdx.x] = a.lut[threadIdx.x];
     __syncthreads();
   }

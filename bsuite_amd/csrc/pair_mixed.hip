@@ -43,7 +43,7 @@ __global__ void __launch_bounds__(BSX_BLOCK) pair_mixed_advance_kernel(const uin
 __global__ void __launch_bounds__(BSX_BLOCK) pair_mixed_stream_kernel(const uint8_t* __restrict__ table,
                                                                       const int32_t* __restrict__ family,
                                                                       const bsx_group_index gi) {
-  __shared__ float s_lut[256];
+  __shared__ float s_lut[MNIST_LUT_FLOATS];
   pair_mixed_stream_body(table, family, gi, blockIdx.x, s_lut);
 }
 

@@ -143,7 +143,7 @@ __global__ void __launch_bounds__(BSX_BLOCK) __attribute__((amdgpu_waves_per_eu(
   __shared__ unsigned int s_cnt[2];
   __shared__ deep_sea_fam::shared s_ds;
   __shared__ catch_fam::shared s_ca;
-  __shared__ float s_lut[256];
+  __shared__ float s_lut[MNIST_LUT_FLOATS];
   __shared__ int32_t s_tile_state[BSX_BLOCK];
   const bsx_pipe_role r = bsx_pipe_role_of(blockIdx.x, gridDim.x, adv_blocks, place);   // uniform per workgroup
   if (r.adv) sweep_phase0_body(adv_table, adv_tags, adv_gi, counter, ticket, r.index, adv_blocks, s_obs, s_cnt, s_ds, s_ca, s_tile_state);
