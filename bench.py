@@ -46,6 +46,7 @@ WORKLOADS = {
     'catch_noise': ('catch_noise/0', 'catch', dict(), 50, 8, 10),     # RewardNoise(0.1): the non-lean kernel instantiations
     'cartpole': ('cartpole/0', 'cartpole', dict(), 6, 48, 128),
     'mountain_car': ('mountain_car/0', 'mountain_car', dict(), 3, 24, 1001),
+    'cartpole_noise': ('cartpole_noise/0', 'cartpole', dict(), 6, 48, 128),   # RewardNoise(0.1): the wrapped rollout kernels
     'bandit': ('bandit/0', 'bandit', dict(mapping_seed=0), 1, 8, 2),
     'memory_len': ('memory_len/10', 'memory_chain', dict(memory_length=12, num_bits=1), 3, 24, 14),
     'umbrella_length': ('umbrella_length/10', 'umbrella_chain', dict(chain_length=12, n_distractor=20), 23, 8, 13),

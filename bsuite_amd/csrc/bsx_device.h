@@ -92,7 +92,9 @@ __device__ __forceinline__ void bsx_draws_end(const bsx_draws* d, const bsx_ctl&
 // lanes only, evaluated in f64 like the reference, result cast to f32 once.
 // NOISE = 0 compiles the RewardNoise branch out: its ~100 f64 polynomial constants are otherwise
 // hoisted into VGPRs ahead of the T-step rollout loop and cost two thirds of the occupancy.
-template <int NOISE = -1>
+// MT = 0: the call draws from the counter-based stream (bsx_make_ctl sets wrap_mt_state only in MT19937-exact mode): the
+// wrapper's own generator — twist, legacy gauss, libm log — is compiled out.
+template <int NOISE = -1, int MT = -1>
 __device__ __forceinline__ double bsx_wrap_reward(const bsx_ctl& c, int64_t i, uint64_t lane, uint64_t step,
                                                   double reward) {
   BSX_NO_CONTRACT
@@ -106,7 +108,7 @@ __device__ __forceinline__ double bsx_wrap_reward(const bsx_ctl& c, int64_t i, u
     bsx_draws w;
     bsx_draws_init(&w, c.wrap_seed, lane, step, BSX_STREAM_WRAP);
     double z;
-    if (c.wrap_mt_state != nullptr) {       // MT19937-exact mode: the wrapper's own RandomState (wrappers.py:267)
+    if (MT != 0 && c.wrap_mt_state != nullptr) {       // MT19937-exact mode: the wrapper's own RandomState (wrappers.py:267)
       w.mt = c.wrap_mt_state + i;
       w.mt_stride = c.n_lanes;
       w.mt_pos = c.wrap_mt_pos[i];
@@ -171,13 +173,13 @@ __device__ __forceinline__ void bsx_track(const bsx_ctl& c, int64_t i, int type,
 // LOG: -1 decide at run time (c.log.steps != nullptr), 0 logging compiled out, 1 always track.
 // `oi` is the output element (== i for step(); t*B + i inside a fused rollout).
 // F64 = false: the lean instantiations (bsx_ctl_lean: reward_f64 == nullptr) compile the f64 reward copy out.
-template <int LOG = -1, int NOISE = -1, bool F64 = true>
+template <int LOG = -1, int NOISE = -1, bool F64 = true, int MT = -1>
 __device__ __forceinline__ void bsx_emit_values(const bsx_ctl& c, int64_t i, int64_t oi, uint64_t lane, uint64_t step,
                                                 int type, double reward, float& r, float& d) {
   r = 0.0f; d = 1.0f;         // FIRST: dm_env.restart has reward/discount None -> 0 / 1 in a batch
   double wrapped = 0.0;
   if (type != BSX_FIRST) {
-    wrapped = bsx_wrap_reward<NOISE>(c, i, lane, step, reward);
+    wrapped = bsx_wrap_reward<NOISE, MT>(c, i, lane, step, reward);
     r = (float)wrapped;
     d = (type == BSX_LAST) ? 0.0f : 1.0f;
   }
@@ -187,11 +189,11 @@ __device__ __forceinline__ void bsx_emit_values(const bsx_ctl& c, int64_t i, int
 
 // Writes the scalar TimeStep fields of one lane (coalesced: lane i -> element oi of each column;
 // oi == i for step(), oi == t*B + i inside a fused T-step rollout).
-template <int LOG = -1, int NOISE = -1, bool F64 = true>
+template <int LOG = -1, int NOISE = -1, bool F64 = true, int MT = -1>
 __device__ __forceinline__ void bsx_emit_at(const bsx_ctl& c, const bsx_timestep_t& out, int64_t i, int64_t oi,
                                             uint64_t lane, uint64_t step, int type, double reward) {
   float r, d;
-  bsx_emit_values<LOG, NOISE, F64>(c, i, oi, lane, step, type, reward, r, d);
+  bsx_emit_values<LOG, NOISE, F64, MT>(c, i, oi, lane, step, type, reward, r, d);
   out.reward[oi] = r;
   out.discount[oi] = d;
   out.step_type[oi] = (int8_t)type;

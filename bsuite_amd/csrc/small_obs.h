@@ -344,12 +344,12 @@ __device__ __forceinline__ void small_obs_regs_rollout(const typename Env::args&
         if (scalars) {
           if constexpr (OFF32) {
             float r, d;
-            bsx_emit_values<LOG, NOISE, F64>(a.ctl, i, oi, lane, step0 + (uint64_t)t, type, reward, r, d);
+            bsx_emit_values<LOG, NOISE, F64, MT>(a.ctl, i, oi, lane, step0 + (uint64_t)t, type, reward, r, d);
             *bsx_at_off(rp, iu * 4u) = r;
             *bsx_at_off(dp, iu * 4u) = d;
             *bsx_at_off(sp, iu) = (int8_t)type;
           } else {
-            bsx_emit_at<LOG, NOISE, F64>(a.ctl, a.out, i, oi, lane, step0 + (uint64_t)t, type, reward);
+            bsx_emit_at<LOG, NOISE, F64, MT>(a.ctl, a.out, i, oi, lane, step0 + (uint64_t)t, type, reward);
           }
         }
         if (rows) {
@@ -439,7 +439,7 @@ __device__ __forceinline__ void small_obs_body(const typename Env::args& a, cons
         double reward = 0.0;
         float o[8];
         type = Env::template step<LOG, MT>(a, i, oi, lane, step0 + (uint64_t)t, o, reward);
-        bsx_emit_at<LOG, NOISE, F64>(a.ctl, a.out, i, oi, lane, step0 + (uint64_t)t, type, reward);
+        bsx_emit_at<LOG, NOISE, F64, MT>(a.ctl, a.out, i, oi, lane, step0 + (uint64_t)t, type, reward);
         // (row-per-lane stores also in a big launch: staging the rows like the fused rollout does left the eager step
         // where it was — 17.5 / 17.5 vs 18.0 / 17.4 us at 2^20 lanes — and cost 4 % at 2^18,
         // profiles/r03/ab_eager_rows_via_lds.log: one memory round trip per launch bounds it, not the write requests;
@@ -468,7 +468,7 @@ __device__ __forceinline__ void small_obs_body(const typename Env::args& a, cons
         float head[HEAD];
         const bsx_bit_sink sink{planes, stride, (uint32_t)((int)threadIdx.x * numel + HEAD)};
         type = Env::template step<LOG, MT, true>(a, i, oi, lane, step0 + (uint64_t)t, head, reward, &sink);
-        bsx_emit_at<LOG, NOISE, F64>(a.ctl, a.out, i, oi, lane, step0 + (uint64_t)t, type, reward);
+        bsx_emit_at<LOG, NOISE, F64, MT>(a.ctl, a.out, i, oi, lane, step0 + (uint64_t)t, type, reward);
 #pragma unroll
         for (int k = 0; k < HEAD; ++k) s_head[threadIdx.x * HEAD + k] = head[k];
         if (t == 0) {
@@ -740,6 +740,9 @@ static int launch_small_obs(const typename Env::args& a, int n_steps, void* hip_
   hipStream_t st = (hipStream_t)hip_stream;
   if (n_steps < 1) return BSX_EINVAL;
   const bool logging = a.ctl.log.steps != nullptr, noise = a.ctl.wrap_kind >= BSX_WRAP_NOISE;
+  // (the wrapped rollouts are compiled with and without the MT19937-exact draws: the common wrapped run draws from the
+  // counter-based stream, and the generator's twist + numpy's legacy samplers cost the loop 50-70 VGPRs)
+  const bool mt = a.ctl.mt_state != nullptr;
   const bool lean = bsx_ctl_lean(a.ctl);
   // the register-resident families' lean rollouts are compiled per variant (row length, swing-up): -1 = none
   // (and address every [B, numel] slab with 32-bit byte offsets: a slab of 4 GiB or more takes the generic loop)
@@ -768,6 +771,9 @@ static int launch_small_obs(const typename Env::args& a, int n_steps, void* hip_
     if (n_steps == 1 && lean && eager2) launch_eager2<Env>(a, Env_variant, st);                            \
     else if (n_steps == 1 && lean) small_obs_kernel<Env, false, 0, 0, 0, D><<<g, b, lds, st>>>(a, 1);      \
     else if (n_steps == 1) small_obs_kernel<Env, false, -1, -1, -1, D><<<g, b, lds, st>>>(a, 1);           \
+    else if (logging && noise && !mt) small_obs_kernel<Env, true, 1, 1, 0, D><<<g, b, lds, st>>>(a, n_steps); \
+    else if (logging && !mt) small_obs_kernel<Env, true, 1, 0, 0, D><<<g, b, lds, st>>>(a, n_steps);       \
+    else if (noise && !mt) small_obs_kernel<Env, true, 0, 1, 0, D><<<g, b, lds, st>>>(a, n_steps);         \
     else if (logging && noise) small_obs_kernel<Env, true, 1, 1, -1, D><<<g, b, lds, st>>>(a, n_steps);    \
     else if (logging) small_obs_kernel<Env, true, 1, 0, -1, D><<<g, b, lds, st>>>(a, n_steps);             \
     else if (noise) small_obs_kernel<Env, true, 0, 1, -1, D><<<g, b, lds, st>>>(a, n_steps);               \

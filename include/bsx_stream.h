@@ -181,6 +181,18 @@ BSX_HD uint64_t bsx_f64_to_bits(double d) { union { uint64_t u; double d; } x; x
 #define BSX_NO_CONTRACT
 #endif
 
+/* A floating-point constant of the polynomials below, materialised where it is used (device: an SGPR pair set by
+ * s_mov_b64 behind an opaque asm; host: the literal).  Left to itself the compiler hoists all ~60 of them out of the
+ * step loop of a fused rollout into VGPR pairs — 120 vector registers, i.e. 2 waves per SIMD for every kernel that can
+ * draw a RewardNoise normal (157-218 VGPRs in the NOISE = 1 rollout instantiations).  Same values, same
+ * operations: no numerical effect. */
+#if defined(__HIP_DEVICE_COMPILE__)
+static __device__ __forceinline__ double bsx_k_(double c) { asm volatile("" : "+s"(c)); return c; }
+#define BSX_K(c) bsx_k_(c)
+#else
+#define BSX_K(c) (c)
+#endif
+
 BSX_HD double bsx_log(double x) {
   BSX_NO_CONTRACT
   uint64_t u = bsx_f64_to_bits(x);
@@ -189,18 +201,18 @@ BSX_HD double bsx_log(double x) {
   if (m > 1.4142135623730951) { m = m * 0.5; e += 1; }                             /* [~.707,1.414] */
   double s = (m - 1.0) / (m + 1.0);
   double s2 = s * s;
-  double p = 1.0 / 25.0;
-  p = p * s2 + 1.0 / 23.0;
-  p = p * s2 + 1.0 / 21.0;
-  p = p * s2 + 1.0 / 19.0;
-  p = p * s2 + 1.0 / 17.0;
-  p = p * s2 + 1.0 / 15.0;
-  p = p * s2 + 1.0 / 13.0;
-  p = p * s2 + 1.0 / 11.0;
-  p = p * s2 + 1.0 / 9.0;
-  p = p * s2 + 1.0 / 7.0;
-  p = p * s2 + 1.0 / 5.0;
-  p = p * s2 + 1.0 / 3.0;
+  double p = BSX_K(1.0 / 25.0);
+  p = p * s2 + BSX_K(1.0 / 23.0);
+  p = p * s2 + BSX_K(1.0 / 21.0);
+  p = p * s2 + BSX_K(1.0 / 19.0);
+  p = p * s2 + BSX_K(1.0 / 17.0);
+  p = p * s2 + BSX_K(1.0 / 15.0);
+  p = p * s2 + BSX_K(1.0 / 13.0);
+  p = p * s2 + BSX_K(1.0 / 11.0);
+  p = p * s2 + BSX_K(1.0 / 9.0);
+  p = p * s2 + BSX_K(1.0 / 7.0);
+  p = p * s2 + BSX_K(1.0 / 5.0);
+  p = p * s2 + BSX_K(1.0 / 3.0);
   p = p * s2 + 1.0;
   double lm = 2.0 * s * p;
   return (double)e * 0.6931471805599453 + lm;
@@ -222,21 +234,21 @@ BSX_HD double bsx_normal_from_k53(uint64_t k) {
   double val;
   if (aq <= 0.425) {
     double r = 0.180625 - q * q;
-    double num = 2.5090809287301226727e+3;
-    num = num * r + 3.3430575583588128105e+4;
-    num = num * r + 6.7265770927008700853e+4;
-    num = num * r + 4.5921953931549871457e+4;
-    num = num * r + 1.3731693765509461125e+4;
-    num = num * r + 1.9715909503065514427e+3;
-    num = num * r + 1.3314166789178437745e+2;
-    num = num * r + 3.3871328727963666080e+0;
-    double den = 5.2264952788528545610e+3;
-    den = den * r + 2.8729085735721942674e+4;
-    den = den * r + 3.9307895800092710610e+4;
-    den = den * r + 2.1213794301586595867e+4;
-    den = den * r + 5.3941960214247511077e+3;
-    den = den * r + 6.8718700749205790830e+2;
-    den = den * r + 4.2313330701600911252e+1;
+    double num = BSX_K(2.5090809287301226727e+3);
+    num = num * r + BSX_K(3.3430575583588128105e+4);
+    num = num * r + BSX_K(6.7265770927008700853e+4);
+    num = num * r + BSX_K(4.5921953931549871457e+4);
+    num = num * r + BSX_K(1.3731693765509461125e+4);
+    num = num * r + BSX_K(1.9715909503065514427e+3);
+    num = num * r + BSX_K(1.3314166789178437745e+2);
+    num = num * r + BSX_K(3.3871328727963666080e+0);
+    double den = BSX_K(5.2264952788528545610e+3);
+    den = den * r + BSX_K(2.8729085735721942674e+4);
+    den = den * r + BSX_K(3.9307895800092710610e+4);
+    den = den * r + BSX_K(2.1213794301586595867e+4);
+    den = den * r + BSX_K(5.3941960214247511077e+3);
+    den = den * r + BSX_K(6.8718700749205790830e+2);
+    den = den * r + BSX_K(4.2313330701600911252e+1);
     den = den * r + 1.0;
     return q * num / den;
   }
@@ -244,40 +256,40 @@ BSX_HD double bsx_normal_from_k53(uint64_t k) {
   r = BSX_SQRT(-bsx_log(r));
   if (r <= 5.0) {
     r = r - 1.6;
-    double num = 7.74545014278341407640e-4;
-    num = num * r + 2.27238449892691845833e-2;
-    num = num * r + 2.41780725177450611770e-1;
-    num = num * r + 1.27045825245236838258e+0;
-    num = num * r + 3.64784832476320460504e+0;
-    num = num * r + 5.76949722146069140550e+0;
-    num = num * r + 4.63033784615654529590e+0;
-    num = num * r + 1.42343711074968357734e+0;
-    double den = 1.05075007164441684324e-9;
-    den = den * r + 5.47593808499534494600e-4;
-    den = den * r + 1.51986665636164571966e-2;
-    den = den * r + 1.48103976427480074590e-1;
-    den = den * r + 6.89767334985100004550e-1;
-    den = den * r + 1.67638483018380384940e+0;
-    den = den * r + 2.05319162663775882187e+0;
+    double num = BSX_K(7.74545014278341407640e-4);
+    num = num * r + BSX_K(2.27238449892691845833e-2);
+    num = num * r + BSX_K(2.41780725177450611770e-1);
+    num = num * r + BSX_K(1.27045825245236838258e+0);
+    num = num * r + BSX_K(3.64784832476320460504e+0);
+    num = num * r + BSX_K(5.76949722146069140550e+0);
+    num = num * r + BSX_K(4.63033784615654529590e+0);
+    num = num * r + BSX_K(1.42343711074968357734e+0);
+    double den = BSX_K(1.05075007164441684324e-9);
+    den = den * r + BSX_K(5.47593808499534494600e-4);
+    den = den * r + BSX_K(1.51986665636164571966e-2);
+    den = den * r + BSX_K(1.48103976427480074590e-1);
+    den = den * r + BSX_K(6.89767334985100004550e-1);
+    den = den * r + BSX_K(1.67638483018380384940e+0);
+    den = den * r + BSX_K(2.05319162663775882187e+0);
     den = den * r + 1.0;
     val = num / den;
   } else {
     r = r - 5.0;
-    double num = 2.01033439929228813265e-7;
-    num = num * r + 2.71155556874348757815e-5;
-    num = num * r + 1.24266094738807843860e-3;
-    num = num * r + 2.65321895265761230930e-2;
-    num = num * r + 2.96560571828504891230e-1;
-    num = num * r + 1.78482653991729133580e+0;
-    num = num * r + 5.46378491116411436990e+0;
-    num = num * r + 6.65790464350110377720e+0;
-    double den = 2.04426310338993978564e-15;
-    den = den * r + 1.42151175831644588870e-7;
-    den = den * r + 1.84631831751005468180e-5;
-    den = den * r + 7.86869131145613259100e-4;
-    den = den * r + 1.48753612908506148525e-2;
-    den = den * r + 1.36929880922735805310e-1;
-    den = den * r + 5.99832206555887937690e-1;
+    double num = BSX_K(2.01033439929228813265e-7);
+    num = num * r + BSX_K(2.71155556874348757815e-5);
+    num = num * r + BSX_K(1.24266094738807843860e-3);
+    num = num * r + BSX_K(2.65321895265761230930e-2);
+    num = num * r + BSX_K(2.96560571828504891230e-1);
+    num = num * r + BSX_K(1.78482653991729133580e+0);
+    num = num * r + BSX_K(5.46378491116411436990e+0);
+    num = num * r + BSX_K(6.65790464350110377720e+0);
+    double den = BSX_K(2.04426310338993978564e-15);
+    den = den * r + BSX_K(1.42151175831644588870e-7);
+    den = den * r + BSX_K(1.84631831751005468180e-5);
+    den = den * r + BSX_K(7.86869131145613259100e-4);
+    den = den * r + BSX_K(1.48753612908506148525e-2);
+    den = den * r + BSX_K(1.36929880922735805310e-1);
+    den = den * r + BSX_K(5.99832206555887937690e-1);
     den = den * r + 1.0;
     val = num / den;
   }

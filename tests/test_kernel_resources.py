@@ -3,6 +3,7 @@
 throughput-bound through their occupancy — a change that pushes one of them over a VGPR step (64 -> 7 waves per SIMD,
 72 -> 6 at 80, ...) or into scratch shows up here before it shows up as a slower bench line."""
 import os
+import re
 import shutil
 import sys
 
@@ -86,6 +87,21 @@ def test_lean_rollout_step_loops_reload_no_spilled_scalars():
     name, text = ki.kernel_text(src, want)
     assert sum('v_' in l for l in text) > 300, name
     assert ki.loop_spill_reloads(text, min_depth=2) <= most, (name, ki.loop_spill_reloads(text, min_depth=2))
+
+
+def test_wrapped_rollouts_keep_four_waves_per_simd(kernels):
+  """the fused rollouts a Logging- or RewardNoise-wrapped environment runs (every *_noise id, every
+  recorded run) were 157-218 VGPRs = 2 waves per SIMD: the ~60 f64 constants of the normal transform hoisted out of the
+  step loop into VGPR pairs, and the MT19937-exact generator compiled into every one of them.  The constants are now
+  materialised on the scalar unit where they are used (BSX_K, include/bsx_stream.h) and the counter-based runs have
+  instantiations of their own (MT = 0): at most 128 VGPRs, no scratch."""
+  wrapped = {n: k for n, k in kernels.items()
+             if n.startswith('small_obs_kernel<') and re.search(r', true, (1, 0|0, 1|1, 1), 0, (true|false)>$', n)}
+  assert len(wrapped) >= 15, sorted(wrapped)
+  for n, k in wrapped.items():
+    assert k['vgpr_count'] <= 128 and k['private_segment_fixed_size'] == 0, (n, k['vgpr_count'], k['private_segment_fixed_size'])
+  for n in ('bsx_fused_rollout_kernel<catch_fam, false, catch_hot>', 'bsx_fused_rollout_kernel<deep_sea_fam, false, deep_sea_hot>'):
+    assert kernels[n]['vgpr_count'] <= 128, (n, kernels[n]['vgpr_count'])
 
 
 def test_lean_instantiations_keep_full_occupancy(kernels):
