@@ -273,6 +273,14 @@ __device__ __forceinline__ bsx_group_slot bsx_group_find(const bsx_group_index& 
   return r;
 }
 
+// Fam::advance<LEAN> — with the family's MT19937-exact draws compiled out as well when NOMT (deep_sea's extra template
+// parameter sits between the two).
+template <class Fam, bool LEAN, bool NOMT>
+__device__ __forceinline__ int bsx_fam_advance(const typename Fam::args& a, const typename Fam::shared& s, int64_t i, uint64_t lane,
+                                               uint64_t step, int32_t st, int act, int32_t& nst, double& reward) {
+  return Fam::template advance_nomt<LEAN, NOMT>(a, s, i, lane, step, st, act, nst, reward);
+}
+
 // Advance kernel of the two-kernel families (deep_sea, catch): one lane per thread, coalesced
 // column loads/stores.  At B=2^20 it moves only 22 MB and sits at the ~8 us launch/latency floor of
 // any 2^20-lane kernel; a 4-lanes-per-thread variant with 16-byte column accesses measured the
@@ -284,7 +292,9 @@ __device__ __forceinline__ bsx_group_slot bsx_group_find(const bsx_group_index& 
 //   static int advance(args, shared, i, lane, step, st, act, nst&, reward&)
 // LEAN: no Logging wrapper, no RewardNoise, counter-based draws — those branches are compiled out (the
 // launcher picks it when the call has none of them).
-template <class Fam, bool LEAN = false>
+// MT = 0 (with LEAN = false): a wrapped call on the counter-based stream — the MT19937-exact generators of the
+// environment and of RewardNoise are compiled out (the whole-sweep group, which holds no MT19937-exact segment).
+template <class Fam, bool LEAN = false, int MT = -1>
 __device__ __forceinline__ void bsx_advance_body(const typename Fam::args& a, uint32_t block_id,
                                                  typename Fam::shared& s_fam, unsigned int* s_cnt,
                                                  int32_t* s_state = nullptr) {
@@ -299,11 +309,11 @@ __device__ __forceinline__ void bsx_advance_body(const typename Fam::args& a, ui
     int32_t nst; double reward;
     const int act = a.ctl.force_reset ? 0 : bsx_action(a.ctl, a.action, i, step);
     const int32_t st = a.ctl.state_in != nullptr ? a.ctl.state_in[i] : a.state[i];
-    type = Fam::template advance<LEAN>(a, s_fam, i, lane, step, st, act, nst, reward);
+    type = bsx_fam_advance<Fam, LEAN, MT == 0>(a, s_fam, i, lane, step, st, act, nst, reward);
     a.state[i] = nst;
     if (s_state != nullptr) s_state[threadIdx.x] = nst;     // fused small-batch step: the tile streamer reads it from LDS
     if (LEAN) bsx_emit_at<0, 0, false>(a.ctl, a.out, i, i, lane, step, type, reward);
-    else bsx_emit(a.ctl, a.out, i, lane, step, type, reward);
+    else bsx_emit_at<-1, -1, true, MT>(a.ctl, a.out, i, i, lane, step, type, reward);
   }
   bsx_count_types(a.ctl, type, s_cnt);
   __syncthreads();

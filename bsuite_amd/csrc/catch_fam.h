@@ -32,8 +32,9 @@ struct catch_fam {
   struct shared { int unused; };
   __device__ static __forceinline__ void stage(const args&, shared&) {}
 
-  // LEAN: counter-based draws only (the MT19937-exact mode is compiled out)
-  template <bool LEAN = false>
+  // LEAN: counter-based draws only (the MT19937-exact mode is compiled out); NOMT: the same for a call that is not
+  // lean otherwise (Logging / RewardNoise on the counter-based stream)
+  template <bool LEAN = false, bool NOMT = false>
   __device__ static __forceinline__ int advance(const args& a, const shared&, int64_t i, uint64_t lane,
                                                 uint64_t step, int32_t st, int act, int32_t& nst,
                                                 double& reward) {
@@ -45,9 +46,9 @@ struct catch_fam {
     reward = 0.0;
     if (a.ctl.force_reset || (st & CATCH_RESET_BIT)) {         // catch.py:80-81 -> :68-76
       bsx_draws d;
-      bsx_draws_begin<LEAN ? 0 : -1>(&d, a.ctl, i, lane, step);
+      bsx_draws_begin<(LEAN || NOMT) ? 0 : -1>(&d, a.ctl, i, lane, step);
       ball_x = (int)bsx_randint(&d, (uint32_t)cols);            // :71
-      bsx_draws_end<LEAN ? 0 : -1>(&d, a.ctl, i);
+      bsx_draws_end<(LEAN || NOMT) ? 0 : -1>(&d, a.ctl, i);
       ball_y = 0;
       paddle_x = cols / 2;
       type = BSX_FIRST;
@@ -74,6 +75,11 @@ struct catch_fam {
     nst = (int32_t)((uint32_t)(ball_x | (ball_y << 8) | (paddle_x << 16) | (type == BSX_LAST ? CATCH_RESET_BIT : 0)) |
                     (pending << CATCH_PENDING_SHIFT));
     return type;
+  }
+  template <bool LEAN, bool NOMT>
+  __device__ static __forceinline__ int advance_nomt(const args& a, const shared& s, int64_t i, uint64_t lane, uint64_t step,
+                                                     int32_t st, int act, int32_t& nst, double& reward) {
+    return advance<LEAN, NOMT>(a, s, i, lane, step, st, act, nst, reward);
   }
 };
 

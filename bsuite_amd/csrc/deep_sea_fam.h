@@ -40,7 +40,8 @@ struct deep_sea_fam {
   // step that needs the lane's new state but is not the lane's writer)
   // DET = 1: the caller knows the environment is deterministic (and LEAN): no draw exists, the Philox block and the f64
   // normal transform are compiled out — what the per-thread recomputation of the single-launch step can afford.
-  template <bool LEAN = false, int DET = -1>
+  // NOMT: counter-based draws in a call that is not lean otherwise (see catch_fam.h)
+  template <bool LEAN = false, int DET = -1, bool NOMT = false>
   __device__ static __forceinline__ int advance(const args& a, const shared& s, int64_t i, uint64_t lane,
                                                 uint64_t step, int32_t st, int act, int32_t& nst,
                                                 double& reward, const bool commit = true) {
@@ -58,7 +59,7 @@ struct deep_sea_fam {
       const int mapped = (int)((s.map[cell >> 5] >> (cell & 31)) & 1u);
       const bool right = (act == mapped);                       // deep_sea.py:118
       bsx_draws d;
-      bsx_draws_begin<LEAN ? 0 : -1>(&d, a.ctl, i, lane, step);
+      bsx_draws_begin<(LEAN || NOMT) ? 0 : -1>(&d, a.ctl, i, lane, step);
       if (col == N - 1 && right) {                              // :121-123
         reward += 1.0;
         if (commit) a.info[a.ctl.n_lanes + i] += 1.0;
@@ -70,7 +71,7 @@ struct deep_sea_fam {
         // counter-based stream restarts at every call, so an unused draw leaves no trace and is
         // skipped; the lane's own MT19937 generator (exact mode) must advance, so there it is drawn.
         bool moves = true;
-        if (!deterministic || (!LEAN && a.ctl.mt_state != nullptr)) {
+        if (!deterministic || (!LEAN && !NOMT && a.ctl.mt_state != nullptr)) {
           const double u = bsx_uniform(&d);
           moves = (u > a.inv_size) || deterministic;
         }
@@ -80,7 +81,7 @@ struct deep_sea_fam {
         if (row == col) bad = 1;
         col = col - 1 < 0 ? 0 : col - 1;
       }
-      bsx_draws_end<LEAN ? 0 : -1>(&d, a.ctl, i);
+      bsx_draws_end<(LEAN || NOMT) ? 0 : -1>(&d, a.ctl, i);
       row += 1;                                                 // :137
       if (row == N) {                                           // :140-143
         if (bad && commit) a.info[i] += 1.0;
@@ -91,6 +92,11 @@ struct deep_sea_fam {
     }
     nst = row | (col << 8) | (bad << 16) | (type == BSX_LAST ? DS_RESET_BIT : 0) | (int32_t)(((uint32_t)(step + 1) & 1u) << DS_TAG_SHIFT);
     return type;
+  }
+  template <bool LEAN, bool NOMT>
+  __device__ static __forceinline__ int advance_nomt(const args& a, const shared& s, int64_t i, uint64_t lane, uint64_t step,
+                                                     int32_t st, int act, int32_t& nst, double& reward) {
+    return advance<LEAN, -1, NOMT>(a, s, i, lane, step, st, act, nst, reward);
   }
 };
 

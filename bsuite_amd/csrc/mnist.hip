@@ -133,7 +133,7 @@ extern "C" int bsx_group_set_mnist(bsx_group_t* g, int32_t index, const bsx_mnis
     a.ctl.state_in = call->state_alt;            // pipelined sweeps: the advance reads the other column
     return bsx_mixed_put(g, BSX_FAM_MNIST, index, call, &a, sizeof(a), &o, sizeof(o),
                               (uint64_t)(call->n_lanes + BSX_BLOCK - 1) / BSX_BLOCK,
-                              bsx_flat_blocks((uint64_t)call->n_lanes * o.cells, 8), 0);
+                              bsx_flat_blocks((uint64_t)call->n_lanes * o.cells, PAIR_MNIST_K), 0);
   }
   rc = bsx_group_check_set(g, BSX_FAM_MNIST, index, call, sizeof(mnist_args), sizeof(mnist_observe_args), 0);
   if (rc != 0) return rc;

@@ -21,6 +21,8 @@ struct mnist_args {
 #define MN_RESET_BIT (1 << 28)
 #define MN_SHOW_BIT (1 << 29)
 
+// MT = 0: no segment of the launch is in MT19937-exact mode (the whole-sweep group): those draws are compiled out
+template <int MT = -1>
 __device__ __forceinline__ void mnist_advance_body(const mnist_args& a, uint32_t block_id, unsigned int* s_cnt) {
   if (threadIdx.x < 2) s_cnt[threadIdx.x] = 0;
   __syncthreads();
@@ -34,9 +36,9 @@ __device__ __forceinline__ void mnist_advance_body(const mnist_args& a, uint32_t
     int32_t nst;
     if (a.ctl.force_reset || (st & MN_RESET_BIT)) {             // mnist.py:61-67
       bsx_draws d;
-      bsx_draws_begin(&d, a.ctl, i, lane, step);
+      bsx_draws_begin<MT>(&d, a.ctl, i, lane, step);
       const uint32_t idx = bsx_randint(&d, (uint32_t)a.num_data);
-      bsx_draws_end(&d, a.ctl, i);
+      bsx_draws_end<MT>(&d, a.ctl, i);
       nst = (int32_t)idx | ((int32_t)a.labels[idx] << 24) | MN_SHOW_BIT;
       type = BSX_FIRST;
     } else {                                                    // mnist.py:69-75
@@ -47,7 +49,7 @@ __device__ __forceinline__ void mnist_advance_body(const mnist_args& a, uint32_t
       type = BSX_LAST;
     }
     a.state[i] = nst;
-    bsx_emit(a.ctl, a.out, i, lane, step, type, reward);
+    bsx_emit_at<-1, -1, true, MT>(a.ctl, a.out, i, i, lane, step, type, reward);
   }
   bsx_count_types(a.ctl, type, s_cnt);
   __syncthreads();

@@ -30,7 +30,9 @@ int bsx_sweep_launch_pipelined(bsx_group* streams_of, bsx_group* advances_of, hi
 
 // One workgroup of the mixed observation store stream: `block` of the phase-1 grid runs its segment's
 // family stream body (deep_sea 4 x 4 KiB, catch 2 x 4 KiB, mnist 8 x 4 KiB runs per workgroup).
+#ifndef PAIR_MNIST_K
 #define PAIR_MNIST_K 8
+#endif
 __device__ __forceinline__ void pair_mixed_stream_body(const uint8_t* __restrict__ table, const int32_t* __restrict__ family,
                                                        const bsx_group_index& gi, uint32_t block, float* s_lut) {
   const bsx_group_slot w = bsx_group_find(gi, (int)block);

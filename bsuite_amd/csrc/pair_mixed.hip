@@ -80,6 +80,9 @@ int bsx_mixed_put(bsx_group* g, int32_t family, int32_t index, const bsx_call_t*
   int rc = bsx_group_check_set(g, g->family, index, call, PAIR_ADV_STRIDE, PAIR_STR_STRIDE, 0);
   if (rc != 0) return rc;
   if (blocks1 > 0x3FFFFFFFull || blocks2 > 0x3FFFFFFFull) return BSX_EINVAL;
+  // the whole-sweep launches are compiled without the MT19937-exact generators (a seeded small-batch mode: such
+  // segments go into per-family groups or step eagerly)
+  if (g->family == BSX_FAM_SWEEP_MIXED && call->stream.mt_state != nullptr) return BSX_EMODE;
   if (g->family == BSX_FAM_SWEEP_MIXED) {           // the group bumps ONE call counter: all segments must share it
     if (g->shared_counter == nullptr) g->shared_counter = const_cast<uint64_t*>(call->stream.step_base);
     else if (g->shared_counter != call->stream.step_base) return BSX_EINVAL;

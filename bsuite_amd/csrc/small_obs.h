@@ -618,22 +618,24 @@ static size_t small_obs_rollout_lds(const typename Env::args& a) {
 // MT19937 draws (uniform per workgroup) runs the lean instantiation, like a stand-alone call does: a cartpole
 // workgroup then issues a third fewer instructions, and the heavy workgroups are what a sweep's lane advance
 // waits for (profiles/r02/sweep_phase0_trace.json).
-template <class Env, bool D>
+// MT = 0: the group holds no segment in MT19937-exact mode (the whole-sweep group refuses them, bsx_mixed_put): the
+// wrapped segments' bodies are compiled without the generator's twist and numpy's legacy samplers.
+template <class Env, bool D, int MT = -1>
 __device__ __forceinline__ void small_obs_group_body_d(const typename Env::args& a, const uint32_t blk, float* s_obs,
                                                        unsigned int* s_cnt) {
   if (bsx_ctl_lean(a.ctl)) small_obs_body<Env, false, 0, 0, 0, D>(a, 1, blk, s_obs, s_cnt);
-  else small_obs_body<Env, false, -1, -1, -1, D>(a, 1, blk, s_obs, s_cnt);
+  else small_obs_body<Env, false, -1, -1, MT, D>(a, 1, blk, s_obs, s_cnt);
 }
-template <class Env>
+template <class Env, int MT = -1>
 __device__ __forceinline__ void small_obs_group_body(const typename Env::args& a, const uint32_t blk, float* s_obs,
                                                      unsigned int* s_cnt) {
   if constexpr (Env::PACKED) {
     if (!bsx_small_direct_shape(a.obs_numel)) {                 // uniform per workgroup
-      small_obs_group_body_d<Env, false>(a, blk, s_obs, s_cnt);
+      small_obs_group_body_d<Env, false, MT>(a, blk, s_obs, s_cnt);
       return;
     }
   }
-  small_obs_group_body_d<Env, true>(a, blk, s_obs, s_cnt);
+  small_obs_group_body_d<Env, true, MT>(a, blk, s_obs, s_cnt);
 }
 
 // Grouped launch: every workgroup looks up its segment and runs the single-step body on that

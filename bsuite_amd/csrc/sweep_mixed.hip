@@ -55,19 +55,19 @@ __device__ __forceinline__ void sweep_phase0_body(const uint8_t* __restrict__ ta
   const uint32_t blk = w.block;
   const uint8_t* slot = table + (size_t)w.seg * BSX_MIXED_ADV_STRIDE;
 #define SWEEP_SMALL_CASE(FAM, ENV) \
-  case FAM: small_obs_group_body<ENV>(*reinterpret_cast<const ENV::args*>(slot), blk, s_obs, s_cnt); break;
+  case FAM: small_obs_group_body<ENV, 0>(*reinterpret_cast<const ENV::args*>(slot), blk, s_obs, s_cnt); break;
   switch (tag) {
     case BSX_FAM_DEEP_SEA: {
       const deep_sea_fam::args& a = *reinterpret_cast<const deep_sea_fam::args*>(slot);
       if (bsx_ctl_lean(a.ctl)) bsx_advance_body<deep_sea_fam, true>(a, blk, s_ds, s_cnt);
-      else bsx_advance_body<deep_sea_fam, false>(a, blk, s_ds, s_cnt);
+      else bsx_advance_body<deep_sea_fam, false, 0>(a, blk, s_ds, s_cnt);
       break;
     }
     case BSX_FAM_CATCH: {
       const catch_fam::args& a = *reinterpret_cast<const catch_fam::args*>(slot);
       int32_t* tile = a.tile_cells_magic != 0u ? s_tile_state : nullptr;      // uniform: boards written right here
       if (bsx_ctl_lean(a.ctl)) bsx_advance_body<catch_fam, true>(a, blk, s_ca, s_cnt, tile);
-      else bsx_advance_body<catch_fam, false>(a, blk, s_ca, s_cnt, tile);
+      else bsx_advance_body<catch_fam, false, 0>(a, blk, s_ca, s_cnt, tile);
       if (tile != nullptr) {                   // (the advance ended with a barrier: the tile's states are complete)
         const int64_t lane0 = (int64_t)blk * BSX_BLOCK, left = a.ctl.n_lanes - lane0;
         const uint32_t cells = (uint32_t)(a.rows * a.columns);
@@ -76,7 +76,7 @@ __device__ __forceinline__ void sweep_phase0_body(const uint8_t* __restrict__ ta
       }
       break;
     }
-    case BSX_FAM_MNIST: mnist_advance_body(*reinterpret_cast<const mnist_args*>(slot), blk, s_cnt); break;
+    case BSX_FAM_MNIST: mnist_advance_body<0>(*reinterpret_cast<const mnist_args*>(slot), blk, s_cnt); break;
     SWEEP_SMALL_CASE(BSX_FAM_BANDIT, bandit_env)
     SWEEP_SMALL_CASE(BSX_FAM_MEMORY_CHAIN, memory_chain_env)
     SWEEP_SMALL_CASE(BSX_FAM_UMBRELLA_CHAIN, umbrella_chain_env)
@@ -107,7 +107,7 @@ __device__ __forceinline__ void sweep_phase0_body(const uint8_t* __restrict__ ta
   }
 }
 
-__global__ void __launch_bounds__(BSX_BLOCK) __attribute__((amdgpu_waves_per_eu(8))) sweep_phase0_kernel(
+__global__ void __launch_bounds__(BSX_BLOCK) sweep_phase0_kernel(
     const uint8_t* __restrict__ table, const int32_t* __restrict__ tags, const bsx_group_index gi, uint64_t* counter,
     uint32_t* ticket, uint64_t* trace) {
   extern __shared__ __attribute__((aligned(16))) float s_obs[];
@@ -135,7 +135,7 @@ int bsx_sweep_launch_phase0(bsx_group* g, hipStream_t st) {
 // their own TimeStep buffers, so nothing in the launch depends on anything else in it: the stream reads the
 // column phase 0 of step s wrote in the previous launch, phase 0 of step s+1 reads it too and writes the
 // other one.  The latency-bound phase 0 (~26 us alone) hides beside the ~140 us store stream.
-__global__ void __launch_bounds__(BSX_BLOCK) __attribute__((amdgpu_waves_per_eu(8))) sweep_pipelined_kernel(
+__global__ void __launch_bounds__(BSX_BLOCK) sweep_pipelined_kernel(
     const uint8_t* __restrict__ adv_table, const int32_t* __restrict__ adv_tags, const bsx_group_index adv_gi,
     uint64_t* counter, uint32_t* ticket, const uint32_t adv_blocks, const uint32_t place,
     const uint8_t* __restrict__ str_table, const int32_t* __restrict__ str_tags, const bsx_group_index str_gi) {

@@ -89,6 +89,17 @@ def test_lean_rollout_step_loops_reload_no_spilled_scalars():
     assert ki.loop_spill_reloads(text, min_depth=2) <= most, (name, ki.loop_spill_reloads(text, min_depth=2))
 
 
+def test_sweep_kernels_spill_nothing(kernels):
+  """sweep_phase0_kernel spilled 157 scalar registers (sweep_pipelined_kernel 58) under the 80-SGPR cap that
+  amdgpu_waves_per_eu(8) brings — the attribute held a kernel that compiled the MT19937-exact generators into every
+  wrapped segment's body to 64 VGPRs.  The whole-sweep launches are now compiled without those generators (the group
+  refuses MT19937-exact segments): 46 VGPRs without the attribute, no spill of either kind."""
+  for n in ('sweep_phase0_kernel', 'sweep_pipelined_kernel'):
+    k = kernels[n]
+    assert k['sgpr_spill_count'] == 0 and k['vgpr_spill_count'] == 0 and k['private_segment_fixed_size'] == 0, (n, k)
+    assert k['vgpr_count'] <= 64, (n, k['vgpr_count'])
+
+
 def test_wrapped_rollouts_keep_four_waves_per_simd(kernels):
   """the fused rollouts a Logging- or RewardNoise-wrapped environment runs (every *_noise id, every
   recorded run) were 157-218 VGPRs = 2 waves per SIMD: the ~60 f64 constants of the normal transform hoisted out of the
