@@ -240,6 +240,11 @@ __device__ __forceinline__ void small_obs_regs_rollout(const typename Env::args&
   int8_t* sp = a.out.step_type;
   float* op = a.out.observation;
   const int32_t* ap = a.action;
+  // (Tried, profiles/r04/ab_rollout_action_prepack.log: a pre-pass that leaves action[t, i] as a BYTE in step_type[t, i] —
+  // the slot this loop overwrites after reading it — so that the loop reads 1 byte per lane-step from an array one
+  // read-dominated pass has just produced.  The loop does not get faster by what the pre-pass costs: cartpole 9.9-10.2 ->
+  // 10.9-11.0 us per step, mountain_car 5.9-6.5 -> 5.8-6.1 at 2^20 lanes but 2.64 -> 2.93 at 2^19 and 5.5 -> 6.2 at
+  // T = 64.  Not adopted.)
 #pragma unroll 1
   for (int t0 = 0; t0 < n_steps; t0 += RUN) {
     const int run = n_steps - t0 < RUN ? n_steps - t0 : RUN;             // uniform

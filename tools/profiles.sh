@@ -15,6 +15,9 @@ timeout 400 python bench.py > $out/bench_default.json 2> $out/bench_default.err;
 timeout 400 python tools/kernel_stats.py $out/bench_headline_kernel_stats.csv -- --steps 200 --warmup 20 $A > /dev/null 2>$out/kernel_stats.err
 timeout 400 python tools/kernel_stats.py $out/bench_catch_kernel_stats.csv -- --workload catch --steps 200 --warmup 20 $A > /dev/null 2>>$out/kernel_stats.err
 timeout 400 python tools/kernel_stats.py $out/bench_sweep_kernel_stats.csv --last 100 -- --workload sweep --steps 100 --warmup 20 > /dev/null 2>>$out/kernel_stats.err
+# a rank's share of an 8-GPU strong-scaled run (2^17 lanes): deep_sea is ONE launch there (deep_sea_step1_kernel), catch the fused tile step
+timeout 300 python tools/kernel_stats.py $out/deep_sea_2p17_kernel_stats.csv -- --lanes 131072 --steps 200 --warmup 20 $A > /dev/null 2>>$out/kernel_stats.err
+timeout 300 python tools/kernel_stats.py $out/catch_2p17_kernel_stats.csv -- --workload catch --lanes 131072 --steps 200 --warmup 20 $A > /dev/null 2>>$out/kernel_stats.err
 # HBM traffic (WRITE_SIZE / FETCH_SIZE, separate passes) of every BASELINE config
 pm() { timeout 240 python tools/pmc.py "$@" 2>&1 | tail -1; }
 pm traffic deep_sea $out/deep_sea_pmc_traffic.json --kernels "bsx_advance_kernel<deep_sea_fam" "bsx_hot_stream_kernel<deep_sea_hot" --alg-bytes $((3621*B)) -- --steps 20 --warmup 4 $A --workload deep_sea
@@ -28,7 +31,7 @@ pm traffic sweep_pipelined $out/sweep_pipelined_pmc_traffic.json --kernels sweep
 # issue-side counters of the fused rollouts (bound "valu") and of the eager physics steps
 for w in cartpole mountain_car; do
   ns=""; [ $w = mountain_car ] && ns="--no-stagger"
-  pm sq ${w}_rollout16 $out/${w}_rollout16_pmc_sq.json --kernels "small_obs_kernel<${w}_env, true" --last 4 -- --workload $w --rollout 16 --steps 64 --warmup 16 $A $ns
+  pm sq ${w}_rollout16 $out/${w}_rollout16_pmc_sq.json --kernels "small_obs_lean_rollout_kernel<${w}_env" --last 4 -- --workload $w --rollout 16 --steps 64 --warmup 16 $A $ns
   pm sq ${w}_eager $out/${w}_eager_pmc_sq.json --kernels "small_obs_kernel<${w}_env, false" -- --workload $w --steps 20 --warmup 4 $A $ns
 done
 if [ "${1:-}" != quick ]; then
@@ -39,8 +42,8 @@ import sys,json; d=json.loads(sys.stdin.read()); r=d['roofline']; print('%-18s e
   timeout 400 python tools/strong_scaling_proxy.py $out/strong_scaling_proxy.json > $out/strong_scaling_proxy.log 2>&1
   BSX_BENCH_BACKEND=gloo BSX_BENCH_SINGLE_DEVICE=1 timeout 400 python bench.py --gpus 2 --no-cpu-baseline 2>/dev/null | grep '^{' > $out/bench_2ranks_on_one_gpu_gloo.json
   timeout 300 python tools/physics_error.py > $out/physics_error.log 2>&1; cp gpurun_out/physics_error.json $out/ 2>/dev/null
-  timeout 400 python tools/fuzz_gpu.py --seconds 300 --seed 11 > $out/fuzz_gpu_300s.log 2>&1; tail -1 $out/fuzz_gpu_300s.log
-  # the engine against the UNMODIFIED reference, live: 8 x 1000 random cases (families, kwargs, wrappers, resets, policies)
-  ( BSX_LIVE_CASES=1000 timeout 900 python -m pytest tests/test_gpu_vs_reference_live.py -q -m gpu ) > $out/live_reference_8000_cases.log 2>&1; tail -2 $out/live_reference_8000_cases.log
+  timeout 300 python tools/fuzz_gpu.py --seconds ${FUZZ_SECONDS:-300} --seed 11 > $out/fuzz_gpu.log 2>&1; tail -1 $out/fuzz_gpu.log
+  # the engine against the UNMODIFIED reference, live: 8 x LIVE_CASES random cases (families, kwargs, wrappers, resets, policies)
+  ( BSX_LIVE_CASES=${LIVE_CASES:-1000} timeout 900 python -m pytest tests/test_gpu_vs_reference_live.py -q -m gpu ) > $out/live_reference_cases.log 2>&1; tail -2 $out/live_reference_cases.log
 fi
 ls -la $out
