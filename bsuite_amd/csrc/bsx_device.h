@@ -511,6 +511,46 @@ __global__ void __launch_bounds__(BSX_BLOCK) bsx_fused_tile_kernel(const typenam
   bsx_tile_stream(obs + lane0 * (int64_t)cells, s_state, left < BSX_BLOCK ? (int)left : BSX_BLOCK, cells, cells_magic, fn);
 }
 
+// ... with 64-lane tiles: wave 0 advances the workgroup's 64 lanes, all four waves stream their [64 x cells] boards.  A
+// rank's share of a strong-scaled batch (2^17 lanes of catch) is 512 workgroups of the 256-lane kernel — two per CU,
+// every wave a chain of {loads, advance, barrier, 13 chunk stores}; 64-lane tiles make it 2048 workgroups (8 per CU)
+// whose threads each write 3 chunks.
+template <class Fam, bool LEAN, class HotFn>
+__global__ void __launch_bounds__(BSX_BLOCK) bsx_fused_tile64_kernel(const typename Fam::args a, float* __restrict__ obs,
+                                                                     const uint32_t cells, const uint32_t cells_magic,
+                                                                     const HotFn fn) {
+  __shared__ typename Fam::shared s_fam;
+  __shared__ int32_t s_state[BSX_WAVE];
+  Fam::stage(a, s_fam);
+  __syncthreads();
+  const int64_t lane0 = (int64_t)blockIdx.x * BSX_WAVE;
+  const int64_t i = lane0 + threadIdx.x;
+  int type = -1;
+  if (threadIdx.x < BSX_WAVE && i < a.ctl.n_lanes) {
+    const uint64_t lane = a.ctl.lane_offset + (uint64_t)i;
+    const uint64_t step = bsx_step_of(a.ctl);
+    int32_t nst; double reward;
+    const int act = a.ctl.force_reset ? 0 : bsx_action(a.ctl, a.action, i, step);
+    const int32_t st = a.ctl.state_in != nullptr ? a.ctl.state_in[i] : a.state[i];
+    type = Fam::template advance<LEAN>(a, s_fam, i, lane, step, st, act, nst, reward);
+    a.state[i] = nst;
+    s_state[threadIdx.x] = nst;
+    if (LEAN) bsx_emit_at<0, 0, false>(a.ctl, a.out, i, i, lane, step, type, reward);
+    else bsx_emit(a.ctl, a.out, i, lane, step, type, reward);
+  }
+  if (threadIdx.x < BSX_WAVE && a.ctl.counters != nullptr) {               // one wave: its ballots ARE the workgroup's counts
+    const unsigned long long last = __ballot(type == BSX_LAST), first = __ballot(type == BSX_FIRST);
+    if (threadIdx.x == 0 && (last | first) != 0ull) {
+      unsigned long long* shard = (unsigned long long*)a.ctl.counters + (size_t)(blockIdx.x & (BSX_COUNTER_SHARDS - 1)) * BSX_COUNTER_STRIDE;
+      if (last) atomicAdd(&shard[0], (unsigned long long)__popcll(last));
+      if (first) atomicAdd(&shard[1], (unsigned long long)__popcll(first));
+    }
+  }
+  __syncthreads();
+  const int64_t left = a.ctl.n_lanes - lane0;
+  bsx_tile_stream(obs + lane0 * (int64_t)cells, s_state, left < BSX_WAVE ? (int)left : BSX_WAVE, cells, cells_magic, fn);
+}
+
 // The same for a rollout of T steps: ONE launch.  Lanes never interact, so a workgroup can take its 256 lanes
 // through all T steps on its own — packed state in a register, actions prefetched one step ahead, per step one
 // barrier (the LDS state tile is double-buffered) and the [256 x cells] tile of slice t streamed while the next

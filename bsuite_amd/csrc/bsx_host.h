@@ -304,6 +304,9 @@ static int bsx_pair_call(const typename Fam::args& a0, const bsx_call_t* call, c
   static const int fused_cells = bsx_env_int("BSX_FUSED_TILE_MAX_CELLS", 128);
   static const int fused_step_mib = bsx_env_int("BSX_FUSED_TILE_MAX_MIB", 128);
   static const int fused_roll_mib = bsx_env_int("BSX_FUSED_ROLLOUT_MAX_MIB", 128);
+  // (64-lane tiles up to 2^17 lanes: catch 2^15 7.3 -> 5.6 us, 2^16 8.1 -> 6.0, 2^17 9.1 -> 8.0; 2^18 12.3 -> 12.7 keeps the
+  // 256-lane tiles; profiles/r04/ab_catch_fused_tile64.log)
+  static const int64_t tile64_max_lanes = bsx_env_int("BSX_FUSED_TILE64_MAX_LANES", 1 << 17);
   const int64_t step_bytes = B * (int64_t)cells * 4;
   const bool fusable = call->obs_paint == nullptr && cells >= 4u && (int)cells <= fused_cells &&
                        (((uint64_t)B * cells) & 3ull) == 0 && (reinterpret_cast<uintptr_t>(out.observation) & 15u) == 0;
@@ -320,6 +323,10 @@ static int bsx_pair_call(const typename Fam::args& a0, const bsx_call_t* call, c
       const typename Fam::args s = at(t);
       if (call->obs_paint != nullptr) {
         rc = bsx_launch_advance_delta<Fam, HotFn>(s, fn, call->obs_paint, cells, st);
+      } else if (fused && lean_f && B <= tile64_max_lanes) {
+        // (64-lane tiles while the 256-lane grid would leave the chip under-filled: bsx_fused_tile64_kernel)
+        const dim3 grid((unsigned)((B + BSX_WAVE - 1) / BSX_WAVE)), block(BSX_BLOCK);
+        bsx_fused_tile64_kernel<Fam, true, HotFn><<<grid, block, 0, st>>>(s, s.out.observation, cells, magic, fn);
       } else if (fused) {
         const dim3 grid((unsigned)((B + BSX_BLOCK - 1) / BSX_BLOCK)), block(BSX_BLOCK);
         if (lean_f) bsx_fused_tile_kernel<Fam, true, HotFn><<<grid, block, 0, st>>>(s, s.out.observation, cells, magic, fn);
