@@ -4,8 +4,9 @@ fused one-launch step / rollout (bsx_fused_tile_kernel, bsx_fused_rollout_kernel
 boards whose 16-byte chunks straddle two lanes, odd slice alignments, both parities of T — exercise the FUSED kernel;
 the pair path runs in-process only for bigger boards (deep_sea N >= 12, incl. the benched N=30) and batches.  Here
 the same small-shape parity tests run once more in a subprocess against the tuning build of the library (-DBSX_TUNING,
-bsuite_amd/build.py) with BSX_FUSED_TILE_MAX_CELLS=0, i.e. with the fused step switched off: every edge case of the
-stream kernel stays covered against the golden fixtures and the C oracle."""
+bsuite_amd/build.py) with BSX_FUSED_TILE_MAX_CELLS=0 and BSX_DEEP_SEA_STEP1=0, i.e. with the fused step and the single-launch
+deep_sea step (N >= 28, up to 2^18 lanes) switched off: every edge case of the stream kernel stays covered against the
+golden fixtures and the C oracle."""
 import os
 import subprocess
 import sys
@@ -19,12 +20,28 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 @pytest.mark.timeout(1200)
 def test_pair_path_parity_at_small_shapes():
   from bsuite_amd import build as _build
-  env = dict(os.environ, BSX_NATIVE_LIB=_build.build(tuning=True), BSX_FUSED_TILE_MAX_CELLS='0', PYTHONPATH=ROOT)
+  env = dict(os.environ, BSX_NATIVE_LIB=_build.build(tuning=True), BSX_FUSED_TILE_MAX_CELLS='0', BSX_DEEP_SEA_STEP1='0', PYTHONPATH=ROOT)
   p = subprocess.run([sys.executable, '-m', 'pytest', '-q', '-x', '-m', 'gpu', '-p', 'no:cacheprovider',
                       'tests/test_gpu_golden.py', 'tests/test_gpu_oracle_batch.py', 'tests/test_gpu_rollout.py',
                       'tests/test_gpu_delta_obs.py', 'tests/test_gpu_engine_features.py',
                       '-k', 'deep_sea or catch or pipelined or delta or engine'],
                      cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=1100)
+  tail = p.stdout[-3000:]
+  assert p.returncode == 0, tail
+  assert ' passed' in tail and 'failed' not in tail, tail
+
+
+@pytest.mark.timeout(900)
+def test_256_lane_fused_tiles_at_small_shapes():
+  """Up to 2^17 lanes the fused one-launch step uses 64-lane tiles (bsx_fused_tile64_kernel), so the in-process tests at
+  small shapes no longer reach the 256-lane tile kernel that 2^17 < B <= 2^19 lanes take: here they do
+  (BSX_FUSED_TILE64_MAX_LANES=0 in the tuning build)."""
+  from bsuite_amd import build as _build
+  env = dict(os.environ, BSX_NATIVE_LIB=_build.build(tuning=True), BSX_FUSED_TILE64_MAX_LANES='0', PYTHONPATH=ROOT)
+  p = subprocess.run([sys.executable, '-m', 'pytest', '-q', '-x', '-m', 'gpu', '-p', 'no:cacheprovider',
+                      'tests/test_gpu_golden.py', 'tests/test_gpu_oracle_batch.py', 'tests/test_gpu_engine_features.py',
+                      '-k', 'deep_sea or catch or engine'],
+                     cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=800)
   tail = p.stdout[-3000:]
   assert p.returncode == 0, tail
   assert ' passed' in tail and 'failed' not in tail, tail
