@@ -244,7 +244,13 @@ __device__ __forceinline__ void small_obs_regs_rollout(const typename Env::args&
   // the slot this loop overwrites after reading it — so that the loop reads 1 byte per lane-step from an array one
   // read-dominated pass has just produced.  The loop does not get faster by what the pre-pass costs: cartpole 9.9-10.2 ->
   // 10.9-11.0 us per step, mountain_car 5.9-6.5 -> 5.8-6.1 at 2^20 lanes but 2.64 -> 2.93 at 2^19 and 5.5 -> 6.2 at
-  // T = 64.  Not adopted.)
+  // T = 64.  Not adopted.
+  // Nor did removing the per-run drain: the next run's actions loaded by inline asm at the START of the current run
+  // (invisible to the compiler's wait insertion) and awaited at its end with `s_waitcnt vmcnt(8 x stores per step)`,
+  // which the loads alone satisfy — correct (rollout tests), mountain_car r16 6.5-6.65 -> 6.25-6.4 us, nothing at
+  // T = 32 / 64, cartpole +-1 % at the price of its eighth wave (profiles/r04/ab_rollout_prefetched_runs.log).  The loop
+  // is 26 % faster without its action loads (exp_action_load_ablation.log), but neither their bytes, nor their
+  // source, nor the wait behind them is where that time goes.)
 #pragma unroll 1
   for (int t0 = 0; t0 < n_steps; t0 += RUN) {
     const int run = n_steps - t0 < RUN ? n_steps - t0 : RUN;             // uniform
