@@ -75,7 +75,7 @@ static void run(const char* what, int T, size_t B) {
   const double us = ms / 10 * 1e3;
   double bytes = 0;
   if (MASK & 1) bytes += 4; if (MASK & 2) bytes += 4; if (MASK & 4) bytes += 1; if (MASK & 32) bytes += 4;
-  if (MASK & 64) bytes += 9; if (MASK & 8) bytes += 4 * ROWF; if (MASK & (16 | 128 | 256)) bytes += 4;
+  if (MASK & 64) bytes += 9; if (MASK & 8) bytes += 4 * ROWF; if (MASK & (16 | 128 | 256 | 512)) bytes += 4;
   printf("  %-58s %7.2f us per step  %5.2f TB/s (%2.0f B per lane-step)\n", what, us / T, bytes * B * T / us / 1e6, bytes);
 }
 
@@ -121,5 +121,10 @@ int main() {
   run<128, 3>("rows of 3: action loads only (runs of 8)", T, B);
   run<1 | 2 | 4 | 8 | 128, 6>("rows of 6: action loads in runs of 8", T, B);
   run<1 | 2 | 4 | 8 | 128, 3, 128>("rows of 3: 128 FMAs + action loads in runs of 8", T, B);
+  run<1 | 2 | 4 | 8 | 512, 3>("rows of 3: the same rows through the scalar cache (s_load)", T, B);
+  run<1 | 2 | 4 | 8 | 512, 6>("rows of 6: the same rows through the scalar cache (s_load)", T, B);
+  run<512, 3>("rows of 3: scalar loads only", T, B);
+  run<1 | 2 | 4 | 8, 3>("rows of 3: no loads", T, B);
+  run<1 | 2 | 4 | 8, 6>("rows of 6: no loads", T, B);
   return 0;
 }
