@@ -249,8 +249,10 @@ __device__ __forceinline__ void small_obs_regs_rollout(const typename Env::args&
   // (invisible to the compiler's wait insertion) and awaited at its end with `s_waitcnt vmcnt(8 x stores per step)`,
   // which the loads alone satisfy — correct (rollout tests), mountain_car r16 6.5-6.65 -> 6.25-6.4 us, nothing at
   // T = 32 / 64, cartpole +-1 % at the price of its eighth wave (profiles/r04/ab_rollout_prefetched_runs.log).  The loop
-  // is 26 % faster without its action loads (exp_action_load_ablation.log), but neither their bytes, nor their
-  // source, nor the wait behind them is where that time goes.)
+  // is 26-36 % faster without its action loads (exp_action_load_ablation.log) — and so is the bare access pattern
+  // (tools/micro/step_stores.hip, same box: 3.95 us without loads, 5.04 in runs of eight, 4.64 with all rows loaded
+  // before the first store = the loads' own 0.69 us added; prefetched a run ahead 5.70): reads among a saturating
+  // stream of per-lane stores cost at least their own time, in any arrangement.)
 #pragma unroll 1
   for (int t0 = 0; t0 < n_steps; t0 += RUN) {
     const int run = n_steps - t0 < RUN ? n_steps - t0 : RUN;             // uniform
