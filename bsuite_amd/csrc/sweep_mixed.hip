@@ -45,6 +45,10 @@ int bsx_small_mixed_launch(bsx_group* g, int phase, hipStream_t st) {
 // streams (cross-queue waits cost ~10 us each; kernels sharing the machine with the store stream
 // stretch it: profiles/r02/ab_sweep_*.log, sweep_*_timeline*.txt).  The last workgroup to retire bumps
 // the call counter the segments share, so no other kernel has to.
+// (Tried, profiles/r04/ab_sweep_state_warmers.log: this launch takes ~20 us back to back and ~30 us behind the 850 MB
+// store stream, so the stream launch was ended by one "warmer" workgroup per small-observation workgroup of this one,
+// loading — and dropping — the state words it is going to read into the same XCD's L2.  166.6 -> 192.6 us per sweep
+// step: reads placed among the stream's draining stores wait just as long and slow the stores down too.  Not adopted.)
 __device__ __forceinline__ void sweep_phase0_body(const uint8_t* __restrict__ table, const int32_t* __restrict__ tags,
                                                   const bsx_group_index& gi, uint64_t* counter, uint32_t* ticket,
                                                   const uint32_t block, const uint32_t n_blocks, float* s_obs,
