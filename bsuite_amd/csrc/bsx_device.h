@@ -374,6 +374,10 @@ __device__ __forceinline__ void bsx_hot_stream_body(float* __restrict__ obs,
                                                     int64_t n_lanes, uint32_t cells,
                                                     uint32_t cells_magic, bsx_div64 dv,
                                                     const HotFn& fn, uint32_t block_id, int wave_contig = 1) {
+#ifdef BSX_TUNING
+  const int pace = wave_contig >> 8;                                     // BSX_STREAM_PACE (bsx_launch_hot_stream)
+  wave_contig &= 1;
+#endif
   const uint64_t total = (uint64_t)n_lanes * cells;                      // floats in the array
   const uint64_t F0 = (uint64_t)block_id * (uint64_t)(K * 4 * BS);
   const uint64_t lane_b = __umul64hi(F0, dv.m) >> dv.s;                  // uniform
@@ -387,6 +391,9 @@ __device__ __forceinline__ void bsx_hot_stream_body(float* __restrict__ obs,
   int r0[K];
   int32_t s0[K], s1[K];
   bool live[K];
+  // (Measured in round 4, profiles/r04/ab_stream_without_state_loads.log / ab_stream_occupancy_pace.log: WITHOUT these loads
+  // the stream is 9 % slower; with fewer than 8 resident workgroups per CU it is slower at every step (7: +5 %, 4: +26 %);
+  // s_sleep pacing between the loads and the stores never helps.)
   // (One state load per WAVE — lane j fetches row (first row of the wave) + j — handed to the chunks through
   // ds_bpermute instead of one mostly redundant load per chunk: 7 % slower, deep_sea 593 -> 636 us; the K stores then
   // all hang on one load + a cross-lane hop.  profiles/r03/ab_stream_wave_state_load.log)
@@ -401,9 +408,17 @@ __device__ __forceinline__ void bsx_hot_stream_body(float* __restrict__ obs,
     dl[u] = __umulhi(f, cells_magic);
     r0[u] = (int)(f - dl[u] * cells);
     live[u] = F0 + ((uint64_t)c << 2) + 3 < total;
+#if defined(BSX_ABLATE_STREAM_LOADS)      // measurement builds only (tools/ab/): the store stream without its state loads
+    s0[u] = live[u] ? (int32_t)(dl[u] * 7u + (uint32_t)lane_b) & 0x0F0F : 0;
+    s1[u] = s0[u] + 1;
+#else
     s0[u] = live[u] ? st[dl[u]] : 0;
     s1[u] = (live[u] && !aligned && (uint64_t)dl[u] + 1 < lanes_left) ? st[dl[u] + 1] : 0;
+#endif
   }
+#ifdef BSX_TUNING
+  for (int q = 0; q < pace; ++q) __builtin_amdgcn_s_sleep(16);           // 16 x 64 clocks per round
+#endif
 #pragma unroll
   for (int u = 0; u < K; ++u) {
     if (!live[u]) continue;

@@ -151,8 +151,10 @@ static inline int bsx_launch_hot_stream(float* obs, const int32_t* state, int64_
   const uint64_t blocks = (total + per_block - 1) / per_block;
   if (blocks > 0x7FFFFFFFull) return BSX_EINVAL;
   const dim3 g((unsigned)blocks);
-  static const int wave_contig = bsx_env_int("BSX_STREAM_WAVE_CONTIG", 1);
-#define BSX_HS(KK, BS) case KK: bsx_hot_stream_kernel<HotFn, KK, BS><<<g, dim3(BS), 0, st>>>(obs, state, n_lanes, cells, cells_magic, dv, fn, wave_contig); break
+  // BSX_STREAM_LDS: dynamic LDS nobody uses = fewer workgroups per CU; BSX_STREAM_PACE: s_sleep rounds before the stores
+  static const int wave_contig = bsx_env_int("BSX_STREAM_WAVE_CONTIG", 1) | (bsx_env_int("BSX_STREAM_PACE", 0) << 8);
+  static const int lds = bsx_env_int("BSX_STREAM_LDS", 0);
+#define BSX_HS(KK, BS) case KK: bsx_hot_stream_kernel<HotFn, KK, BS><<<g, dim3(BS), (size_t)lds, st>>>(obs, state, n_lanes, cells, cells_magic, dv, fn, wave_contig); break
 #define BSX_HS_ALL(BS) switch (kk) { BSX_HS(1, BS); BSX_HS(2, BS); BSX_HS(3, BS); BSX_HS(4, BS); BSX_HS(5, BS); BSX_HS(6, BS); BSX_HS(8, BS); BSX_HS(12, BS); BSX_HS(16, BS); default: return BSX_EINVAL; }
   if (bs == 256) { BSX_HS_ALL(256) }
   else if (bs == 128) { BSX_HS_ALL(128) }
