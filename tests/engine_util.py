@@ -162,16 +162,23 @@ def oracle_physics_state(orc, family):
   return dict(x=s[:, 0].copy(), theta=s[:, 2].copy(), theta_dot=s[:, 3].copy())
 
 
-def teacher_force(raw_env, orc, family):
-  """device f32 state := f32(reference f64 state); step counter and reset flag := the reference's."""
+def teacher_force(raw_env, orc, family, lanes=None):
+  """device f32 state := f32(reference f64 state); step counter and reset flag := the reference's.  `lanes`: an index
+  tensor — only those lanes of the environment (the oracle then holds exactly them, in that order)."""
   if family == 'mountain_car':
     st32 = np.stack([orc.s['position'], orc.s['velocity']]).astype(np.float32)
     k = orc.s['timestep'].astype(np.int32)
   else:
     st32 = orc.s['state'][:, :4].T.astype(np.float32)
     k = np.rint(orc.s['state'][:, 4] / orc.cfg.timescale).astype(np.int32)
-  raw_env._state['state'].copy_(torch.from_numpy(np.ascontiguousarray(st32)).cuda())
-  raw_env._state['steps'].copy_(torch.from_numpy(k | (orc.reset_next.astype(np.int32) << 30)).cuda())
+  st_t = torch.from_numpy(np.ascontiguousarray(st32)).cuda()
+  k_t = torch.from_numpy(k | (orc.reset_next.astype(np.int32) << 30)).cuda()
+  if lanes is None:
+    raw_env._state['state'].copy_(st_t)
+    raw_env._state['steps'].copy_(k_t)
+  else:
+    raw_env._state['state'][:, lanes] = st_t
+    raw_env._state['steps'][lanes] = k_t
 
 
 def _force_physics_state(env, fam, phys_prev, idx):

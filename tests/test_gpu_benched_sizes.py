@@ -55,19 +55,29 @@ def test_config5_full_sweep_as_benched(tmp_path, pipelined):
       okw.update(images=imgs, labels=labels)
     idx = np.unique(np.concatenate([[0, lanes - 1], rng.integers(0, lanes, size=n_samp - 2)]))
     orc = coracle.OracleEnv(fam, okw, (begin + idx).astype(np.uint64), seed=seed, wrap=wrap)
-    orcs.append((fam, idx, torch.from_numpy(idx).to(batch.device), orc, np.ones(len(idx), bool)))
+    chk = eu.PhysicsChecker(fam, okw, len(idx)) if fam in PHYSICS else None
+    orcs.append((fam, idx, torch.from_numpy(idx).to(batch.device), orc, np.ones(len(idx), bool), chk))
 
   for s in range(steps):
     out = batch.step_grouped()
     if pipelined:
       assert out is outs[s & 1]
-    for (bid, _, _), a, ts, (fam, idx, idx_t, orc, same) in zip(batch.segments, acts, out, orcs):
+    for (bid, _, _), a, ts, env, (fam, idx, idx_t, orc, same, chk) in zip(batch.segments, acts, out, batch.envs, orcs):
       st, r, d, o = orc.call(a[s % ring][idx_t].cpu().numpy(), s)
       gst, gr, gd, go = (x[idx_t].cpu().numpy() for x in (ts.step_type, ts.reward, ts.discount, ts.observation))
       live = st != 0
-      if fam in PHYSICS:
-        # free-running f32 engine vs the f64 oracle (no teacher forcing inside a grouped launch): the lanes
-        # whose step types still agree stay within the drift profiles/HISTORY.md §5 reports for a few dozen calls
+      if fam in PHYSICS and not pipelined:
+        # closed loop: the state columns are plain tensors the group's argument slots point at, so the sampled lanes
+        # are TEACHER-FORCED between step_grouped() calls like every other physics test — f32(reference f64 state)
+        # in, one call, 1e-6 * max(1, |b|) on every continuous component (a verified threshold tie waives the
+        # discrete fields only: PhysicsChecker)
+        chk.check((gst, gr, gd, go), (st, r, d, o), eu.oracle_physics_state(orc, fam), msg=f'{bid} s={s}')
+        eu.teacher_force(eu.raw(env), orc, fam, lanes=idx_t)
+      elif fam in PHYSICS:
+        # pipelined: the lanes are already one advance ahead when a step's TimeSteps come back, nothing can be forced;
+        # free-running f32 engine vs the f64 oracle — the lanes whose step types still agree stay within the drift
+        # profiles/HISTORY.md §5 reports for a few dozen calls (the all-lane bit-equality with a stand-alone
+        # environment below is the pin)
         same &= gst == st
         assert same.mean() > 0.7, bid
         assert np.abs(go[same].astype(np.float64) - o[same]).max() <= 2e-4, (bid, s)
@@ -83,6 +93,10 @@ def test_config5_full_sweep_as_benched(tmp_path, pipelined):
 
   # every lane of every segment == the stand-alone environment of that id (same kernels, another launch path)
   total_last = 0
+  forced = {bid: idx for (bid, _, _), (fam, idx, _, _, _, _) in zip(batch.segments, orcs) if fam in PHYSICS and not pipelined}
+  for _, _, _, _, _, chk in orcs:
+    if chk is not None and not pipelined:
+      chk.assert_few_ties()
   for (bid, begin, lanes), a, ts, env in zip(batch.segments, acts, out, batch.envs):
     name = bid.split('/')[0]
     ekw = dict(kw.get(name, {}))
@@ -91,15 +105,22 @@ def test_config5_full_sweep_as_benched(tmp_path, pipelined):
     ref = bsuite_amd.load_from_id(bid, batch=lanes, lane_offset=begin, num_buffers=1, **ekw)
     for s in range(steps):
       rts = ref.step(a[s % ring])
+    keep = np.ones(lanes, bool)
+    if forced.get(bid) is not None:
+      keep[forced[bid]] = False               # (the teacher-forced sample lanes no longer follow the free-running engine)
     for x, y in zip(eu.to_np(ts), eu.to_np(rts)):
-      np.testing.assert_array_equal(x, y, err_msg=bid)
+      np.testing.assert_array_equal(x[keep], y[keep], err_msg=bid)
     for s in range(steps, steps + ahead):
       ref.step(a[s % ring])
+    keep_t = torch.from_numpy(keep).to(batch.device)
     for k, v in ref.bsuite_info().items():
-      torch.testing.assert_close(env.bsuite_info()[k], v, rtol=0, atol=0)
-    torch.testing.assert_close(eu.raw(env).episode_counters(), eu.raw(ref).episode_counters(), rtol=0, atol=0)
-    vec, names = bdist.local_summary(ref)
-    assert summ[bid] == dict(zip(names, vec.tolist())), bid          # exact, per segment
+      torch.testing.assert_close(env.bsuite_info()[k][..., keep_t], v[..., keep_t], rtol=0, atol=0)
+    if forced.get(bid) is None:
+      # (a segment with teacher-forced sample lanes: its sums are those of slightly different trajectories; the
+      # pipelined parametrisation of this test holds every id to these two exact comparisons)
+      torch.testing.assert_close(eu.raw(env).episode_counters(), eu.raw(ref).episode_counters(), rtol=0, atol=0)
+      vec, names = bdist.local_summary(ref)
+      assert summ[bid] == dict(zip(names, vec.tolist())), bid        # exact, per segment
     total_last += summ[bid]['episodes_finished']
     del ref
   assert total_last > B                                              # the bandits alone finish 25 episodes per lane

@@ -1,6 +1,12 @@
 """GPU: rollout(actions[T,B]) == T consecutive step() calls, bit for bit, for every family —
 including the fused T-step kernels of the small-observation families, odd observation widths
-(unaligned [t] slices), wrappers and the Logging bookkeeping."""
+(unaligned [t] slices), wrappers and the Logging bookkeeping.
+
+This is ENGINE vs ENGINE on purpose: `step()` is what the oracle, the golden fixtures and the live reference pin
+(tests/test_gpu_oracle_batch.py, test_gpu_golden.py, test_gpu_vs_reference_live.py), and bit-equality of the fused
+rollouts with T such calls is a stronger statement than any tolerance against the f64 oracle could be — for the
+physics families in particular, whose free-running f32 trajectories leave the 1e-6 band of a free-running f64
+reference within a few dozen calls."""
 import numpy as np
 import pytest
 import torch
