@@ -54,6 +54,24 @@ __host__ __device__ __forceinline__ bool bsx_ctl_lean(const bsx_ctl& c) {
   return c.log.steps == nullptr && c.wrap_kind < BSX_WRAP_NOISE && c.mt_state == nullptr && c.reward_f64 == nullptr;
 }
 
+// bsuite_info accumulators (f64 columns [K, B], a lane owns its slots).  An update can be a NO-RETURN hardware atomic
+// (global_atomic_add_f64) where nothing in the launch reads the column back (no fused Logging rows): the same IEEE add,
+// executed at the L2, and the wave does not wait for a dependent load of a cold column from HBM before it stores.
+// Measured in every family, same call (profiles/r04/ab_info_atomics.log): it pays where a few lanes of a wave update now
+// and then — memory_chain with long episodes, memory_len 13.3 -> 12.0 us per step — and costs where updates are dense
+// (bandit 9.6 -> 11.2, memory_size 44.1 -> 47.4, umbrella_distract 98 -> 103, deep_sea's headline 589 -> 595) or is
+// neutral (cartpole, mountain_car, mnist): adopted for memory_chain at L >= 8 only.  The columns must then be ordinary
+// device memory (hardware f64 atomics do not reach fine-grained host mappings): include/bsuite_amd.h says so.
+// `quiet`: no Logging wrapper reads the column in this launch (bsx_track snapshots it).
+__device__ __forceinline__ void bsx_info_add(bool quiet, double* p, double v) {
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(BSX_NO_INFO_ATOMICS)
+  if (quiet) { __builtin_amdgcn_global_atomic_fadd_f64((__attribute__((address_space(1))) double*)p, v); return; }
+#endif
+  *p += v;
+}
+template <int LOG>
+__device__ __forceinline__ bool bsx_info_quiet(const bsx_ctl& c) { return LOG == 0 || (LOG == -1 && c.log.steps == nullptr); }
+
 __device__ __forceinline__ uint64_t bsx_step_of(const bsx_ctl& c) {
   return c.step_index + (c.step_base ? *c.step_base : 0ull);
 }

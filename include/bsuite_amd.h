@@ -7,7 +7,9 @@
  * entry point per environment family.  Every entry point is the drop-in for the `_step/_reset`
  * pair it cites.  All pointers are DEVICE pointers (HIP) unless a comment says "host"; nothing
  * here allocates, synchronises or reads back — calls are asynchronous on the caller's stream and
- * safe to capture into a hipGraph.
+ * safe to capture into a hipGraph.  The `info` columns must be ordinary (coarse-grained) device
+ * memory, e.g. hipMalloc: memory_chain's end-of-episode update is a hardware f64 atomic, which does
+ * not reach fine-grained host mappings.
  *
  * Return value of every function: 0 = ok, <0 = argument error (see bsx_strerror), >0 = hipError_t.
  *
