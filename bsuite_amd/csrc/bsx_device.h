@@ -237,6 +237,19 @@ __device__ __forceinline__ void bsx_count_types(const bsx_ctl& c, int type, unsi
   }
 }
 
+// The LAST barrier of a workgroup, in front of bsx_flush_counts: it has to order the waves' LDS counter updates and
+// nothing else.  __syncthreads() is a fence + barrier, and on gfx9 its release half waits for vmcnt(0) — every wave
+// sat through the acknowledgements of its final stores (1-3 us behind a saturated memory system) before it could
+// arrive, and the workgroup's slot stayed taken for that long; the waves may simply END with their stores in flight
+// (the kernel's completion covers them).  BSX_FINAL_BARRIER_FENCED restores the old form for A/B builds.
+__device__ __forceinline__ void bsx_final_barrier() {
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(BSX_FINAL_BARRIER_FENCED)
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+#else
+  __syncthreads();
+#endif
+}
+
 // Call after a __syncthreads() that follows every wave's bsx_count_types.
 __device__ __forceinline__ void bsx_flush_counts(const bsx_ctl& c, const unsigned int* s_cnt,
                                                  uint32_t block_id = 0xFFFFFFFFu) {
@@ -334,7 +347,7 @@ __device__ __forceinline__ void bsx_advance_body(const typename Fam::args& a, ui
     else bsx_emit_at<-1, -1, true, MT>(a.ctl, a.out, i, i, lane, step, type, reward);
   }
   bsx_count_types(a.ctl, type, s_cnt);
-  __syncthreads();
+  bsx_final_barrier();
   bsx_flush_counts(a.ctl, s_cnt, block_id);
 }
 
@@ -627,7 +640,7 @@ __global__ void __launch_bounds__(BSX_BLOCK) bsx_fused_rollout_kernel(const type
     bsx_tile_stream(obs + ((int64_t)t * B + lane0) * (int64_t)cells, s_state[t & 1], lanes_here, cells, cells_magic, fn);
   }
   if (mine) a.state[i] = st;
-  __syncthreads();
+  bsx_final_barrier();
   bsx_flush_counts(a.ctl, s_cnt, blockIdx.x);
 }
 
@@ -697,7 +710,7 @@ __global__ void __launch_bounds__(BSX_BLOCK) bsx_advance_delta_kernel(const type
     bsx_emit(a.ctl, a.out, i, lane, step, type, reward);
   }
   bsx_count_types(a.ctl, type, s_cnt);
-  __syncthreads();
+  bsx_final_barrier();
   bsx_flush_counts(a.ctl, s_cnt, blockIdx.x);
 }
 

@@ -52,7 +52,7 @@ __device__ __forceinline__ void mnist_advance_body(const mnist_args& a, uint32_t
     bsx_emit_at<-1, -1, true, MT>(a.ctl, a.out, i, i, lane, step, type, reward);
   }
   bsx_count_types(a.ctl, type, s_cnt);
-  __syncthreads();
+  bsx_final_barrier();
   bsx_flush_counts(a.ctl, s_cnt, block_id);
 }
 

@@ -400,7 +400,7 @@ __device__ __forceinline__ void small_obs_regs_rollout(const typename Env::args&
     if (n_last) atomicAdd(&s_cnt[0], n_last);
     if (n_first) atomicAdd(&s_cnt[1], n_first);
   }
-  __syncthreads();
+  bsx_final_barrier();
   bsx_flush_counts(a.ctl, s_cnt, block_id);
 }
 
@@ -544,7 +544,7 @@ __device__ __forceinline__ void small_obs_body(const typename Env::args& a, cons
       }
     }
   }
-  __syncthreads();
+  bsx_final_barrier();
   bsx_flush_counts(a.ctl, s_cnt, block_id);
 }
 
@@ -594,7 +594,7 @@ __global__ void __launch_bounds__(BSX_BLOCK) small_obs_eager2_kernel(const typen
     }
     bsx_count_types(a.ctl, type[h], s_cnt);
   }
-  __syncthreads();
+  bsx_final_barrier();
   bsx_flush_counts(a.ctl, s_cnt, blockIdx.x);
 }
 

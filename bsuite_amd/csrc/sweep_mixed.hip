@@ -93,7 +93,7 @@ __device__ __forceinline__ void sweep_phase0_body(const uint8_t* __restrict__ ta
   // Every workgroup read the call counter when it started; the one that retires last moves it on.
   // Two-level ticket (64 shards, one 128-byte line each, then one word): several thousand arrivals on ONE
   // word would serialise at ~12 ns each (the lesson of the episode counters, bsx_device.h).
-  __syncthreads();
+  bsx_final_barrier();
   // (No fence: a workgroup's reads of the counter completed before its barrier, and a release fence here
   // would write back this XCD's whole L2 once per workgroup — measured 165 us instead of 25.)
   if (threadIdx.x == 0 && counter != nullptr) {
