@@ -237,6 +237,19 @@ __device__ __forceinline__ void bsx_count_types(const bsx_ctl& c, int type, unsi
   }
 }
 
+// Measurement builds only (-DBSX_TRACE_LIFE, tools/sweep_phase0_trace.py --life): thread 0 of every workgroup of the
+// sweep's phase 0 stamps the wall clock at up to 8 points of its life into bsx_life_trace_ptr[8 * blockIdx.x + k].
+#ifdef BSX_TRACE_LIFE
+static __device__ uint64_t* bsx_life_trace_ptr;
+#define BSX_LIFE(k) do { if (threadIdx.x == 0 && bsx_life_trace_ptr != nullptr) bsx_life_trace_ptr[8 * (size_t)blockIdx.x + (k)] = wall_clock64(); } while (0)
+#define BSX_LIFE_AFTER_V(k, v) do { asm volatile("" :: "v"(v)); BSX_LIFE(k); } while (0)
+#define BSX_LIFE_AFTER_S(k, v) do { asm volatile("" :: "s"(v)); BSX_LIFE(k); } while (0)
+#else
+#define BSX_LIFE(k) do {} while (0)
+#define BSX_LIFE_AFTER_V(k, v) do {} while (0)
+#define BSX_LIFE_AFTER_S(k, v) do {} while (0)
+#endif
+
 // The LAST barrier of a workgroup, in front of bsx_flush_counts: it has to order the waves' LDS counter updates and
 // nothing else.  __syncthreads() is a fence + barrier, and on gfx9 its release half waits for vmcnt(0) — every wave
 // sat through the acknowledgements of its final stores (1-3 us behind a saturated memory system) before it could
@@ -338,16 +351,21 @@ __device__ __forceinline__ void bsx_advance_body(const typename Fam::args& a, ui
     const uint64_t lane = a.ctl.lane_offset + (uint64_t)i;
     const uint64_t step = bsx_step_of(a.ctl);
     int32_t nst; double reward;
+    BSX_LIFE_AFTER_S(2, (uint32_t)step);                    // the argument slot and the call counter have arrived
     const int act = a.ctl.force_reset ? 0 : bsx_action(a.ctl, a.action, i, step);
     const int32_t st = a.ctl.state_in != nullptr ? a.ctl.state_in[i] : a.state[i];
+    BSX_LIFE_AFTER_V(3, st + act);                              // ... the lane's state and action
     type = bsx_fam_advance<Fam, LEAN, MT == 0>(a, s_fam, i, lane, step, st, act, nst, reward);
+    BSX_LIFE_AFTER_V(4, nst);                                   // ... computed
     a.state[i] = nst;
     if (s_state != nullptr) s_state[threadIdx.x] = nst;     // fused small-batch step: the tile streamer reads it from LDS
     if (LEAN) bsx_emit_at<0, 0, false>(a.ctl, a.out, i, i, lane, step, type, reward);
     else bsx_emit_at<-1, -1, true, MT>(a.ctl, a.out, i, i, lane, step, type, reward);
   }
+  BSX_LIFE(5);                                                  // stores issued
   bsx_count_types(a.ctl, type, s_cnt);
   bsx_final_barrier();
+  BSX_LIFE(6);
   bsx_flush_counts(a.ctl, s_cnt, block_id);
 }
 

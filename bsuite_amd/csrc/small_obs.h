@@ -451,7 +451,9 @@ __device__ __forceinline__ void small_obs_body(const typename Env::args& a, cons
       if (mine) {
         double reward = 0.0;
         float o[8];
+        BSX_LIFE_AFTER_S(2, (uint32_t)step0);                   // the argument slot and the call counter have arrived
         type = Env::template step<LOG, MT>(a, i, oi, lane, step0 + (uint64_t)t, o, reward);
+        BSX_LIFE_AFTER_V(4, type);                              // loads + arithmetic (+ the state stores issued)
         bsx_emit_at<LOG, NOISE, F64, MT>(a.ctl, a.out, i, oi, lane, step0 + (uint64_t)t, type, reward);
         // (row-per-lane stores also in a big launch: staging the rows like the fused rollout does left the eager step
         // where it was — 17.5 / 17.5 vs 18.0 / 17.4 us at 2^20 lanes — and cost 4 % at 2^18,
@@ -544,7 +546,9 @@ __device__ __forceinline__ void small_obs_body(const typename Env::args& a, cons
       }
     }
   }
+  BSX_LIFE(5);
   bsx_final_barrier();
+  BSX_LIFE(6);
   bsx_flush_counts(a.ctl, s_cnt, block_id);
 }
 

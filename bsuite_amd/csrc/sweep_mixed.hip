@@ -54,10 +54,12 @@ __device__ __forceinline__ void sweep_phase0_body(const uint8_t* __restrict__ ta
                                                   const uint32_t block, const uint32_t n_blocks, float* s_obs,
                                                   unsigned int* s_cnt, deep_sea_fam::shared& s_ds, catch_fam::shared& s_ca,
                                                   int32_t* s_tile_state) {
+  BSX_LIFE(0);
   const bsx_group_slot w = bsx_group_find(gi, (int)block);
   const int tag = w.tag >= 0 ? w.tag : tags[w.seg];  // uniform per workgroup
   const uint32_t blk = w.block;
   const uint8_t* slot = table + (size_t)w.seg * BSX_MIXED_ADV_STRIDE;
+  BSX_LIFE_AFTER_S(1, tag);                          // the map entry has arrived
 #define SWEEP_SMALL_CASE(FAM, ENV) \
   case FAM: small_obs_group_body<ENV, 0>(*reinterpret_cast<const ENV::args*>(slot), blk, s_obs, s_cnt); break;
   switch (tag) {
@@ -109,6 +111,7 @@ __device__ __forceinline__ void sweep_phase0_body(const uint8_t* __restrict__ ta
       }
     }
   }
+  BSX_LIFE(7);
 }
 
 __global__ void __launch_bounds__(BSX_BLOCK) sweep_phase0_kernel(
@@ -128,6 +131,12 @@ __global__ void __launch_bounds__(BSX_BLOCK) sweep_phase0_kernel(
 }
 
 int bsx_sweep_launch_phase0(bsx_group* g, hipStream_t st) {
+#ifdef BSX_TRACE_LIFE
+  {
+    uint64_t* life = g->trace != nullptr ? g->trace + 3 * (size_t)g->total_blocks : nullptr;   // bsx_group_trace: 11 words per workgroup
+    (void)hipMemcpyToSymbolAsync(HIP_SYMBOL(bsx_life_trace_ptr), &life, sizeof(life), 0, hipMemcpyHostToDevice, st);
+  }
+#endif
   sweep_phase0_kernel<<<dim3((unsigned)g->total_blocks), dim3(BSX_BLOCK), g->lds_bytes, st>>>(
       (const uint8_t*)g->d_args, g->d_tags, g->index1(), g->shared_counter, g->d_ticket, g->trace);
   return (int)hipGetLastError();

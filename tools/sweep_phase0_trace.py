@@ -24,6 +24,8 @@ def main():
   ap = argparse.ArgumentParser()
   ap.add_argument('--lanes', type=int, default=1 << 20)
   ap.add_argument('--out', default=os.path.join(ROOT, 'gpurun_out', 'sweep_phase0_trace.json'))
+  ap.add_argument('--life', action='store_true',
+                  help='a -DBSX_TRACE_LIFE build (BSX_NATIVE_LIB): 8 stamps inside every workgroup, medians per family')
   ap.add_argument('--phase0-only', action='store_true',
                   help='step only the lane-advance launch, back to back: no store stream in between to sweep the caches')
   args = ap.parse_args()
@@ -45,14 +47,15 @@ def main():
     one_step()
   torch.cuda.synchronize()
   n_blocks = sum((lanes + 255) // 256 for _, _, lanes in batch.segments)
-  buf = torch.zeros(3 * n_blocks, dtype=torch.int64, device='cuda')
+  buf = torch.zeros((11 if args.life else 3) * n_blocks, dtype=torch.int64, device='cuda')
   _native.check(_native.lib.bsx_group_trace(batch._groups[0], buf.data_ptr(), buf.numel()), 'bsx_group_trace')
   names = {v: k for k, v in _native.FAMILY_IDS.items()}
   summary = []
   for rep in range(3):
     one_step()
     torch.cuda.synchronize()
-    t = buf.cpu().numpy().reshape(-1, 3)
+    raw = buf.cpu().numpy()
+    t = raw[:3 * n_blocks].reshape(-1, 3)
     t0 = t[:, 0].min()
     start, end, tag = (t[:, 0] - t0) / 100.0, (t[:, 1] - t0) / 100.0, t[:, 2]      # us
     rec = {'rep': rep, 'workgroups': int(n_blocks), 'span_us': float(end.max()),
@@ -72,6 +75,18 @@ def main():
     rec['peak_resident_workgroups'] = peak
     hist = collections.Counter(int(s) for s in start)
     rec['starts_per_us'] = [hist.get(u, 0) for u in range(int(end.max()) + 1)]
+    if args.life:
+      # stamps: 0 entry, 1 map entry arrived, 2 argument slot + call counter arrived, 3 state + action arrived (advance
+      # bodies only), 4 computed, 5 stores issued, 6 past the final barrier, 7 past the retirement ticket
+      life = raw[3 * n_blocks:].reshape(-1, 8).astype(np.float64)
+      rec['life_stamps_us_median'] = {}
+      for fam in sorted(set(tag.tolist())):
+        m = tag == fam
+        rows = life[m]
+        base = rows[:, 0:1]
+        rel = np.where(rows > 0, (rows - base) / 100.0, np.nan)
+        rec['life_stamps_us_median'][names.get(int(fam), str(fam))] = [None if np.isnan(x) else round(float(x), 2) for x in np.nanmedian(rel, axis=0)]
+      print(json.dumps(rec['life_stamps_us_median']))
     summary.append(rec)
     print(json.dumps({k: v for k, v in rec.items() if k != 'starts_per_us'}))
     print('starts per us:', rec['starts_per_us'])
