@@ -16,6 +16,9 @@ from bsuite_amd import _native  # noqa: E402
 
 B, T = 1 << 20, 16
 STAGGER = '--stagger' in sys.argv
+PRE_STEPS = int(sys.argv[sys.argv.index('--pre-steps') + 1]) if '--pre-steps' in sys.argv else 0
+ROUNDTRIP = '--roundtrip' in sys.argv
+PERIOD = int(sys.argv[sys.argv.index('--period') + 1]) if '--period' in sys.argv else 0   # lanes at phases i % PERIOD (0: the episode length)
 OFFS = [int(x) for x in sys.argv[sys.argv.index('--offsets') + 1].split(',')] if '--offsets' in sys.argv else [0, 256, 1024, 4096, 4096 + 256, 65536, 65536 + 1024, (1 << 20) + 4096]
 
 
@@ -37,7 +40,11 @@ def run(bid, off):
   acts = torch.randint(0, env.action_spec().num_values, (32, B), dtype=torch.int32, device='cuda')
   if STAGGER:
     import bench                                                # lanes at staggered episode phases, as bench.py times them
-    bench.stagger_phases(env, acts, bench.WORKLOADS[bid.split('/')[0]][5])
+    bench.stagger_phases(env, acts, PERIOD if PERIOD else bench.WORKLOADS[bid.split('/')[0]][5])
+  for k in range(PRE_STEPS):                                    # eager step() calls before the rollouts
+    env.step(acts[k % 32])
+  if ROUNDTRIP:
+    raw.load_state_dict(raw.state_dict())
   acts = acts[:T].contiguous()
   env.rollout(acts)
   if off is not None:
