@@ -89,6 +89,23 @@ def test_lean_rollout_step_loops_reload_no_spilled_scalars():
     assert ki.loop_spill_reloads(text, min_depth=2) <= most, (name, ki.loop_spill_reloads(text, min_depth=2))
 
 
+def test_last_barrier_of_a_workgroup_does_not_wait_for_its_stores():
+  """bsx_final_barrier (csrc/bsx_device.h): the barrier in front of bsx_flush_counts orders the waves' LDS counter
+  updates only — `s_waitcnt lgkmcnt(0)` + `s_barrier` — where __syncthreads() made every wave sit through the
+  acknowledgements of its final stores (`s_waitcnt vmcnt(0)`) before it could retire."""
+  import kernel_isa as ki
+  for src, want in (('small_obs.hip', 'small_obs_kernel<mountain_car_env, false, 0, 0, 0, true>'),
+                    ('small_obs.hip', 'small_obs_kernel<cartpole_env, false, 0, 0, 0, true>'),
+                    ('deep_sea.hip', 'bsx_advance_kernel<deep_sea_fam, true>')):
+    name, text = ki.kernel_text(os.path.join(ROOT, 'bsuite_amd', 'csrc', src), want)
+    ins = [l.split(';')[0].strip() for l in text if l.strip() and not l.strip().startswith((';', '.'))]
+    bars = [k for k, l in enumerate(ins) if l.startswith('s_barrier')]
+    assert bars, name
+    last = bars[-1]
+    assert ins[last - 1].startswith('s_waitcnt') and 'lgkmcnt(0)' in ins[last - 1] and 'vmcnt' not in ins[last - 1], (name, ins[last - 3:last + 1])
+    assert any(l.startswith('global_store') for l in ins[:last]), name      # ... with stores issued before it
+
+
 def test_sweep_kernels_spill_nothing(kernels):
   """sweep_phase0_kernel spilled 157 scalar registers (sweep_pipelined_kernel 58) under the 80-SGPR cap that
   amdgpu_waves_per_eu(8) brings — the attribute held a kernel that compiled the MT19937-exact generators into every
