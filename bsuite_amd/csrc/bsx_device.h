@@ -338,13 +338,47 @@ __device__ __forceinline__ int bsx_fam_advance(const typename Fam::args& a, cons
 // launcher picks it when the call has none of them).
 // MT = 0 (with LEAN = false): a wrapped call on the counter-based stream — the MT19937-exact generators of the
 // environment and of RewardNoise are compiled out (the whole-sweep group, which holds no MT19937-exact segment).
-template <class Fam, bool LEAN = false, int MT = -1>
+// LPT = 2: TWO lanes per thread — lanes b*512 + t and b*512 + 256 + t, the loads of both issued before the first use:
+// half as many workgroups, i.e. ONE dispatch round at 2^20 lanes instead of two.
+template <class Fam, bool LEAN = false, int MT = -1, int LPT = 1>
 __device__ __forceinline__ void bsx_advance_body(const typename Fam::args& a, uint32_t block_id,
                                                  typename Fam::shared& s_fam, unsigned int* s_cnt,
                                                  int32_t* s_state = nullptr) {
   if (threadIdx.x < 2) s_cnt[threadIdx.x] = 0;
   Fam::stage(a, s_fam);
   __syncthreads();
+  if constexpr (LPT == 2) {
+    const uint64_t step = bsx_step_of(a.ctl);
+    int64_t i[2];
+    bool mine[2];
+    int act[2], type[2] = {-1, -1};
+    int32_t st[2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      i[h] = (int64_t)block_id * (2 * BSX_BLOCK) + h * BSX_BLOCK + threadIdx.x;
+      mine[h] = i[h] < a.ctl.n_lanes;
+      act[h] = 0; st[h] = 0;
+      if (mine[h]) {
+        if (!a.ctl.force_reset) act[h] = bsx_action(a.ctl, a.action, i[h], step);
+        st[h] = a.ctl.state_in != nullptr ? a.ctl.state_in[i[h]] : a.state[i[h]];
+      }
+    }
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      if (mine[h]) {
+        const uint64_t lane = a.ctl.lane_offset + (uint64_t)i[h];
+        int32_t nst; double reward;
+        type[h] = bsx_fam_advance<Fam, LEAN, MT == 0>(a, s_fam, i[h], lane, step, st[h], act[h], nst, reward);
+        a.state[i[h]] = nst;
+        if (LEAN) bsx_emit_at<0, 0, false>(a.ctl, a.out, i[h], i[h], lane, step, type[h], reward);
+        else bsx_emit_at<-1, -1, true, MT>(a.ctl, a.out, i[h], i[h], lane, step, type[h], reward);
+      }
+      bsx_count_types(a.ctl, type[h], s_cnt);
+    }
+    bsx_final_barrier();
+    bsx_flush_counts(a.ctl, s_cnt, block_id);
+    return;
+  }
   const int64_t i = (int64_t)block_id * BSX_BLOCK + threadIdx.x;
   int type = -1;
   if (i < a.ctl.n_lanes) {
@@ -374,6 +408,12 @@ __global__ void __launch_bounds__(BSX_BLOCK) bsx_advance_kernel(const typename F
   __shared__ typename Fam::shared s_fam;
   __shared__ unsigned int s_cnt[2];
   bsx_advance_body<Fam, LEAN>(a, blockIdx.x, s_fam, s_cnt);
+}
+template <class Fam>
+__global__ void __launch_bounds__(BSX_BLOCK) bsx_advance2_kernel(const typename Fam::args a) {     // two lanes per thread, lean
+  __shared__ typename Fam::shared s_fam;
+  __shared__ unsigned int s_cnt[2];
+  bsx_advance_body<Fam, true, -1, 2>(a, blockIdx.x, s_fam, s_cnt);
 }
 
 template <class Fam>

@@ -101,6 +101,14 @@ static inline int bsx_launch_advance(const typename Fam::args& a, hipStream_t st
   if (blocks > 0x7FFFFFFF) return BSX_EINVAL;
   static const int lean_env = bsx_env_int("BSX_ADVANCE_LEAN", 1);
   const bool lean = lean_env != 0 && bsx_ctl_lean(a.ctl);
+  // From two dispatch rounds of one-lane workgroups up (2^20 lanes): two lanes per thread, both lanes' loads issued up
+  // front — ONE round.  Same call (profiles/r04/ab_advance_two_lanes.log): catch/0 42.5 -> 41.6 us per step, deep_sea -0.5 us;
+  // equal at 2^19 lanes, 79.8 -> 78.8 at 2^21.  (0 = never)
+  static const int lpt2_min_blocks = bsx_env_int("BSX_ADVANCE_LPT2_MIN_BLOCKS", 4096);
+  if (lean && lpt2_min_blocks > 0 && blocks >= lpt2_min_blocks) {
+    bsx_advance2_kernel<Fam><<<dim3((unsigned)((blocks + 1) / 2)), dim3(BSX_BLOCK), 0, st>>>(a);
+    return 0;
+  }
   if (lean) bsx_advance_kernel<Fam, true><<<dim3((unsigned)blocks), dim3(BSX_BLOCK), 0, st>>>(a);
   else bsx_advance_kernel<Fam, false><<<dim3((unsigned)blocks), dim3(BSX_BLOCK), 0, st>>>(a);
   return 0;
