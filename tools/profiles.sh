@@ -20,8 +20,8 @@ timeout 300 python tools/kernel_stats.py $out/deep_sea_2p17_kernel_stats.csv -- 
 timeout 300 python tools/kernel_stats.py $out/catch_2p17_kernel_stats.csv -- --workload catch --lanes 131072 --steps 200 --warmup 20 $A > /dev/null 2>>$out/kernel_stats.err
 # HBM traffic (WRITE_SIZE / FETCH_SIZE, separate passes) of every BASELINE config
 pm() { timeout 240 python tools/pmc.py "$@" 2>&1 | tail -1; }
-pm traffic deep_sea $out/deep_sea_pmc_traffic.json --kernels "bsx_advance_kernel<deep_sea_fam" "bsx_hot_stream_kernel<deep_sea_hot" --alg-bytes $((3621*B)) -- --steps 20 --warmup 4 $A --workload deep_sea
-pm traffic catch $out/catch_pmc_traffic.json --kernels "bsx_advance_kernel<catch_fam" "bsx_hot_stream_kernel<catch_hot" --alg-bytes $((221*B)) -- --steps 20 --warmup 4 $A --workload catch
+pm traffic deep_sea $out/deep_sea_pmc_traffic.json --kernels "bsx_advance2_kernel<deep_sea_fam" "bsx_advance_kernel<deep_sea_fam" "bsx_hot_stream_kernel<deep_sea_hot" --alg-bytes $((3621*B)) -- --steps 20 --warmup 4 $A --workload deep_sea
+pm traffic catch $out/catch_pmc_traffic.json --kernels "bsx_advance2_kernel<catch_fam" "bsx_advance_kernel<catch_fam" "bsx_hot_stream_kernel<catch_hot" --alg-bytes $((221*B)) -- --steps 20 --warmup 4 $A --workload catch
 pm traffic cartpole $out/cartpole_pmc_traffic.json --kernels "small_obs_kernel<cartpole_env" --alg-bytes $((85*B)) -- --steps 20 --warmup 4 $A --workload cartpole
 # (mountain_car lock-step: staggering its 1001-call episodes is ~10^4 torch launches, minutes under a PMC pass; in 24
 #  calls no lane resets either way)
