@@ -90,7 +90,8 @@ class Call(ctypes.Structure):
               ('stream', Stream), ('wrap', RewardWrap), ('counters', ctypes.c_void_p),
               ('hip_stream', ctypes.c_void_p), ('logging', ctypes.POINTER(Logging)),
               ('obs_paint', ctypes.c_void_p), ('reward_f64', ctypes.c_void_p),
-              ('state_alt', ctypes.c_void_p), ('action_ring', ctypes.c_int32), ('flags', ctypes.c_int32)]
+              ('state_alt', ctypes.c_void_p), ('action_ring', ctypes.c_int32), ('flags', ctypes.c_int32),
+              ('row_scratch', ctypes.c_void_p)]
 
 
 class DeepSeaCfg(ctypes.Structure):
@@ -159,6 +160,7 @@ lib = _load()
 _P = ctypes.c_void_p
 _SIGS = {
     'bsx_abi_version': ([], ctypes.c_int),
+    'bsx_row_scratch_words': ([ctypes.c_int32, ctypes.c_int32], ctypes.c_int32),
     'bsx_strerror': ([ctypes.c_int], ctypes.c_char_p),
     'bsx_calib_fill': ([_P, ctypes.c_int64, ctypes.c_int32, _P], ctypes.c_int),
     'bsx_counter_add': ([_P, ctypes.c_uint64, _P], ctypes.c_int),
@@ -214,7 +216,7 @@ for _name, (_args, _res) in _SIGS.items():
   _fn.restype = _res
 if MISSING:
   raise NativeLibraryError(f'{SO_PATH} does not export {MISSING}; rebuild with `python -m bsuite_amd.build --force`')
-ABI_VERSION = 11
+ABI_VERSION = 12
 CALL_STATE_TAGGED = 1   # BSX_CALL_STATE_TAGGED
 if lib.bsx_abi_version() != ABI_VERSION:
   raise NativeLibraryError('ABI version mismatch between bsuite_amd/_native.py and libbsuite_amd.so')

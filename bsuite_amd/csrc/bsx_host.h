@@ -204,7 +204,10 @@ struct bsx_group {
   bool committed = false;
   // a two-kernel segment that has store-stream workgroups but one state column only: fine for {advance, stream} in
   // order, a race in the pipelined launch (the stream of step s would read the column the advance of s+1 writes)
-  bool stream_without_alt = false;
+  bool stream_without_alt = false;      // = any(needs_alt), evaluated at commit
+  std::vector<uint8_t> needs_alt;       // per segment (mixed groups)
+  std::vector<const void*> row_scratch; // per segment: the row scratch of a chain segment on the row path, else null
+  const bsx_group* pipelined_peer = nullptr;   // the group this one was last checked against (bsx_group_step_pipelined)
   // launch(g, phase, stream): phase 0 = the first kernel (the lane advance of a two-kernel family, or the
   // whole step of a small-observation group), phase 1 = the observation stream kernel of a two-kernel
   // family (depends on phase 0 of the same group only), phase < 0 = both in order.

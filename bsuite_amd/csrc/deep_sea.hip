@@ -172,10 +172,11 @@ extern "C" int bsx_deep_sea_step(const bsx_deep_sea_t* cfg, const bsx_call_t* ca
   // ... up to 2^18 lanes of N = 30 (BSX_DEEP_SEA_STEP1_MAX_MIB of observations per step): there the 12.5 us lane advance and
   // the launch gap it removes outweigh the transitions recomputed in every wave of the stream; at 2^20 lanes the
   // recomputation costs the stream 25-50 us (597 -> 622-648 us, profiles/r04/ab_deep_sea_single_launch.log) and the
-  // two launches stay.
+  // two launches stay.  (The kernel reads `action` as a plain [B] column: a call that walks an action ring takes the
+  // two-launch path, whose lane advance goes through bsx_action().)
   static const int step1_env = bsx_env_int("BSX_DEEP_SEA_STEP1", 1);
   static const int step1_max_mib = bsx_env_int("BSX_DEEP_SEA_STEP1_MAX_MIB", 1024);
-  if (step1_env != 0 && (int64_t)call->n_lanes * cells * 4 <= ((int64_t)step1_max_mib << 20) && (call->flags & BSX_CALL_STATE_TAGGED) && call->n_steps <= 1 && cfg->deterministic && bsx_ctl_lean(a.ctl) &&
+  if (step1_env != 0 && (int64_t)call->n_lanes * cells * 4 <= ((int64_t)step1_max_mib << 20) && (call->flags & BSX_CALL_STATE_TAGGED) && call->n_steps <= 1 && call->action_ring <= 1 && cfg->deterministic && bsx_ctl_lean(a.ctl) &&
       call->obs_paint == nullptr && (cells & 3u) == 0 && cells >= 3u * 256u) {
     constexpr int K = 4;
     const uint64_t total = (uint64_t)call->n_lanes * cells;

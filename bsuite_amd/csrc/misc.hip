@@ -10,7 +10,7 @@ extern "C" const char* bsx_strerror(int code) {
     case 0: return "ok";
     case BSX_EINVAL: return "invalid scalar argument";
     case BSX_ENULL: return "required pointer is NULL";
-    case BSX_EALIGN: return "observation buffer is not 16-byte aligned";
+    case BSX_EALIGN: return "observation buffer (or row scratch) is not 16-byte aligned";
     case BSX_ERANGE: return "parameter outside the supported range of this family";
     case BSX_EMODE: return "combination not available (randn in MT19937-exact mode; obs_paint with a rollout, a group or a family without a board)";
     case BSX_ENOMEM: return "host allocation failed";
@@ -165,6 +165,8 @@ static int group_commit(bsx_group* g) {
     rc = upload(map.data(), map.size() * sizeof(int2), (void**)(pass == 0 ? &g->d_map : &g->d_map2));
   }
   if (rc != 0) return rc;
+  g->stream_without_alt = false;
+  for (uint8_t f : g->needs_alt) g->stream_without_alt = g->stream_without_alt || f != 0;
   g->committed = true;
   return 0;
 }
@@ -190,6 +192,15 @@ extern "C" int bsx_group_step_pipelined(bsx_group_t* streams_of, bsx_group_t* ad
       streams_of->shared_counter != advances_of->shared_counter)
     return BSX_EINVAL;
   if (streams_of->stream_without_alt || advances_of->stream_without_alt) return BSX_EMODE;
+  if (streams_of->pipelined_peer != advances_of) {
+    // once per pairing: a chain segment on the row path must not share its row scratch between the two groups (the
+    // stream of step s would decode the rows the advance of step s+1 is writing)
+    const size_t n = streams_of->row_scratch.size() < advances_of->row_scratch.size() ? streams_of->row_scratch.size()
+                                                                                        : advances_of->row_scratch.size();
+    for (size_t i = 0; i < n; ++i)
+      if (streams_of->row_scratch[i] != nullptr && streams_of->row_scratch[i] == advances_of->row_scratch[i]) return BSX_EMODE;
+    streams_of->pipelined_peer = advances_of;
+  }
   return bsx_sweep_launch_pipelined(streams_of, advances_of, (hipStream_t)hip_stream);
 }
 

@@ -9,6 +9,7 @@
 #include "catch_fam.h"
 #include "deep_sea_fam.h"
 #include "mnist_fam.h"
+#include "row_stream.h"
 
 #define BSX_MIXED_ADV_STRIDE 1024      // phase-0 argument slot (advance args of a pair family, or a small family's args)
 #define BSX_MIXED_STR_STRIDE 1280      // phase-1 argument slot (observation stream args of a pair family)
@@ -29,7 +30,7 @@ int bsx_sweep_launch_phase0(bsx_group* g, hipStream_t st);
 int bsx_sweep_launch_pipelined(bsx_group* streams_of, bsx_group* advances_of, hipStream_t st);
 
 // One workgroup of the mixed observation store stream: `block` of the phase-1 grid runs its segment's
-// family stream body (deep_sea 4 x 4 KiB, catch 2 x 4 KiB, mnist 8 x 4 KiB runs per workgroup).
+// family stream body (deep_sea 4 x 4 KiB, catch 2 x 4 KiB, mnist 8 x 4 KiB, wide chain rows 2 x 4 KiB runs per workgroup).
 #ifndef PAIR_MNIST_K
 #define PAIR_MNIST_K 8
 #endif
@@ -57,6 +58,13 @@ __device__ __forceinline__ void pair_mixed_stream_body(const uint8_t* __restrict
       // barrier was not what holds the mnist half of the stream at 5.4 TB/s)
       mnist_observe_body<PAIR_MNIST_K, 3>(*reinterpret_cast<const mnist_observe_args*>(slot), w.block, s_lut);
 #endif
+      break;
+    // wide rows of the chains, left packed by phase 0 (whole-sweep groups; row_stream.h)
+    case BSX_FAM_MEMORY_CHAIN:
+      bsx_row_stream_body<memory_rows, BSX_ROW_STREAM_K>(*reinterpret_cast<const bsx_row_seg*>(slot), w.block);
+      break;
+    case BSX_FAM_UMBRELLA_CHAIN:
+      bsx_row_stream_body<umbrella_rows, BSX_ROW_STREAM_K>(*reinterpret_cast<const bsx_row_seg*>(slot), w.block);
       break;
     default: break;
   }

@@ -22,7 +22,8 @@
 static_assert(sizeof(deep_sea_fam::args) <= PAIR_ADV_STRIDE && sizeof(catch_fam::args) <= PAIR_ADV_STRIDE &&
               sizeof(mnist_args) <= PAIR_ADV_STRIDE, "advance argument struct exceeds the mixed-group slot");
 static_assert(sizeof(bsx_stream_seg<deep_sea_hot>) <= PAIR_STR_STRIDE && sizeof(bsx_stream_seg<catch_hot>) <= PAIR_STR_STRIDE &&
-              sizeof(mnist_observe_args) <= PAIR_STR_STRIDE, "stream argument struct exceeds the mixed-group slot");
+              sizeof(mnist_observe_args) <= PAIR_STR_STRIDE && sizeof(bsx_row_seg) <= PAIR_STR_STRIDE,
+              "stream argument struct exceeds the mixed-group slot");
 
 __global__ void __launch_bounds__(BSX_BLOCK) pair_mixed_advance_kernel(const uint8_t* __restrict__ table,
                                                                        const int32_t* __restrict__ family,
@@ -92,7 +93,13 @@ int bsx_mixed_put(bsx_group* g, int32_t family, int32_t index, const bsx_call_t*
   if (g->tags.empty()) g->tags.assign((size_t)g->n, -1);
   g->tags[index] = family;
   g->blocks[index] = (int32_t)blocks1; g->blocks2[index] = (int32_t)blocks2;
-  if (str != nullptr && blocks2 > 0 && call->state_alt == nullptr) g->stream_without_alt = true;
+  // (per segment, re-evaluated at every put and summed up at commit: ADVICE r04 — a segment set again WITH its second
+  // column no longer blocks the pipelined step.)  The chains' wide rows need no second column: each group of a
+  // pipelined pair brings its own row scratch (checked in bsx_group_step_pipelined).
+  const bool row_seg = family == BSX_FAM_MEMORY_CHAIN || family == BSX_FAM_UMBRELLA_CHAIN;
+  if (g->needs_alt.empty()) { g->needs_alt.assign((size_t)g->n, 0); g->row_scratch.assign((size_t)g->n, nullptr); }
+  g->needs_alt[index] = (str != nullptr && blocks2 > 0 && !row_seg && call->state_alt == nullptr) ? 1 : 0;
+  g->row_scratch[index] = (row_seg && str != nullptr) ? call->row_scratch : nullptr;
   if (lds > g->lds_bytes) g->lds_bytes = lds;
   g->is_set[index] = 1;
   g->launch = g->family == BSX_FAM_SWEEP_MIXED ? sweep_mixed_launch : pair_mixed_launch;

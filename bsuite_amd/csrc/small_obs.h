@@ -25,6 +25,7 @@
 #include "deep_sea_fam.h"
 #include "mnist_fam.h"
 #include "pair_mixed.h"
+#include "row_stream.h"
 
 // n_steps == 1 is env.step()/reset(); n_steps = T > 1 is the fused rollout: the same thread advances
 // its lane T times inside one launch (actions [T,B], outputs [T,B,...]); per-lane state columns are
@@ -49,11 +50,15 @@
 //           per chunk: profiles/r02/ab_packed_records_v*.log).  The HEAD floats stay in the lane's
 //           registers and overwrite their (zero) places in the tile after a second barrier.
 //           LDS per workgroup: 32*numel bytes per plane (<= 8 KiB).
+//   ROWS    the same wide rows when the call brings a scratch column (bsx_call_t.row_scratch, ABI v12) and is a single
+//           step: the lane's thread stores the row in PACKED form there — no LDS, no barrier — and a store stream
+//           decodes it into the observation array in a second launch (row_stream.h).
 // A lane's handle on the tile's bit planes.
 struct bsx_bit_sink {
   uint32_t* planes;        // LDS: PLANES x `stride` words
   int stride;              // words per plane = 8 * numel
   uint32_t base;           // flat bit index of the lane's element HEAD
+  static constexpr bool ALWAYS = false;    // the tile is zero-filled before every step: only non-zero words need a put
   // ORs bits [32k, 32k+n) of the lane's bit string (n in 1..32, the low n bits of w) into plane p
   __device__ __forceinline__ void put(int p, int k, uint32_t w, int n) const {
     uint32_t word, lo, hi;
@@ -406,10 +411,12 @@ __device__ __forceinline__ void small_obs_regs_rollout(const typename Env::args&
 
 // TABSEL: the register-resident families' table (cartpole's time fractions) is staged in LDS (1) or read from device
 // memory (0) — the launcher knows; -1 = both loops in the kernel, chosen per launch by table_fits().
-template <class Env, bool ROLLOUT, int LOG, int NOISE, int MT, bool DIRECT_ARG, bool BIG = false, int V = -1, int TABSEL = -1>
+template <class Env, bool ROLLOUT, int LOG, int NOISE, int MT, bool DIRECT_ARG, bool BIG = false, int V = -1, int TABSEL = -1,
+          bool ROWS_ARG = false>
 __device__ __forceinline__ void small_obs_body(const typename Env::args& a, const int n_steps_arg,
                                                const uint32_t block_id, float* s_obs, unsigned int* s_cnt) {
-  constexpr bool DIRECT = DIRECT_ARG || !Env::PACKED;
+  constexpr bool ROWS = ROWS_ARG && Env::PACKED && !ROLLOUT;         // wide rows, packed, into the call's row scratch
+  constexpr bool DIRECT = DIRECT_ARG || !Env::PACKED || ROWS;
   if constexpr (ROLLOUT && Env::HAS_REGS) {
     bsx_reset_pool* pool = nullptr;
     float* rows = nullptr;
@@ -452,7 +459,17 @@ __device__ __forceinline__ void small_obs_body(const typename Env::args& a, cons
         double reward = 0.0;
         float o[8];
         BSX_LIFE_AFTER_S(2, (uint32_t)step0);                   // the argument slot and the call counter have arrived
-        type = Env::template step<LOG, MT>(a, i, oi, lane, step0 + (uint64_t)t, o, reward);
+        if constexpr (ROWS) {
+          // the row leaves in packed form — HEAD floats + bit-plane words, <= 48 bytes — for the store stream of the
+          // next launch (row_stream.h); o[0 .. HEAD) are the HEAD floats
+          uint32_t* __restrict__ row = a.rows + (uint64_t)i * (uint32_t)a.row_words;
+          const bsx_row_sink sink{row + Env::HEAD, (uint32_t)a.row_w};
+          type = Env::template step<LOG, MT, true>(a, i, oi, lane, step0 + (uint64_t)t, o, reward, &sink);
+#pragma unroll
+          for (int k = 0; k < Env::HEAD; ++k) row[k] = __float_as_uint(o[k]);
+        } else {
+          type = Env::template step<LOG, MT>(a, i, oi, lane, step0 + (uint64_t)t, o, reward);
+        }
         BSX_LIFE_AFTER_V(4, type);                              // loads + arithmetic (+ the state stores issued)
         bsx_emit_at<LOG, NOISE, F64, MT>(a.ctl, a.out, i, oi, lane, step0 + (uint64_t)t, type, reward);
         // (row-per-lane stores also in a big launch: staging the rows like the fused rollout does left the eager step
@@ -460,7 +477,7 @@ __device__ __forceinline__ void small_obs_body(const typename Env::args& a, cons
         // profiles/r03/ab_eager_rows_via_lds.log: one memory round trip per launch bounds it, not the write requests;
         // pooled resets in the eager step: 17.6 -> 19.1-19.6 us, the barriers wait for the slowest wave's loads,
         // profiles/r03/ab_eager_pooled_resets.log)
-        small_obs_store_row(a.out.observation + oi * (int64_t)numel, o, numel);
+        if constexpr (!ROWS) small_obs_store_row(a.out.observation + oi * (int64_t)numel, o, numel);
       }
       bsx_count_types(a.ctl, type, s_cnt);
     } else {
@@ -552,11 +569,11 @@ __device__ __forceinline__ void small_obs_body(const typename Env::args& a, cons
   bsx_flush_counts(a.ctl, s_cnt, block_id);
 }
 
-template <class Env, bool ROLLOUT, int LOG, int NOISE, int MT, bool DIRECT>
+template <class Env, bool ROLLOUT, int LOG, int NOISE, int MT, bool DIRECT, bool ROWS = false>
 __global__ void __launch_bounds__(BSX_BLOCK) small_obs_kernel(const typename Env::args a, const int n_steps) {
   extern __shared__ __attribute__((aligned(16))) float s_obs[];
   __shared__ unsigned int s_cnt[2];
-  small_obs_body<Env, ROLLOUT, LOG, NOISE, MT, DIRECT>(a, n_steps, blockIdx.x, s_obs, s_cnt);
+  small_obs_body<Env, ROLLOUT, LOG, NOISE, MT, DIRECT, false, -1, -1, ROWS>(a, n_steps, blockIdx.x, s_obs, s_cnt);
 }
 
 // Eager step of a register-resident family, TWO lanes per thread (lean calls of 2^19+ lanes): thread t of workgroup b
@@ -624,6 +641,23 @@ static size_t small_obs_lds(const typename Env::args& a) {
     return bsx_small_direct_shape(a.obs_numel) ? 0 : (size_t)(Env::PLANES + 1) * a.obs_numel * (BSX_BLOCK / 32) * 4 + (size_t)(BSX_BLOCK * Env::HEAD + 8) * 4;
   else return 0;
 }
+// does a single-step call of this segment take the row path (packed rows into a.rows + the wide-row store stream)?
+template <class Env>
+static bool small_obs_rows(const typename Env::args& a) {
+  if constexpr (Env::PACKED) return a.rows != nullptr && !bsx_small_direct_shape(a.obs_numel);
+  else return false;
+}
+// the arguments of the wide-row store stream of a segment on the row path
+template <class Env>
+static bsx_row_seg small_obs_row_seg(const typename Env::args& a) {
+  bsx_row_seg g{};
+  if constexpr (Env::PACKED) {
+    g.obs = a.out.observation; g.rows = a.rows; g.n_lanes = a.ctl.n_lanes; g.numel = (uint32_t)a.obs_numel;
+    g.numel_magic = bsx_div_magic(g.numel); g.dv = bsx_make_div64(g.numel);
+    g.row_words = (uint32_t)a.row_words; g.w_words = (uint32_t)a.row_w;
+  }
+  return g;
+}
 // ... and of a fused rollout: the tables a register-resident family stages (cartpole: the time fractions)
 template <class Env>
 static size_t small_obs_rollout_lds(const typename Env::args& a) {
@@ -637,17 +671,25 @@ static size_t small_obs_rollout_lds(const typename Env::args& a) {
 // waits for (profiles/r02/sweep_phase0_trace.json).
 // MT = 0: the group holds no segment in MT19937-exact mode (the whole-sweep group refuses them, bsx_mixed_put): the
 // wrapped segments' bodies are compiled without the generator's twist and numpy's legacy samplers.
-template <class Env, bool D, int MT = -1>
+template <class Env, bool D, int MT = -1, bool ROWS = false>
 __device__ __forceinline__ void small_obs_group_body_d(const typename Env::args& a, const uint32_t blk, float* s_obs,
                                                        unsigned int* s_cnt) {
-  if (bsx_ctl_lean(a.ctl)) small_obs_body<Env, false, 0, 0, 0, D>(a, 1, blk, s_obs, s_cnt);
-  else small_obs_body<Env, false, -1, -1, MT, D>(a, 1, blk, s_obs, s_cnt);
+  if (bsx_ctl_lean(a.ctl)) small_obs_body<Env, false, 0, 0, 0, D, false, -1, -1, ROWS>(a, 1, blk, s_obs, s_cnt);
+  else small_obs_body<Env, false, -1, -1, MT, D, false, -1, -1, ROWS>(a, 1, blk, s_obs, s_cnt);
 }
-template <class Env, int MT = -1>
+// ROWS_OK: the launch is followed by the wide-row store stream (the whole-sweep group's phase 1): a segment that
+// brought a row scratch leaves its rows there, packed; everywhere else wide rows go through the LDS bit planes.
+template <class Env, int MT = -1, bool ROWS_OK = false>
 __device__ __forceinline__ void small_obs_group_body(const typename Env::args& a, const uint32_t blk, float* s_obs,
                                                      unsigned int* s_cnt) {
   if constexpr (Env::PACKED) {
     if (!bsx_small_direct_shape(a.obs_numel)) {                 // uniform per workgroup
+      if constexpr (ROWS_OK) {
+        if (a.rows != nullptr) {
+          small_obs_group_body_d<Env, true, MT, true>(a, blk, s_obs, s_cnt);
+          return;
+        }
+      }
       small_obs_group_body_d<Env, false, MT>(a, blk, s_obs, s_cnt);
       return;
     }
@@ -687,12 +729,21 @@ int bsx_small_mixed_launch(bsx_group* g, int phase, hipStream_t st);
 // Records one segment of a small-observation family in a group (of its own family, or mixed).
 template <class Env>
 static int small_obs_group_put(bsx_group* g, int32_t family, int32_t index, const bsx_call_t* call,
-                               const typename Env::args& a) {
+                               const typename Env::args& a_in) {
   static_assert(sizeof(typename Env::args) <= SMALL_MIXED_STRIDE, "argument struct exceeds the mixed-group slot");
+  typename Env::args a = a_in;
   const uint64_t nb = (uint64_t)(a.ctl.n_lanes + BSX_BLOCK - 1) / BSX_BLOCK;
+  if (g != nullptr && g->family == BSX_FAM_SWEEP_MIXED) {     // one segment of the whole-sweep group
+    if (small_obs_rows<Env>(a)) {
+      // wide rows with a row scratch: phase 0 leaves them packed, the phase-1 store stream writes the observations
+      const bsx_row_seg sg = small_obs_row_seg<Env>(a);
+      return bsx_mixed_put(g, family, index, call, &a, sizeof(a), &sg, sizeof(sg), nb,
+                           bsx_flat_blocks((uint64_t)a.ctl.n_lanes * sg.numel, BSX_ROW_STREAM_K), 0);
+    }
+    return bsx_mixed_put(g, family, index, call, &a, sizeof(a), nullptr, 0, nb, 0, small_obs_lds<Env>(a));   // phase 0 only
+  }
+  if constexpr (Env::PACKED) a.rows = nullptr;                // single-launch groups: the LDS bit planes
   const size_t lds = small_obs_lds<Env>(a);
-  if (g != nullptr && g->family == BSX_FAM_SWEEP_MIXED)       // one segment of the whole-sweep group: phase 0 only
-    return bsx_mixed_put(g, family, index, call, &a, sizeof(a), nullptr, 0, nb, 0, lds);
   const bool mixed = g != nullptr && g->family == BSX_FAM_SMALL_MIXED;
   int rc = bsx_group_check_set(g, mixed ? BSX_FAM_SMALL_MIXED : family, index, call,
                                mixed ? SMALL_MIXED_STRIDE : sizeof(typename Env::args), mixed ? sizeof(int32_t) : 0, BSX_BLOCK);
@@ -802,6 +853,22 @@ static int launch_small_obs(const typename Env::args& a, int n_steps, void* hip_
   }
   if constexpr (Env::PACKED) {
     if (!bsx_small_direct_shape(a.obs_numel)) {
+      if (n_steps == 1 && small_obs_rows<Env>(a)) {
+        // wide rows, a single step, a row scratch: lane advance (rows packed into the scratch) + the store stream
+        // that decodes them (row_stream.h) instead of the one launch with the LDS bit planes and its three barriers
+        if (lean) small_obs_kernel<Env, false, 0, 0, 0, true, true><<<g, b, 0, st>>>(a, 1);
+        else small_obs_kernel<Env, false, -1, -1, -1, true, true><<<g, b, 0, st>>>(a, 1);
+        const bsx_row_seg sg = small_obs_row_seg<Env>(a);
+        static const int row_k = bsx_env_int("BSX_ROW_STREAM_K", BSX_ROW_STREAM_K);
+        const int k = row_k == 1 || row_k == 4 ? row_k : 2;
+        const uint64_t sblocks = bsx_flat_blocks((uint64_t)a.ctl.n_lanes * sg.numel, k);
+        if (sblocks > 0x7FFFFFFFull) return BSX_EINVAL;
+        const dim3 gs((unsigned)sblocks);
+        if (k == 1) bsx_row_stream_kernel<typename Env::rows_t, 1><<<gs, b, 0, st>>>(sg);
+        else if (k == 4) bsx_row_stream_kernel<typename Env::rows_t, 4><<<gs, b, 0, st>>>(sg);
+        else bsx_row_stream_kernel<typename Env::rows_t, 2><<<gs, b, 0, st>>>(sg);
+        return bsx_launch_status();
+      }
       SMALL_OBS_LAUNCH(false)
       return bsx_launch_status();
     }
@@ -845,26 +912,28 @@ struct memory_chain_env {
   struct args {
     bsx_ctl ctl; const int32_t* action; int32_t* state; uint64_t* context; bsx_timestep_t out;
     double* info; int32_t obs_numel; int32_t L; int32_t nb; uint32_t numel_magic;
+    uint32_t* rows; int32_t row_words; int32_t row_w;          // bsx_call_t.row_scratch (row_stream.h), or nullptr
   };
   // Packed rows: HEAD = [time, query]; element 2+b is 0 unless t == 0, then +-1 by context bit b: plane 0 says
-  // "non-zero", plane 1 carries the context bit.
-  static constexpr int HEAD = 2, PLANES = 2;
-  __device__ static float decode(uint32_t nonzero, uint32_t bit) {       // integer selects: no branches
-    return __uint_as_float((0u - nonzero) & (0xBF800000u ^ (bit << 31)));
-  }
-  template <bool PACK>
-  __device__ static void observe(const args& a, float* o, int t, int query, uint64_t ctx, const bsx_bit_sink* sink) {
+  // "non-zero", plane 1 carries the context bit (memory_rows, row_stream.h).
+  typedef memory_rows rows_t;
+  static constexpr int HEAD = rows_t::HEAD, PLANES = rows_t::PLANES;
+  __device__ static float decode(uint32_t nonzero, uint32_t bit) { return rows_t::decode(nonzero, bit); }
+  template <bool PACK, class Sink>
+  __device__ static void observe(const args& a, float* o, int t, int query, uint64_t ctx, const Sink* sink) {
     BSX_NO_CONTRACT
     o[0] = (float)(1.0 - (double)t / (double)a.L);              // memory_chain.py:64
     o[1] = (t == a.L - 1) ? (float)query : 0.0f;                // :66-67
     if constexpr (PACK) {
-      if (t == 0) {                                             // :69-70
+      if (Sink::ALWAYS || t == 0) {                             // :69-70 (a row in device memory is written in full)
+        const uint32_t nz = t == 0 ? 0xFFFFFFFFu : 0u;
+        const uint64_t cx = t == 0 ? ctx : 0ull;
         const int n0 = a.nb < 32 ? a.nb : 32;
-        sink->put(0, 0, 0xFFFFFFFFu, n0);
-        sink->put(1, 0, (uint32_t)ctx, n0);
+        sink->put(0, 0, nz, n0);
+        sink->put(1, 0, (uint32_t)cx, n0);
         if (a.nb > 32) {
-          sink->put(0, 1, 0xFFFFFFFFu, a.nb - 32);
-          sink->put(1, 1, (uint32_t)(ctx >> 32), a.nb - 32);
+          sink->put(0, 1, nz, a.nb - 32);
+          sink->put(1, 1, (uint32_t)(cx >> 32), a.nb - 32);
         }
       }
     } else {
@@ -872,9 +941,9 @@ struct memory_chain_env {
         o[2 + b] = (t == 0) ? (float)(2 * (int)((ctx >> b) & 1ull) - 1) : 0.0f;
     }
   }
-  template <int LOG, int MT, bool PACK = false>
+  template <int LOG, int MT, bool PACK = false, class Sink = bsx_bit_sink>
   __device__ static int step(const args& a, int64_t i, int64_t oi, uint64_t lane, uint64_t step, float* o, double& reward,
-                             const bsx_bit_sink* sink = nullptr) {
+                             const Sink* sink = nullptr) {
     int32_t st = a.state[i];
     int t = st & 0xFFFFF, query = (st >> 20) & 0xFF;
     uint64_t ctx = a.context[i];
@@ -919,12 +988,14 @@ struct umbrella_chain_env {
   struct args {
     bsx_ctl ctl; const int32_t* action; int32_t* state; bsx_timestep_t out; double* info;
     int32_t obs_numel; int32_t L; int32_t nd; uint32_t numel_magic;
+    uint32_t* rows; int32_t row_words; int32_t row_w;          // bsx_call_t.row_scratch (row_stream.h), or nullptr
   };
-  // Packed rows: HEAD = [need, has, time]; element 3+b is distractor bit b as 0.0 / 1.0 (one plane).
-  static constexpr int HEAD = 3, PLANES = 1;
-  __device__ static float decode(uint32_t bit, uint32_t) { return __uint_as_float((0u - bit) & 0x3F800000u); }
-  template <bool PACK, int MT>
-  __device__ static void observe(const args& a, float* o, int t, int need, int has, bsx_draws* d, const bsx_bit_sink* sink) {
+  // Packed rows: HEAD = [need, has, time]; element 3+b is distractor bit b as 0.0 / 1.0 (one plane; umbrella_rows).
+  typedef umbrella_rows rows_t;
+  static constexpr int HEAD = rows_t::HEAD, PLANES = rows_t::PLANES;
+  __device__ static float decode(uint32_t bit, uint32_t) { return rows_t::decode(bit, 0u); }
+  template <bool PACK, int MT, class Sink>
+  __device__ static void observe(const args& a, float* o, int t, int need, int has, bsx_draws* d, const Sink* sink) {
     BSX_NO_CONTRACT
     o[0] = (float)need;                                         // umbrella_chain.py:62
     o[1] = (float)has;                                          // :63
@@ -950,9 +1021,9 @@ struct umbrella_chain_env {
       for (int b = 0; b < a.nd; ++b) o[3 + b] = (float)bsx_bern_vec_bit(d, b, &w);   // :65 BernVec(nd)
     }
   }
-  template <int LOG, int MT, bool PACK = false>
+  template <int LOG, int MT, bool PACK = false, class Sink = bsx_bit_sink>
   __device__ static int step(const args& a, int64_t i, int64_t oi, uint64_t lane, uint64_t step, float* o, double& reward,
-                             const bsx_bit_sink* sink = nullptr) {
+                             const Sink* sink = nullptr) {
     BSX_NO_CONTRACT
     int32_t st = a.state[i];
     int t = st & 0xFFFFF, need = (st >> 20) & 1, has = (st >> 21) & 1;

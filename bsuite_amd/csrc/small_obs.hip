@@ -14,6 +14,27 @@
 // caller that buckets segments by class keeps working).
 extern "C" int bsx_group_small_class(int32_t numel) { (void)numel; return BSX_BLOCK; }
 
+// Words per lane of bsx_call_t.row_scratch (row_stream.h): 0 = no row path for this family / row length.
+extern "C" int32_t bsx_row_scratch_words(int32_t family, int32_t obs_numel) {
+  if (obs_numel < 1 || obs_numel > 256 || bsx_small_direct_shape(obs_numel)) return 0;
+  if (family == BSX_FAM_MEMORY_CHAIN) return bsx_row_words_of(obs_numel, BSX_ROWS_MEMORY);
+  if (family == BSX_FAM_UMBRELLA_CHAIN) return bsx_row_words_of(obs_numel, BSX_ROWS_UMBRELLA);
+  return 0;
+}
+
+// The row path of a chain segment: the call's scratch, if it brings one and the row is wide.
+template <class Env>
+static int chain_rows(const bsx_call_t* call, int32_t family, typename Env::args* a) {
+  a->rows = nullptr; a->row_words = 0; a->row_w = 0;
+  const int32_t words = bsx_row_scratch_words(family, a->obs_numel);
+  if (call->row_scratch == nullptr || words == 0) return 0;
+  if ((reinterpret_cast<uintptr_t>(call->row_scratch) & 15u) != 0) return BSX_EALIGN;
+  if (call->n_lanes * (int64_t)words >= ((int64_t)1 << 40)) return BSX_EINVAL;
+  a->rows = (uint32_t*)call->row_scratch; a->row_words = words;
+  a->row_w = bsx_row_plane_words(a->obs_numel, Env::rows_t::KIND);
+  return 0;
+}
+
 // ------------------------------------------------------------------------------ bandit
 static int bandit_make(const bsx_bandit_t* cfg, const bsx_call_t* call, const int32_t* action, int32_t* state, bsx_timestep_t out, double* info, bandit_env::args* a) {
   if (cfg == nullptr) return BSX_ENULL;
@@ -55,7 +76,7 @@ static int memory_chain_make(const bsx_memory_chain_t* cfg, const bsx_call_t* ca
   a->ctl = bsx_make_ctl(call); a->action = action; a->state = state; a->context = context; a->out = out;
   a->info = info; a->obs_numel = cfg->num_bits + 2; a->L = cfg->memory_length; a->nb = cfg->num_bits;
   a->numel_magic = bsx_div_magic((uint32_t)a->obs_numel);
-  return 0;
+  return chain_rows<memory_chain_env>(call, BSX_FAM_MEMORY_CHAIN, a);
 }
 
 extern "C" int bsx_memory_chain_step(const bsx_memory_chain_t* cfg, const bsx_call_t* call, const int32_t* action, int32_t* state, uint64_t* context, bsx_timestep_t out, double* info) {
@@ -86,7 +107,7 @@ static int umbrella_chain_make(const bsx_umbrella_chain_t* cfg, const bsx_call_t
   a->ctl = bsx_make_ctl(call); a->action = action; a->state = state; a->out = out; a->info = info;
   a->obs_numel = 3 + cfg->n_distractor; a->L = cfg->chain_length; a->nd = cfg->n_distractor;
   a->numel_magic = bsx_div_magic((uint32_t)a->obs_numel);
-  return 0;
+  return chain_rows<umbrella_chain_env>(call, BSX_FAM_UMBRELLA_CHAIN, a);
 }
 
 extern "C" int bsx_umbrella_chain_step(const bsx_umbrella_chain_t* cfg, const bsx_call_t* call, const int32_t* action, int32_t* state, bsx_timestep_t out, double* info) {

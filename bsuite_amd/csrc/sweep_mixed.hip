@@ -39,7 +39,8 @@ int bsx_small_mixed_launch(bsx_group* g, int phase, hipStream_t st) {
 // ------------------------------------------------------------------------------ whole-sweep group, phase 0
 // BSX_FAM_SWEEP_MIXED: ONE launch advances every lane of a heterogeneous sweep — the lane-advance of
 // deep_sea / catch / mnist segments (whose observation stream follows as phase 1, pair_mixed.hip) and the
-// complete step of every small-observation segment.  All of this is latency-bound work that moves a
+// complete step of every small-observation segment — except that a memory_chain / umbrella_chain segment with a wide
+// row and a row scratch (ABI v12) only leaves its rows PACKED here; phase 1 decodes them (row_stream.h).  All of this is latency-bound work that moves a
 // few percent of the sweep's bytes; as separate launches (advance, two small-family groups, counter
 // bump) it cost ~45 us of a ~185 us sweep step whether serialised or spread over HIP
 // streams (cross-queue waits cost ~10 us each; kernels sharing the machine with the store stream
@@ -61,7 +62,7 @@ __device__ __forceinline__ void sweep_phase0_body(const uint8_t* __restrict__ ta
   const uint8_t* slot = table + (size_t)w.seg * BSX_MIXED_ADV_STRIDE;
   BSX_LIFE_AFTER_S(1, tag);                          // the map entry has arrived
 #define SWEEP_SMALL_CASE(FAM, ENV) \
-  case FAM: small_obs_group_body<ENV, 0>(*reinterpret_cast<const ENV::args*>(slot), blk, s_obs, s_cnt); break;
+  case FAM: small_obs_group_body<ENV, 0, true>(*reinterpret_cast<const ENV::args*>(slot), blk, s_obs, s_cnt); break;
   switch (tag) {
     case BSX_FAM_DEEP_SEA: {
       const deep_sea_fam::args& a = *reinterpret_cast<const deep_sea_fam::args*>(slot);

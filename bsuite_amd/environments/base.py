@@ -64,6 +64,12 @@ class Environment(dm_env.EnvironmentBase):
   _state_alt = None
   scalar_host_buffers = True   # scalar view: TimeStep / action buffers in pinned host memory mapped into the device (class
                                # attribute: set False before the first step to A/B against device buffers + read-backs)
+  # memory_chain / umbrella_chain with a row of more than 8 floats: from this many bytes of observations per step() a call
+  # brings a row scratch (bsx_call_t.row_scratch) and is lane advance + store stream instead of the one launch that builds
+  # the rows in LDS (csrc/row_stream.h); below it the second launch costs more than the barriers it removes.  Segments of
+  # a whole-sweep group always bring one (their store stream is the group's).
+  row_path_min_bytes = 8 << 20
+  _rows = None
   _info_keys = ()          # names of the f64 info columns, in native column order
   _info_int_keys = ()      # keys the reference reports as Python ints
 
@@ -190,12 +196,14 @@ class Environment(dm_env.EnvironmentBase):
     return getattr(_native.lib, f'bsx_{self._abi_name}_step')(*self._native_args(call, action_ptr, out))
 
   def _group_set(self, group, index: int, action: torch.Tensor, *, out=None, state_alt=None,
-                 swap_state: bool = False) -> int:
+                 swap_state: bool = False, row_scratch=None) -> int:
     """Records this environment as segment `index` of a grouped launch (bsx_group_set_<family>):
     static arguments — `action` is read in place every group step, outputs go to buffer 0 (or to `out`, a
     dict of reward / discount / step_type / observation tensors), the call index comes from the (shared)
     device step counter.  `action` is int32 [B], or an action RING [R, B] with R a power of two: group step s
-    then reads row s mod R (bsx_call_t.action_ring) — pre-generated random actions that change every step.  `state_alt` (two-kernel families, pipelined sweeps): the lane advance reads that
+    then reads row s mod R (bsx_call_t.action_ring) — pre-generated random actions that change every step.  `row_scratch`
+    (memory_chain / umbrella_chain with wide rows, whole-sweep groups): the segment leaves its rows packed there and the
+    group's store stream decodes them.  `state_alt` (two-kernel families, pipelined sweeps): the lane advance reads that
     column and writes the environment's own; with `swap_state` the roles are exchanged."""
     self._ensure_allocated()
     ring = int(action.shape[0]) if (torch.is_tensor(action) and action.dim() == 2) else 0
@@ -220,6 +228,9 @@ class Environment(dm_env.EnvironmentBase):
     ptrs = self._out_ptrs[0] if out is None else _native.TimeStepPtrs(
         out['reward'].data_ptr(), out['discount'].data_ptr(), out['step_type'].data_ptr(), out['observation'].data_ptr())
     own = self._state.get('state')
+    own_rows = call.row_scratch
+    if row_scratch is not None:                # whole-sweep groups: the chains' wide rows go through the group's store stream
+      call.row_scratch = row_scratch.data_ptr() if row_scratch is not False else None
     try:
       if state_alt is not None:
         if swap_state:
@@ -231,8 +242,28 @@ class Environment(dm_env.EnvironmentBase):
     finally:
       call.state_alt = None
       call.action_ring = 0
+      call.row_scratch = own_rows
       if state_alt is not None:
         self._state['state'] = own
+
+  def _row_scratch_words(self) -> int:
+    """uint32 words per lane of this family's row scratch (bsx_row_scratch_words), 0 = the family has no row path."""
+    fam = _native.FAMILY_IDS.get(self._abi_name, -1)
+    return int(_native.lib.bsx_row_scratch_words(fam, int(np.prod(self._obs_shape)))) if fam >= 0 else 0
+
+  def _row_scratch(self, fresh: bool = False) -> Optional[torch.Tensor]:
+    """The row scratch of this environment (allocated on first use; contents are irrelevant between calls), or a
+    second one (`fresh`: the other group of a pipelined pair must not share it); None for a family without row path."""
+    words = self._row_scratch_words()
+    if not words:
+      return None
+    if fresh or self._rows is None:
+      with torch.cuda.device(self._device):
+        t = torch.empty(self._batch * words, dtype=torch.int32, device=self._device)
+      if fresh:
+        return t
+      self._rows = t
+    return self._rows
 
   def _set_wrap_mt_seeds(self, seeds):
     """rng='mt19937': RewardNoise's own np.random.RandomState(seed) per lane (wrappers.py:267)."""
@@ -330,6 +361,9 @@ class Environment(dm_env.EnvironmentBase):
         counters=self._counters.data_ptr(), hip_stream=None)
     if self._reward_f64 is not None:
       self._call_desc.reward_f64 = self._reward_f64.data_ptr()
+    if (not self._scalar and self._row_scratch_words()
+        and B * int(np.prod(self._obs_shape)) * 4 >= self.row_path_min_bytes):
+      self._call_desc.row_scratch = self._row_scratch().data_ptr()
     if self._wrap_mt_seeds is not None:
       self._upload_wrap_mt()
     # The host side of a step() call is part of the hot path: the tiny families' kernels run 5-7 us at 2^20

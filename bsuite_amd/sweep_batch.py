@@ -161,7 +161,8 @@ class SweepBatch:
 
   # -- grouped launches --------------------------------------------------------------------
   def prepare_groups(self, actions: Sequence[torch.Tensor], mix_small: bool = True, mix_pairs: bool = True,
-                     mix_all: bool = True, pipelined: bool = False, heavy_first: bool = True):
+                     mix_all: bool = True, pipelined: bool = False, heavy_first: bool = True,
+                     rows_in_stream: bool = True):
     """Builds the launch groups.  With `mix_all` (default) ONE group for the whole sweep
     (BSX_FAM_SWEEP_MIXED): a sweep step is two launches — phase 0 advances every lane of every family
     and bumps the shared call counter, phase 1 is the observation store stream of the two-kernel
@@ -172,6 +173,10 @@ class SweepBatch:
     all small-observation families together (BSX_FAM_SMALL_MIXED), else one per family.  Records every local segment with its static `actions` tensor and uploads the
     argument tables.  Returns the per-segment output TimeSteps (tensors that every `step_grouped()`
     overwrites).
+
+    `rows_in_stream` (with `mix_all`; False: A/B): the wide rows of memory_chain / umbrella_chain segments are left
+    packed by phase 0 and written by the phase-1 store stream (bsx_call_t.row_scratch) instead of being built as bit
+    planes in LDS by phase 0 itself.
 
     `pipelined` (with `mix_all`): the sweep's actions are static, so sweep step s+1 does not need the
     observations of step s — ONE launch per step then carries the observation store stream of step s
@@ -204,6 +209,7 @@ class SweepBatch:
     outs = [None] * len(self.envs)
     outs_of = [outs, [None] * len(self.envs)]
     self._state_alt = {}
+    self._row_scratch = {}
     costs = []
     for (name, _), members in sorted(buckets.items()):
       if name == 'sweep_mixed' and heavy_first:
@@ -236,6 +242,18 @@ class SweepBatch:
               if k not in self._state_alt:
                 self._state_alt[k] = raw._state['state'].clone()  # pylint: disable=protected-access
               extra = dict(state_alt=self._state_alt[k], swap_state=(parity == 1))
+          if name == 'sweep_mixed' and rows_in_stream:
+            # memory_chain / umbrella_chain with a wide row: phase 0 leaves the row packed in a scratch and the group's
+            # store stream writes the observation (csrc/row_stream.h); the groups of a pipelined pair bring one each
+            key = (k, parity)
+            if key not in self._row_scratch:
+              rs = raw._row_scratch(fresh=(parity == 1))  # pylint: disable=protected-access
+              self._row_scratch[key] = rs
+            if self._row_scratch[key] is not None:
+              extra['row_scratch'] = self._row_scratch[key]
+          elif name == 'sweep_mixed':
+            extra['row_scratch'] = False             # (A/B: not even the scratch a large segment steps with on its own)
+          if pipelined:
             if parity == 1:
               o = dict(reward=torch.empty_like(o['reward']), discount=torch.empty_like(o['discount']),
                        step_type=torch.empty_like(o['step_type']),

@@ -194,7 +194,7 @@ class Logging(_RewardWrapper):
   def check_overflow(self):
     """Raises as soon as some lane has logged more rows than its buffer holds (one 4-byte device-to-host read).  The
     batched row buffer is sized for the log points within 100 x bsuite_num_episodes episodes (enable_logging); a run
-    beyond that horizon keeps counting rows but stores no more of them — call this (or flush(), or counters()) now
+    beyond that horizon keeps counting rows but stores no more of them — call this (or flush(), or counters(check=True)) now
     and then rather than learning it from rows() after the run; Logging(..., max_rows=...) sizes the buffer."""
     cap = self._lg['rows'].shape[1]
     worst = int(self._lg['n_rows'].max().item())
@@ -275,10 +275,13 @@ class Logging(_RewardWrapper):
     import pandas as pd  # pylint: disable=import-outside-toplevel
     return pd.DataFrame(self.rows(lane))
 
-  def counters(self) -> Dict[str, Any]:
-    """The live per-lane accumulators as device tensors [B] (steps, episode, total_return, ...); raises if a lane's
-    row buffer has overflowed (check_overflow)."""
-    self.check_overflow()
+  def counters(self, check: bool = False) -> Dict[str, Any]:
+    """The live per-lane accumulators as device tensors [B] (steps, episode, total_return, ...).  Never synchronises
+    with the host (and is safe inside a HIP-graph capture) unless `check=True`, which first raises if a lane's row
+    buffer has overflowed (check_overflow: one device-to-host read); `overflowed()` is the same fact as a device
+    tensor."""
+    if check:
+      self.check_overflow()
     return {k: self._lg[k] for k in ('steps', 'episode', 'total_return', 'episode_len', 'episode_return')}
 
 

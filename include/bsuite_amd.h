@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define BSX_ABI_VERSION 11
+#define BSX_ABI_VERSION 12
 
 #define BSX_FIRST 0
 #define BSX_MID 1
@@ -189,6 +189,18 @@ typedef struct {
                                fresh actions with no host work) and captured hipGraphs.  Not a power of two:
                                BSX_EINVAL; with n_steps > 1 or obs_paint: BSX_EMODE.                 */
   int32_t flags;            /* BSX_CALL_* bits (ABI v11; was padding, 0 = the v10 behaviour)                  */
+  void* row_scratch;        /* device or NULL (ABI v12), memory_chain / umbrella_chain with an observation row of more
+                               than 8 floats: n_lanes x bsx_row_scratch_words(family, obs_numel) uint32, 16-byte
+                               aligned, contents irrelevant between calls.  With it a single step()/reset() call is
+                               lane advance + store stream, like deep_sea / catch: every lane's thread leaves its row
+                               PACKED in the scratch (the HEAD floats + one or two bit planes, <= 48 bytes) and a
+                               barrier-free store stream decodes it into `out.observation` (csrc/row_stream.h) — at
+                               2^20 lanes faster than the one launch that builds the rows as bit planes in LDS
+                               (three workgroup barriers per step), which NULL selects and which rollouts
+                               (n_steps > 1) always take.  In a BSX_FAM_SWEEP_MIXED group such a segment's rows are
+                               decoded by the phase-1 store stream; the two groups of a pipelined pair must bring
+                               DIFFERENT scratches (bsx_group_step_pipelined: BSX_EMODE); the single-launch groups
+                               ignore it.  Ignored by the other families and by short rows.                     */
 } bsx_call_t;
 
 /* bsx_call_t.flags */
@@ -257,7 +269,7 @@ typedef struct {
 /* state: int32 [B] = timestep | query<<20 | reset_next<<28 (initialise to 1<<28)
  * context: uint64 [B] (bit i = context[i])
  * info : double [2,B] = total_perfect, total_regret (memory_chain.py:108-112)
- * obs  : float [B, 1, nb+2] */
+ * obs  : float [B, 1, nb+2]; nb > 6: see bsx_call_t.row_scratch */
 int bsx_memory_chain_step(const bsx_memory_chain_t* cfg, const bsx_call_t* call,
                           const int32_t* action, int32_t* state, uint64_t* context,
                           bsx_timestep_t out, double* info);
@@ -268,7 +280,7 @@ typedef struct {
   int32_t n_distractor;   /* nd (umbrella_chain.py:39); 0..253 */
 } bsx_umbrella_chain_t;
 /* state: int32 [B] = timestep | need<<20 | has<<21 | reset_next<<22 (initialise to 1<<22)
- * info : double [1,B] = total_regret; obs float [B, 1, 3+nd] */
+ * info : double [1,B] = total_regret; obs float [B, 1, 3+nd]; nd > 5: see bsx_call_t.row_scratch */
 int bsx_umbrella_chain_step(const bsx_umbrella_chain_t* cfg, const bsx_call_t* call,
                             const int32_t* action, int32_t* state, bsx_timestep_t out,
                             double* info);
@@ -471,6 +483,10 @@ int bsx_image_observation(const bsx_image_t* cfg, int64_t n_lanes, const float* 
 
 /* ---- misc ---------------------------------------------------------------------------------- */
 int bsx_abi_version(void);
+/* uint32 words per lane of bsx_call_t.row_scratch for a `family` (BSX_FAM_*) observation row of `obs_numel` floats:
+ * HEAD floats + bit-plane words, rounded up to 4 (memory_chain: 2 + 2*ceil(nb/32); umbrella_chain: 3 + ceil(nd/32));
+ * 0 = this family / row length has no row path (the scratch would be ignored). */
+int32_t bsx_row_scratch_words(int32_t family, int32_t obs_numel);
 const char* bsx_strerror(int code);
 /* Pure-store calibration: writes n_bytes of zeros with the same 16-B cooperative pattern the
  * observation writers use; the measured rate is the practical ceiling for store-bound families. */

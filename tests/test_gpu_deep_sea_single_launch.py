@@ -151,3 +151,68 @@ def test_neighbours_of_the_single_launch_path(kw, wrap):
   info = env.bsuite_info()
   for k, v in orc.bsuite_info().items():
     np.testing.assert_array_equal(info[k].cpu().numpy(), v, err_msg=k)
+
+
+def test_action_ring_with_tagged_states_takes_the_two_launch_path():
+  """the single-launch kernel reads `action` as a plain [B] column, so a TAGGED call that walks an action
+  ring (C-ABI callers, captured graphs) must not take it: row (call index mod R) of the ring is what every lane acts on."""
+  kw = dict(size=30, mapping_seed=42)
+  B, R, seed = 2500, 4, 8
+  env = eu.make_env('deep_sea', kw, batch=B, lane_offset=0, seed=seed)
+  orc = coracle.OracleEnv('deep_sea', kw, np.arange(B, dtype=np.uint64), seed=seed)
+  g = torch.Generator(device='cuda'); g.manual_seed(5)
+  ring = torch.randint(2, (R, B), generator=g, device='cuda', dtype=torch.int32)
+  ring_np = ring.cpu().numpy()
+  raw = eu.raw(env)
+  raw._ensure_allocated()
+  assert raw._call_desc.flags == 1
+  raw._call_desc.action_ring = R
+  try:
+    for t in range(2 * 30 + 5):
+      b = raw._call(ring.data_ptr(), False)                        # host call index t -> row t mod R
+      _check(raw._wrap_output(b), orc.call(ring_np[t % R], t), f'ring t={t}')
+  finally:
+    raw._call_desc.action_ring = 0
+
+
+def test_tag_flag_is_only_set_when_call_indices_are_consecutive():
+  """a graph captured with the HOST call count replays one index over and over, and a segment of a shared
+  counter may be stepped twice between bumps — neither may take the single-launch step, whose readers would take an
+  already-tagged word for an already-advanced one."""
+  import bsuite_amd
+  B = 3000
+  shared = torch.zeros(1, dtype=torch.int64, device='cuda')
+  seg = bsuite_amd.load_from_id('deep_sea/10', batch=B, seed=5, shared_step_counter=shared)
+  ref = bsuite_amd.load_from_id('deep_sea/10', batch=B, seed=5)
+  g = torch.Generator(device='cuda'); g.manual_seed(3)
+  acts = torch.randint(2, (40, B), generator=g, device='cuda', dtype=torch.int32)
+  for t in range(6):                                               # the counter is never bumped: every call repeats index 0
+    x, y = seg.step(acts[t]), ref.step(acts[t])
+    for u, v in zip(eu.to_np(x), eu.to_np(y)):
+      np.testing.assert_array_equal(u, v, err_msg=f'shared counter t={t}')
+  assert eu.raw(seg)._call_desc.flags == 0
+  # host count + capture: the captured call is the two-launch step; eager calls before and after stay single-launch
+  env = bsuite_amd.load_from_id('deep_sea/10', batch=B, seed=5, num_buffers=1)
+  ref = bsuite_amd.load_from_id('deep_sea/10', batch=B, seed=5, num_buffers=1)
+  static = acts[0].clone()
+  env.step(static); ref.step(acts[0])
+  assert eu.raw(env)._call_desc.flags == 1
+  side = torch.cuda.Stream()
+  side.wait_stream(torch.cuda.current_stream())
+  graph = torch.cuda.CUDAGraph()
+  with torch.cuda.stream(side):
+    with torch.cuda.graph(graph, stream=side):
+      out = env.step(static)
+  torch.cuda.current_stream().wait_stream(side)
+  for rep in range(1, 36):                                         # across an episode end
+    static.copy_(acts[rep])
+    graph.replay()
+    want = ref.step(acts[rep])
+    torch.cuda.synchronize()
+    for u, v in zip(eu.to_np(out), eu.to_np(want)):
+      np.testing.assert_array_equal(u, v, err_msg=f'replay {rep}')
+  for t in range(36, 40):                                          # eager again: tagged, single launch
+    x, y = env.step(acts[t]), ref.step(acts[t])
+    assert eu.raw(env)._call_desc.flags == 1
+    for u, v in zip(eu.to_np(x), eu.to_np(y)):
+      np.testing.assert_array_equal(u, v, err_msg=f'eager after replays t={t}')

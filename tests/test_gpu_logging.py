@@ -117,6 +117,11 @@ def test_by_step_logging_rows_fit_and_overflow_is_loud():
     small.rows(0)
   with pytest.raises(RuntimeError):
     small.all_rows()
+  assert set(small.counters()) >= {'steps', 'episode'}          # live tensors: no host read, no raise
+  with pytest.raises(RuntimeError):
+    small.counters(check=True)
+  with pytest.raises(RuntimeError):
+    small.flush()
 
 
 def test_state_dict_carries_logging_and_wrapper_state():
