@@ -25,6 +25,20 @@
 #define BSX_FABSF(x) fabsf(x)
 #endif
 
+/* np.float32(np.int8(b)) / np.float32(255) — a pixel of the MNIST bandit's observation (bsuite/utils/datasets.py:55-56 parses
+ * the idx bytes as int8, mnist.py:64 divides by 255 in f32) — correctly rounded, without a table and without a division:
+ * q = x * RN(1/255), then one Newton step on the exact remainder (two fused multiply-adds).  Equal to the IEEE division
+ * for all 256 bytes (tests/test_physics_math.py, against numpy), so a 16-byte chunk of the observation stream is four
+ * {v_bfe_i32, v_cvt, 3 VALU} instead of four LDS reads behind a table fill and a workgroup barrier.
+ * four_pixels: one aligned dword of the image table; k = 0..3: which byte. */
+BSX_HD float bsx_mnist_pixel_value(uint32_t four_pixels, int k) {
+  const float x = (float)((int32_t)(four_pixels << (24 - 8 * k)) >> 24);
+  const float r = 0x1.010102p-8f;                                  /* RN(1/255) = 0x3b808081 */
+  const float q = x * r;
+  const float e = BSX_FMAF(-q, 255.0f, x);
+  return BSX_FMAF(e, r, q);
+}
+
 #define BSX_SINCOS_MAX_ARG 64.0f   /* beyond this callers must use the library routines */
 
 /* sin and cos of x for |x| <= BSX_SINCOS_MAX_ARG.

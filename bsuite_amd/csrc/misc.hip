@@ -52,6 +52,46 @@ extern "C" int bsx_counter_add(uint64_t* counter, uint64_t delta, void* hip_stre
   return bsx_launch_status();
 }
 
+// bsuite_info() for callers of the C ABI: the columns as the reference would report them right now.  catch counts its
+// misses in spare bits of the packed state word and cartpole / mountain_car fold exact per-episode sums into their columns
+// only when an episode ends (include/bsuite_amd.h, each family's "Accounting" note): this adds the part that is still
+// pending in the lane's state — what the Python classes' bsuite_info() does on the host side of the boundary.
+//   bsuite/environments/catch.py:116-117, cartpole.py:179-181, mountain_car.py:99-100
+__global__ void __launch_bounds__(BSX_BLOCK) bsuite_info_kernel(int32_t family, int32_t variant, int64_t n_lanes,
+                                                                const int32_t* __restrict__ state,
+                                                                const double* __restrict__ info, int32_t n_info,
+                                                                int32_t folded, double* __restrict__ out) {
+  const int64_t i = (int64_t)blockIdx.x * BSX_BLOCK + threadIdx.x;
+  if (i >= n_lanes) return;
+  double pend0 = 0.0, pend2 = 0.0;
+  if (folded) {
+    if (family == BSX_FAM_CATCH) {
+      pend0 = 2.0 * (double)(((uint32_t)state[i] >> 25) & 0x7Fu);          // a miss costs regret 2 (catch.py:92-94)
+    } else if ((family == BSX_FAM_CARTPOLE && variant == 0) || family == BSX_FAM_MOUNTAIN_CAR) {
+      const int32_t sk = state[i];                                         // steps = k | reset_next << 30
+      const double k = (sk >> 30) & 1 ? 0.0 : (double)(sk & 0x3FFFFFFF);   // the running episode has paid k rewards of +1 / -1
+      pend0 = family == BSX_FAM_CARTPOLE ? k : -k;
+      pend2 = family == BSX_FAM_CARTPOLE ? k : 0.0;                        // (cartpole's internal episode_return column)
+    }
+  }
+  for (int c = 0; c < n_info; ++c)
+    out[(int64_t)c * n_lanes + i] = info[(int64_t)c * n_lanes + i] + (c == 0 ? pend0 : c == 2 ? pend2 : 0.0);
+}
+
+extern "C" int bsx_bsuite_info(int32_t family, int32_t variant, int64_t n_lanes, const int32_t* state, const double* info,
+                               int32_t n_info, int32_t folded, double* info_out, void* hip_stream) {
+  if (family < BSX_FAM_DEEP_SEA || family > BSX_FAM_MNIST || n_lanes < 0 || n_info < 0 || n_info > 8) return BSX_EINVAL;
+  if (n_lanes == 0 || n_info == 0) return 0;
+  if (info == nullptr || info_out == nullptr) return BSX_ENULL;
+  const bool pending = folded && (family == BSX_FAM_CATCH || (family == BSX_FAM_CARTPOLE && variant == 0) || family == BSX_FAM_MOUNTAIN_CAR);
+  if (pending && state == nullptr) return BSX_ENULL;
+  const int64_t blocks = (n_lanes + BSX_BLOCK - 1) / BSX_BLOCK;
+  if (blocks > 0x7FFFFFFF) return BSX_EINVAL;
+  bsuite_info_kernel<<<dim3((unsigned)blocks), dim3(BSX_BLOCK), 0, (hipStream_t)hip_stream>>>(
+      family, variant, n_lanes, state, info, n_info, pending ? 1 : 0, info_out);
+  return bsx_launch_status();
+}
+
 __global__ void __launch_bounds__(BSX_BLOCK) stream_dump_kernel(uint64_t seed, uint64_t lane0, int64_t n_lanes,
                                                                 uint64_t step, uint32_t stream_id, int n_words,
                                                                 uint32_t* words, double* normals) {

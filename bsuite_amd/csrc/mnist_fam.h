@@ -5,6 +5,7 @@
 #define BSX_MNIST_FAM_H_
 
 #include "bsx_device.h"
+#include "bsx_math.h"
 
 struct mnist_args {
   bsx_ctl ctl;
@@ -64,6 +65,8 @@ struct mnist_observe_args {
   uint32_t cells;
   uint32_t cells_magic;
   bsx_div64 dv;
+  int32_t arith;          // the LUT is exactly np.float32(int8) / 255 (mnist_make checks all 256 entries): compute it
+  int32_t _pad;
   float lut[256];
 };
 
@@ -77,10 +80,11 @@ struct mnist_observe_args {
 // loads (r03: the mnist half of the sweep's stream ran at 5.0-5.2 TB/s even then, WAIT_ANY 68 % of the wave cycles:
 // the LUT load + barrier in front of every workgroup's stores, profiles/r03/stream_mnist_pmc_sq.json).
 #define MNIST_LUT_FLOATS (256 * (BSX_BLOCK / BSX_WAVE))
+// bit 3 = no LUT at all: the pixel values are computed (mnist_pixel_value) — no LDS, no barrier.
 template <int K, int VAR>
 __device__ __forceinline__ void mnist_observe_body(const mnist_observe_args& a, uint32_t block_id, float* s_lut) {
   if (VAR & 4) s_lut += (threadIdx.x >> 6) * 256;          // this wave's copy
-  if (!(VAR & 1) && !(VAR & 4)) {
+  if (!(VAR & 1) && !(VAR & 4) && !(VAR & 8)) {
     s_lut[threadIdx.x] = a.lut[threadIdx.x];
     __syncthreads();
   }
@@ -110,7 +114,8 @@ __device__ __forceinline__ void mnist_observe_body(const mnist_observe_args& a, 
         px[u] = *reinterpret_cast<const uint32_t*>(a.images + (uint64_t)(s & 0x00FFFFFF) * cells + r0);
     }
   }
-  if (VAR & 4) {
+  if (VAR & 8) {
+  } else if (VAR & 4) {
     bool any_show = false;
 #pragma unroll
     for (int u = 0; u < K; ++u) any_show |= show[u];
@@ -132,7 +137,8 @@ __device__ __forceinline__ void mnist_observe_body(const mnist_observe_args& a, 
     bsx_f4 v = {0.f, 0.f, 0.f, 0.f};                            // mnist.py:73 zeros after the guess
     if (show[u]) {                                              // mnist.py:64 astype(f32) / 255
       const uint32_t p = px[u];
-      v.x = s_lut[p & 0xFF]; v.y = s_lut[(p >> 8) & 0xFF]; v.z = s_lut[(p >> 16) & 0xFF]; v.w = s_lut[p >> 24];
+      if (VAR & 8) { v.x = bsx_mnist_pixel_value(p, 0); v.y = bsx_mnist_pixel_value(p, 1); v.z = bsx_mnist_pixel_value(p, 2); v.w = bsx_mnist_pixel_value(p, 3); }
+      else { v.x = s_lut[p & 0xFF]; v.y = s_lut[(p >> 8) & 0xFF]; v.z = s_lut[(p >> 16) & 0xFF]; v.w = s_lut[p >> 24]; }
     }
     o4[c] = v;
   }

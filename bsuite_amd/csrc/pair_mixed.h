@@ -56,7 +56,10 @@ __device__ __forceinline__ void pair_mixed_stream_body(const uint8_t* __restrict
       // (variant 7 — no workgroup barrier, a per-wave LUT copy filled only when the wave shows an image — measured the
       // same as 3: sweep step 165.8-166.1 vs 164.2-166.2 us, profiles/r04/ab_sweep_mnist_stream_no_barrier.log; the
       // barrier was not what holds the mnist half of the stream at 5.4 TB/s)
-      mnist_observe_body<PAIR_MNIST_K, 3>(*reinterpret_cast<const mnist_observe_args*>(slot), w.block, s_lut);
+      if (reinterpret_cast<const mnist_observe_args*>(slot)->arith)     // uniform: the reference's table, computed (no LDS, no barrier)
+        mnist_observe_body<PAIR_MNIST_K, 3 | 8>(*reinterpret_cast<const mnist_observe_args*>(slot), w.block, s_lut);
+      else
+        mnist_observe_body<PAIR_MNIST_K, 3>(*reinterpret_cast<const mnist_observe_args*>(slot), w.block, s_lut);
 #endif
       break;
     // wide rows of the chains, left packed by phase 0 (whole-sweep groups; row_stream.h)

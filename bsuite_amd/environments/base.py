@@ -647,14 +647,21 @@ class Environment(dm_env.EnvironmentBase):
     """Subclass hook: called once `_pending_info()` has been added to the columns (enable_logging), for families
     that keep the pending amount in state bits of their own (catch) rather than deriving it from a step counter."""
 
+  _info_pending_column = None   # subclass: the state column that carries the not-yet-folded part of an info column
+  _info_variant = 0             # subclass: bsx_bsuite_info's `variant` (cartpole: 1 = swing-up)
+
   def _info_columns(self) -> torch.Tensor:
-    """The f64 [K, B] bsuite_info accumulators as the reference would report them right now."""
-    pending = {} if self._logging is not None else self._pending_info()
-    if not pending:
+    """The f64 [K, B] bsuite_info accumulators as the reference would report them right now: the columns themselves,
+    or — families that fold part of an accumulator lazily (catch, cartpole, mountain_car; never under Logging) — a
+    fresh tensor from bsx_bsuite_info, the C ABI's form of this method."""
+    if self._logging is not None or self._info_pending_column is None:
       return self._info
-    cols = self._info.clone()
-    for j, p in pending.items():
-      cols[j] += p
+    cols = torch.empty_like(self._info)
+    with torch.cuda.device(self._device):
+      _native.check(_native.lib.bsx_bsuite_info(
+          _native.FAMILY_IDS[self._abi_name], self._info_variant, self._batch,
+          self._state[self._info_pending_column].data_ptr(), self._info.data_ptr(), self._info.shape[0], 1,
+          cols.data_ptr(), torch.cuda.current_stream(self._device).cuda_stream), 'bsx_bsuite_info')
     return cols
 
   def bsuite_info(self) -> Dict[str, Any]:

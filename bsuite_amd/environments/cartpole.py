@@ -83,6 +83,7 @@ class Cartpole(_CartpoleBase):
   """Classic cart-pole balancing task, 6-d observation (cartpole.py:68-116)."""
 
   _info_keys = ('raw_return', 'best_episode', '_episode_return', '_total_upright')
+  _info_pending_column = 'steps'            # raw_return / episode_return of the running episode (bsx_bsuite_info)
 
   def _pending_info(self):
     # Rewards are 1 on every step that does not end the episode (cartpole.py:142-149), so a running
@@ -109,6 +110,7 @@ class CartpoleSwingup(_CartpoleBase):
   """Swing-up variant with a move cost, 8-d observation (cartpole_swingup.py:30-78)."""
 
   _info_keys = ('raw_return', 'best_episode', '_episode_return', 'total_upright')
+  _info_variant = 1                         # accumulates per step like the reference: nothing pending
 
   def __init__(self,
                height_threshold: float = 0.5,

@@ -17,6 +17,7 @@ class Catch(base.Environment):
   """Falling-ball / paddle grid; observation is the rows x columns board (catch.py:30-66)."""
 
   _info_keys = ('total_regret',)
+  _info_pending_column = 'state'            # misses counted in the state word (bsx_bsuite_info)
 
   def __init__(self, rows: int = 10, columns: int = 5, seed: Optional[int] = None,
                **engine_kwargs):

@@ -14,6 +14,7 @@ class MountainCar(base.Environment):
   """Mountain Car, an underpowered car must power up a hill (mountain_car.py:29-57)."""
 
   _info_keys = ('raw_return',)
+  _info_pending_column = 'steps'            # the running episode's -t (bsx_bsuite_info)
 
   def __init__(self, max_steps: int = 1000, seed: Optional[int] = None, **engine_kwargs):
     if max_steps < 1:

@@ -245,7 +245,7 @@ typedef struct {
  * info : double [1,B] = total_regret (catch.py:116-117).  Accounting (ABI v10): with call->logging the column is
  *        updated at every episode end like the reference.  Without it the lane counts its misses (regret 2 each, a
  *        catch costs 0: catch.py:92-94) in bits 25..31 of the state word and adds 2*127 to the column once per 127
- *        misses: the reference's value is  info[0][i] + 2 * ((uint32_t)state[i] >> 25).
+ *        misses: the reference's value is  info[0][i] + 2 * ((uint32_t)state[i] >> 25)  (bsx_bsuite_info computes it).
  * obs  : float [B, rows, columns] */
 int bsx_catch_step(const bsx_catch_t* cfg, const bsx_call_t* call, const int32_t* action,
                    int32_t* state, bsx_timestep_t out, double* info);
@@ -320,7 +320,7 @@ typedef struct {
  * them per step like the reference.  Classic cartpole without logging (rewards are 0/1, so an episode
  * of k steps returns exactly (k-1) + its last reward) folds raw_return and best_episode into the
  * columns when an episode ENDS and leaves episode_return untouched: mid-episode the reference's
- * raw_return is  info[0][i] + (steps[i] >> 30 ? 0 : steps[i] & 0x3FFFFFFF). */
+ * raw_return is  info[0][i] + (steps[i] >> 30 ? 0 : steps[i] & 0x3FFFFFFF)  (bsx_bsuite_info computes it). */
 int bsx_cartpole_step(const bsx_cartpole_t* cfg, const bsx_call_t* call, const int32_t* action,
                       float* state, int32_t* steps, bsx_timestep_t out, double* info);
 
@@ -333,7 +333,7 @@ typedef struct {
  * info double [1,B] = raw_return; obs float [B,1,3].
  * Every step pays -1: without call->logging raw_return is folded into the column when an episode
  * ENDS (ABI v8); mid-episode the reference's value is
- * info[0][i] - (steps[i] >> 30 ? 0 : steps[i] & 0x3FFFFFFF).  With call->logging it is per step. */
+ * info[0][i] - (steps[i] >> 30 ? 0 : steps[i] & 0x3FFFFFFF)  (bsx_bsuite_info computes it).  With call->logging it is per step. */
 int bsx_mountain_car_step(const bsx_mountain_car_t* cfg, const bsx_call_t* call,
                           const int32_t* action, float* state, int32_t* steps,
                           bsx_timestep_t out, double* info);
@@ -483,6 +483,16 @@ int bsx_image_observation(const bsx_image_t* cfg, int64_t n_lanes, const float* 
 
 /* ---- misc ---------------------------------------------------------------------------------- */
 int bsx_abi_version(void);
+/* bsuite_info() through the C ABI (v12): info_out [n_info, B] = the family's info columns as the REFERENCE would report
+ * them right now (catch.py:116-117 total_regret, cartpole.py:179-181 raw_return / best_episode, mountain_car.py:99-100
+ * raw_return, ...).  Without call->logging some families keep part of an accumulator in their state word until it is
+ * cheap to fold (see each family's accounting note above): `folded` != 0 says the columns were maintained that way and
+ * the pending part is added from `state` — catch: the packed state column; cartpole (variant 0; swing-up, variant 1,
+ * accumulates per step) and mountain_car: the `steps` column; every other family (and folded == 0, i.e. columns kept
+ * under call->logging): a plain copy, `state` may be NULL.  Cartpole's column 2 is its internal running
+ * episode_return.  Asynchronous on hip_stream like every entry point; info_out may not alias info. */
+int bsx_bsuite_info(int32_t family, int32_t variant, int64_t n_lanes, const int32_t* state, const double* info,
+                    int32_t n_info, int32_t folded, double* info_out, void* hip_stream);
 /* uint32 words per lane of bsx_call_t.row_scratch for a `family` (BSX_FAM_*) observation row of `obs_numel` floats:
  * HEAD floats + bit-plane words, rounded up to 4 (memory_chain: 2 + 2*ceil(nb/32); umbrella_chain: 3 + ceil(nd/32));
  * 0 = this family / row length has no row path (the scratch would be ignored). */

@@ -97,7 +97,61 @@ int main(void) {
     EXPECT(bsx_deep_sea_step(NULL, &call, d_action, d_state, out, d_info) == BSX_ENULL);
     call.n_lanes = -3;
     EXPECT(bsx_deep_sea_step(&cfg, &call, d_action, d_state, out, d_info) == BSX_EINVAL);
+    call.n_lanes = B;
   }
-  printf("abi_host_demo: ok (%d lanes x %d calls of deep_sea N=%d through the C ABI)\n", B, N + 2, N);
+  /* catch (bsuite/environments/catch.py:68-117): the paddle never moves (action 1 = stay, :27), so a lane's total_regret
+   * is 2 x the episodes whose ball did not fall on the centre column — counted here from the rewards — and
+   * bsx_bsuite_info() must report exactly that although the library keeps the misses in spare bits of the state word
+   * and folds them into the f64 column only once per 127 (the header's accounting note). */
+  {
+    enum { ROWS = 10, COLS = 5, CALLS = 10 * 200 };           /* 200 episodes: every lane misses more than 127 times */
+    bsx_catch_t ccfg = {ROWS, COLS};
+    float* d_cobs; double *d_cinfo, *d_cinfo_out;
+    static double h_cinfo[B], h_cinfo_out[B], want[B];
+    static int32_t h_state[B];
+    CHECK_HIP(hipMalloc((void**)&d_cobs, (size_t)B * ROWS * COLS * sizeof(float)));
+    CHECK_HIP(hipMalloc((void**)&d_cinfo, B * sizeof(double)));
+    CHECK_HIP(hipMalloc((void**)&d_cinfo_out, B * sizeof(double)));
+    CHECK_HIP(hipMemset(d_cinfo, 0, B * sizeof(double)));
+    for (int i = 0; i < B; ++i) { h_i32[i] = 1 << 24; want[i] = 0.0; }     /* reset_next (base.py:52) */
+    CHECK_HIP(hipMemcpy(d_state, h_i32, sizeof h_i32, hipMemcpyHostToDevice));
+    for (int i = 0; i < B; ++i) h_i32[i] = 1;                               /* "stay" */
+    CHECK_HIP(hipMemcpy(d_action, h_i32, sizeof h_i32, hipMemcpyHostToDevice));
+    call.n_lanes = B; call.stream.seed = 7;
+    bsx_timestep_t cout = {d_reward, d_discount, d_type, d_cobs};
+    int t, i = -1;
+    for (t = 0; t < CALLS; ++t) {
+      call.stream.step_index = (uint64_t)t;
+      CHECK_BSX(bsx_catch_step(&ccfg, &call, d_action, d_state, cout, d_cinfo));
+      if (t % 10 == 9) {                                                     /* the call that ends every lane's episode */
+        CHECK_HIP(hipMemcpy(h_reward, d_reward, sizeof h_reward, hipMemcpyDeviceToHost));
+        CHECK_HIP(hipMemcpy(h_type, d_type, sizeof h_type, hipMemcpyDeviceToHost));
+        for (i = 0; i < B; ++i) { EXPECT(h_type[i] == BSX_LAST); EXPECT(h_reward[i] == 1.0f || h_reward[i] == -1.0f); want[i] += 1.0 - (double)h_reward[i]; }
+      }
+    }
+    CHECK_BSX(bsx_bsuite_info(BSX_FAM_CATCH, 0, B, d_state, d_cinfo, 1, 1, d_cinfo_out, NULL));
+    CHECK_HIP(hipDeviceSynchronize());
+    CHECK_HIP(hipMemcpy(h_cinfo, d_cinfo, sizeof h_cinfo, hipMemcpyDeviceToHost));
+    CHECK_HIP(hipMemcpy(h_cinfo_out, d_cinfo_out, sizeof h_cinfo_out, hipMemcpyDeviceToHost));
+    CHECK_HIP(hipMemcpy(h_state, d_state, sizeof h_state, hipMemcpyDeviceToHost));
+    int folded_lanes = 0, misses = 0;
+    for (i = 0; i < B; ++i) {
+      EXPECT(h_cinfo_out[i] == want[i]);                                      /* the reference's total_regret (:116-117) */
+      EXPECT(h_cinfo[i] + 2.0 * (double)(((uint32_t)h_state[i]) >> 25) == want[i]);   /* the documented identity */
+      folded_lanes += h_cinfo[i] != 0.0;
+      misses += (int)(want[i] / 2.0);
+    }
+    EXPECT(folded_lanes > B / 2);                                             /* lanes crossed 127 misses: both parts were exercised */
+    EXPECT(misses > 150 * B && misses < 170 * B);                             /* ~4/5 of 200 episodes miss with the paddle at rest */
+    /* a plain copy where nothing is pending (deep_sea), and the argument checks */
+    CHECK_BSX(bsx_bsuite_info(BSX_FAM_DEEP_SEA, 0, B, NULL, d_info, 1, 1, d_cinfo_out, NULL));
+    CHECK_HIP(hipDeviceSynchronize());
+    CHECK_HIP(hipMemcpy(h_cinfo_out, d_cinfo_out, sizeof h_cinfo_out, hipMemcpyDeviceToHost));
+    for (i = 0; i < B; ++i) EXPECT(h_cinfo_out[i] == h_info[i]);
+    EXPECT(bsx_bsuite_info(BSX_FAM_CATCH, 0, B, NULL, d_cinfo, 1, 1, d_cinfo_out, NULL) == BSX_ENULL);
+    EXPECT(bsx_bsuite_info(99, 0, B, d_state, d_cinfo, 1, 1, d_cinfo_out, NULL) == BSX_EINVAL);
+    EXPECT(bsx_row_scratch_words(BSX_FAM_UMBRELLA_CHAIN, 23) == 4 && bsx_row_scratch_words(BSX_FAM_CATCH, 50) == 0);
+  }
+  printf("abi_host_demo: ok (%d lanes x %d calls of deep_sea N=%d, catch total_regret via bsx_bsuite_info, through the C ABI)\n", B, N + 2, N);
   return 0;
 }

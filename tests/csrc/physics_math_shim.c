@@ -15,3 +15,9 @@ void shim_sincos_advance(const float* t, const float* d, int64_t n, float* s, fl
     bsx_sincos_advance(s0, c0, d[i], &s[i], &c[i]);
   }
 }
+
+/* the MNIST bandit's pixel value for every byte b = 0..255, in each of the four byte positions of a dword */
+void shim_mnist_pixels(float* out /* [4][256] */) {
+  for (int k = 0; k < 4; ++k)
+    for (uint32_t b = 0; b < 256u; ++b) out[k * 256 + b] = bsx_mnist_pixel_value((b << (8 * k)) | (0xA5A5A5A5u & ~(0xFFu << (8 * k))), k);
+}

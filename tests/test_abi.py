@@ -43,7 +43,7 @@ int main(void) {
          offsetof(bsx_cartpole_t, move_cost), offsetof(bsx_cartpole_t, time_frac),
          sizeof(bsx_logging_t), sizeof(bsx_mnist_t), offsetof(bsx_call_t, logging),
          offsetof(bsx_stream_t, mt_pos), offsetof(bsx_logging_t, log_by_step));
-  printf("%zu\n", offsetof(bsx_call_t, action_ring));
+  printf("%zu %zu\n", offsetof(bsx_call_t, action_ring), offsetof(bsx_call_t, row_scratch));
   return 0;
 }'''
   import tempfile
@@ -60,14 +60,14 @@ int main(void) {
           _native.Call.counters.offset, _native.CartpoleCfg.move_cost.offset,
           _native.CartpoleCfg.time_frac.offset,
           ctypes.sizeof(_native.Logging), ctypes.sizeof(_native.MnistCfg), _native.Call.logging.offset,
-          _native.Stream.mt_pos.offset, _native.Logging.log_by_step.offset, _native.Call.action_ring.offset]
+          _native.Stream.mt_pos.offset, _native.Logging.log_by_step.offset, _native.Call.action_ring.offset, _native.Call.row_scratch.offset]
   assert got == want
 
 
 def test_argument_errors_without_touching_the_gpu():
   from bsuite_amd import _native
   lib = _native.lib
-  assert lib.bsx_abi_version() == 11
+  assert lib.bsx_abi_version() == 12
   assert lib.bsx_strerror(0) == b'ok'
   cfg = _native.DeepSeaCfg(size=10, deterministic=1, move_cost=0.001, inv_size=0.1)
   call = _native.Call(n_lanes=4)
@@ -90,6 +90,15 @@ def test_argument_errors_without_touching_the_gpu():
   call.action_ring, call.n_steps = 4, 2
   assert lib.bsx_deep_sea_step(ctypes.byref(cfg), ctypes.byref(call), 16, 16, out, 16) == -5  # BSX_EMODE
   call.action_ring, call.n_steps = 0, 0
+  # ABI v12: the row scratch of the chains' wide rows must be 16-byte aligned; bsuite_info through the ABI checks its arguments
+  uc, uout = _native.UmbrellaChainCfg(5, 20), _native.TimeStepPtrs(16, 16, 16, 32)
+  call.row_scratch = 24
+  assert lib.bsx_umbrella_chain_step(ctypes.byref(uc), ctypes.byref(call), 16, 16, uout, 16) == -3   # BSX_EALIGN
+  call.row_scratch = None
+  assert lib.bsx_row_scratch_words(_native.FAMILY_IDS['umbrella_chain'], 23) == 4
+  assert lib.bsx_bsuite_info(_native.FAMILY_IDS['catch'], 0, 8, None, 16, 1, 1, 16, None) == -2      # pending part needs the state column
+  assert lib.bsx_bsuite_info(_native.FAMILY_IDS['catch'], 0, 0, None, None, 1, 1, None, None) == 0  # empty batch
+  assert lib.bsx_bsuite_info(12, 0, 8, 16, 16, 1, 1, 16, None) == -1
   # ABI v9: pipelined group step / phase-0 trace refuse what they cannot run (host-side checks only)
   assert lib.bsx_group_step_pipelined(None, None, None) == -2
   assert lib.bsx_group_trace(None, None, 0) == -2

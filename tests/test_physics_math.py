@@ -62,3 +62,14 @@ def test_angle_advance_matches_the_unrounded_angle(shim):
   ang = t.astype(np.float64) + d.astype(np.float64)        # what the f64 reference takes sin/cos of
   assert np.max(np.abs(s - np.sin(ang))) < 3e-7
   assert np.max(np.abs(c - np.cos(ang))) < 3e-7
+
+
+def test_mnist_pixel_value_is_numpys_f32_division(shim):
+  """np.float32(np.int8(b)) / 255 for every byte, every byte position: the table-free form the observation stream of
+  the MNIST bandit computes (bsuite/utils/datasets.py:55-56, mnist.py:64) is the IEEE quotient bit for bit."""
+  out = np.empty((4, 256), np.float32)
+  shim.shim_mnist_pixels(_ptr(out))
+  want = np.arange(256, dtype=np.uint8).view(np.int8).astype(np.float32) / 255
+  assert want.dtype == np.float32
+  for k in range(4):
+    np.testing.assert_array_equal(out[k].view(np.uint32), want.view(np.uint32))
