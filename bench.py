@@ -315,7 +315,47 @@ class Rank:
     torch.cuda.set_device(local_rank)
     self.dev = torch.device('cuda', local_rank)
     self._ceiling = None
+    self.pinned_cores = self.pin_to_local_cores(local_rank) if self.world > 1 else None
     self.warm_runtime()
+
+  def pin_to_local_cores(self, local_rank):
+    """One rank per GPU: bind this process to host cores of its GPU's NUMA node, the node's cores dealt out evenly among
+    the ranks whose GPUs share it (the eager step of the small families costs the host about what the
+    kernel costs the GPU, and eight ranks on one node would otherwise migrate over — and contend for — the same cores;
+    the reference pins nothing, bsuite/baselines/utils/pool.py:28-54).  Best effort: returns the number of cores bound
+    to, or None where the topology cannot be read (BSX_BENCH_NO_PIN=1 switches it off)."""
+    if os.environ.get('BSX_BENCH_NO_PIN') or not hasattr(os, 'sched_setaffinity'):
+      return None
+    try:
+      torch = self.torch
+
+      def node_of(idx):
+        pr = torch.cuda.get_device_properties(idx)
+        bdf = f'{pr.pci_domain_id:04x}:{pr.pci_bus_id:02x}:{pr.pci_device_id:02x}.0'
+        with open(f'/sys/bus/pci/devices/{bdf}/numa_node') as f:
+          return int(f.read())
+
+      single = bool(os.environ.get('BSX_BENCH_SINGLE_DEVICE'))
+      n_local = int(os.environ.get('LOCAL_WORLD_SIZE', self.world))
+      me = int(os.environ.get('LOCAL_RANK', '0'))
+      nodes = [node_of(0 if single else r) for r in range(n_local)]
+      node = nodes[me]
+      if node < 0:
+        return None
+      with open(f'/sys/devices/system/node/node{node}/cpulist') as f:
+        cpus = []
+        for part in f.read().strip().split(','):
+          lo, _, hi = part.partition('-')
+          cpus += list(range(int(lo), int(hi or lo) + 1))
+      cpus = sorted(set(cpus) & os.sched_getaffinity(0))
+      sharers = [r for r in range(n_local) if nodes[r] == node]
+      share = cpus[sharers.index(me)::len(sharers)]              # interleaved: SMT siblings stay with one rank or the other evenly
+      if len(share) < 2:
+        return None
+      os.sched_setaffinity(0, share)
+      return len(share)
+    except Exception:  # pylint: disable=broad-except
+      return None
 
   def warm_runtime(self, launches=2048):
     """The first time a process has more than ~256 launches in flight on a stream, the HIP runtime stalls once
@@ -518,6 +558,50 @@ class Rank:
       torch.cuda.empty_cache()
     return self._ceiling
 
+  def copy_ceiling(self):
+    """Copy ceiling of THIS box for the small-observation families' access mix (a third read, two thirds written:
+    bsx_calib_copy, 1 GiB in, 2 GiB out, one 16-byte load + two 16-byte stores per thread): (R + W) bytes per second.
+    A kernel that mixes reads into its writes runs against this line, not against the pure-fill rate."""
+    if getattr(self, '_copy_ceiling', None) is None:
+      torch = self.torch
+      from bsuite_amd import _native
+      n = 1 << 30
+      src = torch.empty(n, dtype=torch.uint8, device=self.dev)
+      dst = torch.empty(2 * n, dtype=torch.uint8, device=self.dev)
+      stream_h = torch.cuda.current_stream(self.dev).cuda_stream
+      for _ in range(3):
+        _native.lib.bsx_calib_copy(dst.data_ptr(), src.data_ptr(), n, 2, stream_h)
+      c0, c1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+      c0.record()
+      for _ in range(10):
+        _native.lib.bsx_calib_copy(dst.data_ptr(), src.data_ptr(), n, 2, stream_h)
+      c1.record()
+      torch.cuda.synchronize(self.dev)
+      self._copy_ceiling = 3 * n * 10 / (c0.elapsed_time(c1) * 1e-3) / 1e9
+      del src, dst
+      torch.cuda.empty_cache()
+    return self._copy_ceiling
+
+  def host_step_us(self, calls=4000):
+    """What ONE env.step() costs the host on this box (Python + ctypes + hipLaunchKernel), in microseconds: eager calls
+    of a 256-lane bandit, whose kernel the GPU finishes faster than any host can enqueue it.  An eager record whose
+    kernel time is not well above this figure is bound by the host, not by the GPU (the same
+    mountain_car step measured 9.9 us on one box and 11.6 on another) — such records carry `host_bound`."""
+    if getattr(self, '_host_step_us', None) is None:
+      torch = self.torch
+      env = self.bsuite_amd.load_from_id('bandit/0', batch=256, device=self.dev, seed=1, num_buffers=2)
+      a = torch.zeros(256, dtype=torch.int32, device=self.dev)
+      for _ in range(200):
+        env.step(a)
+      torch.cuda.synchronize(self.dev)
+      t0 = time.perf_counter()
+      for _ in range(calls):
+        env.step(a)
+      dt = time.perf_counter() - t0
+      torch.cuda.synchronize(self.dev)
+      self._host_step_us = dt / calls * 1e6
+    return self._host_step_us
+
   def roofline(self, r, full=False):
     """HBM roofline of a record: algorithmic bytes per launch / launch time by HIP events.  Fused
     rollouts of the physics families also carry the VALU-issue roofline (`valu`: wave-instructions of the committed
@@ -547,9 +631,24 @@ class Rank:
     per call — deep_sea / catch: software-pipelined, T+1 launches (bsx_call_t.state_alt); the other families: one
     fused T-step kernel."""
     mode = 'e' if r['mode'] == 'eager' else f"g{r['chunk']}" if r['mode'] == 'graph' else f"r{r['chunk']}"
-    return {'value': r['value'], 'ms_per_step': r['wall'] / r['steps'] * 1e3, 'steps': r['steps'], 'mode': mode,
-            'lanes_per_gpu': r['lanes'], 'bytes_per_env_step': r['bytes_per_step'], 'roofline': self.roofline(r),
-            'episodes_finished': r['episodes_finished']}
+    roof = self.roofline(r)
+    # (compact: `steps`, `lanes_per_gpu` and the roofline's peak / unit are the same for every sub-record of a line and
+    # stand once in `also_common`; a record that differs carries its own)
+    for k in ('peak', 'unit'):
+      roof.pop(k, None)
+    out = {'value': r['value'], 'ms_per_step': r['wall'] / r['steps'] * 1e3, 'mode': mode,
+           'bytes_per_env_step': r['bytes_per_step'], 'roofline': roof}
+    common = getattr(self, '_also_common', None)
+    if common is None or r['steps'] != common['steps']:
+      out['steps'] = r['steps']
+    if common is None or r['lanes'] != common['lanes_per_gpu']:
+      out['lanes_per_gpu'] = r['lanes']
+    if r['mode'] == 'eager' and r['family'] not in ('deep_sea', 'catch', 'mnist') and self.world == 1:
+      # the small-observation families read a third of what they write: their line is this box's COPY rate
+      roof['frac_of_box_copy'] = r['achieved'] / self.copy_ceiling()
+      if r['kernel_ms'] * 1e3 < 1.25 * self.host_step_us():
+        out['host_bound'] = True           # one launch per call: the host enqueues about as slowly as the kernel runs
+    return out
 
   # -------------------------------------------------------------------------------------------
   def measure_sweep(self, lanes, steps, warmup, ring=16):
@@ -578,8 +677,8 @@ class Rank:
     local_bytes = float(sum(l * sb.bytes_per_step(int(np.prod(e.observation_spec().shape)))
                             for e, (_, _, l) in zip(batch.envs, batch.segments)))
     timed = {}
-    for name, pipelined in (('closed', False), ('pipelined', True)):
-      batch.prepare_groups(acts, pipelined=pipelined, rows_in_stream=(self.args.row_path != 'off'))
+    for name, pipelined in (('closed', False), ('split', False), ('pipelined', True)):
+      batch.prepare_groups(acts, pipelined=pipelined, rows_in_stream=(self.args.row_path != 'off'), split=(name == 'split'))
 
       def run(n):
         for _ in range(n):
@@ -599,11 +698,17 @@ class Rank:
       return {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBPS, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBPS,
               'traffic': traffic}
 
-    tr = {k: (pmc_traffic(k, int(total_lanes))[0] if self.world == 1 else None) for k in ('sweep_closed', 'sweep_pipelined')}
-    (wall, step_ms), (wall_p, step_ms_p) = timed['closed'], timed['pipelined']
-    rec = {'value': total_lanes * steps / wall, 'ms_per_step': wall / steps * 1e3, 'steps': steps, 'mode': 'closed-loop, 2 launches/step',
+    tr = {k: (pmc_traffic(k, int(total_lanes))[0] if self.world == 1 else None) for k in ('sweep_closed', 'sweep_split', 'sweep_pipelined')}
+    # `value`: the closed-loop schedule step_grouped() runs by default (sweep_batch.DEFAULT_SPLIT); the other closed-loop
+    # cut of the same two launches beside it
+    main, other = ('split', 'closed') if sb.DEFAULT_SPLIT else ('closed', 'split')
+    modes = {'closed': 'closed-loop, 2 launches/step: phase 0 | store stream',
+             'split': 'closed-loop, 2 launches/step: advance of the stream families | store stream + small families'}
+    (wall, step_ms), (wall_o, step_ms_o), (wall_p, step_ms_p) = timed[main], timed[other], timed['pipelined']
+    rec = {'value': total_lanes * steps / wall, 'ms_per_step': wall / steps * 1e3, 'steps': steps, 'mode': modes[main],
            'global_lanes': int(total_lanes), 'segments_per_rank': [int(x) for x in g[:, 2].tolist()], 'action_ring': ring,
-           'alg_bytes_busiest_rank': max_rank_bytes, 'roofline': roof(step_ms, tr['sweep_closed']),
+           'alg_bytes_busiest_rank': max_rank_bytes, 'roofline': roof(step_ms, tr['sweep_' + main]),
+           other: {'ms_per_step': wall_o / steps * 1e3, 'frac': roof(step_ms_o)['frac']},
            'pipelined': {'value': total_lanes * steps / wall_p, 'ms_per_step': wall_p / steps * 1e3, 'open_loop': True,
                          'mode': '1 launch/step', 'roofline': roof(step_ms_p, tr['sweep_pipelined'])},
            'episodes_finished': float(g[:, 3].sum())}
@@ -640,6 +745,7 @@ class Rank:
                            'global_lanes': rec['global_lanes'], 'segments_per_rank': rec['segments_per_rank'],
                            'sharding': f'whole segments bin-packed over {world} rank(s) by lanes x bytes/step'},
                 'roofline': rec['roofline'], 'launch': rec['mode'], 'pipelined': rec['pipelined'],
+                **{k: rec[k] for k in ('closed', 'split') if k in rec},
                 'episodes_finished': rec['episodes_finished']}
         print(json.dumps(sig(line)), flush=True)
       return
@@ -664,6 +770,8 @@ class Rank:
       K, W = max(args.steps, 200), max(args.warmup, 40)
       K16, W16 = (K + 15) // 16 * 16, (W + 15) // 16 * 16
 
+      self._also_common = {'steps': K, 'lanes_per_gpu': lanes, 'roofline': {'bound': 'hbm', 'peak': HBM_PEAK_GBPS, 'unit': 'GB/s'}}
+
       def sub(workload, n_lanes, md='eager', ch=0, k=K, w=W):
         return self.guarded(workload, lambda: self.sub_record(self.measure(workload, n_lanes, k, w, md, ch)))
 
@@ -683,8 +791,16 @@ class Rank:
         for w_ in ('cartpole', 'mountain_car'):                  # BASELINE configs[3]
           bid = WORKLOADS[w_][0]
           also[bid] = sub(w_, lanes)
-          also[bid + ' g16'] = sub(w_, lanes, 'graph', 16, K16, W16)
+          if w_ == 'mountain_car':                               # (the graph record: the same launches without the host between them)
+            also[bid + ' g16'] = sub(w_, lanes, 'graph', 16, K16, W16)
           also[bid + ' r16'] = sub(w_, lanes, 'rollout', 16, K16, W16)
+        # the other families north_star names (bandit, memory_chain, umbrella_chain, discounting_chain) and the mnist
+        # bandit of the sweep: eager step() and — where a rollout is one fused launch — rollout(16)
+        for w_ in ('bandit', 'discounting_chain', 'memory_len', 'umbrella_length', 'mnist'):
+          bid = WORKLOADS[w_][0]
+          also[bid] = sub(w_, lanes)
+          if w_ != 'mnist':
+            also[bid + ' r16'] = sub(w_, lanes, 'rollout', 16, K16, W16)
       elif strong:
         # weak scaling as information: the full batch on every GPU
         also['weak'] = dict(self.guarded('weak', lambda: self.sub_record(
@@ -707,11 +823,16 @@ class Rank:
                                  + (', Logging wrapper' if args.logging else ''),
                      'mode': (f'g{args.graph}' if args.graph else f'r{args.rollout}' if args.rollout else 'e'),
                      'lanes_per_gpu': B, 'global_lanes': B * world, 'bytes_per_env_step': m['bytes_per_step'],
+                     **({'pinned_cores_per_rank': self.pinned_cores} if world > 1 else {}),
                      'episode_phases': 'lock-step' if args.no_stagger else 'staggered'},
           'roofline': self.roofline(m, full=True),
       }
       if also:
         line['also'] = also
+        if getattr(self, '_also_common', None):
+          line['also_common'] = self._also_common
+      if world == 1 and headline:
+        line['host'] = {'step_us': self.host_step_us(), 'box_copy_GBps': self.copy_ceiling()}
       line.update(episodes_finished=m['episodes_finished'], bsuite_info_sums=m['info_sums'], timed_mix=m['timed_mix'])
       if world == 1 and not args.no_cpu_baseline:
         line['cpu_baseline'] = cpu_baseline(m['bsuite_id'], m['family'], m['okw'], m['num_actions'])

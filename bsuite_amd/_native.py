@@ -165,6 +165,7 @@ _SIGS = {
                         ctypes.c_int),
     'bsx_strerror': ([ctypes.c_int], ctypes.c_char_p),
     'bsx_calib_fill': ([_P, ctypes.c_int64, ctypes.c_int32, _P], ctypes.c_int),
+    'bsx_calib_copy': ([_P, _P, ctypes.c_int64, ctypes.c_int32, _P], ctypes.c_int),
     'bsx_counter_add': ([_P, ctypes.c_uint64, _P], ctypes.c_int),
     'bsx_image_observation': ([ctypes.POINTER(ImageCfg), ctypes.c_int64, _P, _P, _P], ctypes.c_int),
     'bsx_stream_dump': ([ctypes.c_uint64, ctypes.c_uint64, ctypes.c_int64, ctypes.c_uint64,
@@ -197,6 +198,7 @@ _SIGS.update({
     'bsx_group_small_class': ([ctypes.c_int32], ctypes.c_int),
     'bsx_group_step_phase': ([_G, ctypes.c_int32, _P], ctypes.c_int),
     'bsx_group_step_pipelined': ([_G, _G, _P], ctypes.c_int),
+    'bsx_group_step_split': ([_G, _P], ctypes.c_int),
     'bsx_group_trace': ([_G, _P, ctypes.c_int64], ctypes.c_int),
     'bsx_group_destroy': ([_G], ctypes.c_int),
 })

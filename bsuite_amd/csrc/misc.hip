@@ -44,6 +44,36 @@ extern "C" int bsx_calib_fill(void* dst, int64_t n_bytes, int32_t nontemporal, v
   return bsx_launch_status();
 }
 
+// Copy calibration: the access mix of the small-observation families' eager step — it reads a third of what it writes
+// (state in; state, TimeStep scalars and the row out).  One 16-byte load per thread, W 16-byte stores (to W regions n_bytes
+// apart), no loop, blocks in address order: the rate (R + W bytes per second) such a mix reaches on this box is the
+// ceiling for a kernel that mixes reads into its writes, as the fill rate is for a pure store stream.
+template <int W>
+__global__ void __launch_bounds__(BSX_BLOCK) calib_copy_kernel(const bsx_f4* __restrict__ src, bsx_f4* __restrict__ dst, int64_t n16) {
+  const int64_t i = (int64_t)blockIdx.x * BSX_BLOCK + threadIdx.x;
+  if (i < n16) {
+    const bsx_f4 v = src[i];
+#pragma unroll
+    for (int w = 0; w < W; ++w) dst[(int64_t)w * n16 + i] = v;
+  }
+}
+
+extern "C" int bsx_calib_copy(void* dst, const void* src, int64_t n_bytes, int32_t writes_per_read, void* hip_stream) {
+  if (dst == nullptr || src == nullptr) return BSX_ENULL;
+  if (n_bytes < 0 || (n_bytes & 15) != 0 || writes_per_read < 1 || writes_per_read > 3) return BSX_EINVAL;
+  if (((reinterpret_cast<uintptr_t>(dst) | reinterpret_cast<uintptr_t>(src)) & 15u) != 0) return BSX_EALIGN;
+  if (n_bytes == 0) return 0;
+  const int64_t n16 = n_bytes / 16;
+  const int64_t blocks = (n16 + BSX_BLOCK - 1) / BSX_BLOCK;
+  if (blocks > 0x7FFFFFFF) return BSX_EINVAL;
+  hipStream_t st = (hipStream_t)hip_stream;
+  const dim3 g((unsigned)blocks), b(BSX_BLOCK);
+  if (writes_per_read == 1) calib_copy_kernel<1><<<g, b, 0, st>>>((const bsx_f4*)src, (bsx_f4*)dst, n16);
+  else if (writes_per_read == 2) calib_copy_kernel<2><<<g, b, 0, st>>>((const bsx_f4*)src, (bsx_f4*)dst, n16);
+  else calib_copy_kernel<3><<<g, b, 0, st>>>((const bsx_f4*)src, (bsx_f4*)dst, n16);
+  return bsx_launch_status();
+}
+
 __global__ void counter_add_kernel(uint64_t* counter, uint64_t delta) { *counter += delta; }
 
 extern "C" int bsx_counter_add(uint64_t* counter, uint64_t delta, void* hip_stream) {
@@ -207,6 +237,15 @@ static int group_commit(bsx_group* g) {
   if (rc != 0) return rc;
   g->stream_without_alt = false;
   for (uint8_t f : g->needs_alt) g->stream_without_alt = g->stream_without_alt || f != 0;
+  // the split step needs the segments with a share of the store stream to be the tail of the phase-0 grid
+  g->split_block = -1;
+  if (g->family == BSX_FAM_SWEEP_MIXED) {
+    int first = g->n;
+    while (first > 0 && g->blocks2[first - 1] > 0) --first;
+    bool tail_only = true;
+    for (int i = 0; i < first; ++i) tail_only = tail_only && g->blocks2[i] == 0;
+    if (tail_only) g->split_block = start[first];
+  }
   g->committed = true;
   return 0;
 }
@@ -223,6 +262,13 @@ extern "C" int bsx_group_step_phase(bsx_group_t* g, int32_t phase, void* hip_str
   if (g == nullptr) return BSX_ENULL;
   if (!g->committed || phase < 0 || phase >= g->n_phases) return BSX_EINVAL;
   return g->launch(g, phase, (hipStream_t)hip_stream);
+}
+
+extern "C" int bsx_group_step_split(bsx_group_t* g, void* hip_stream) {
+  if (g == nullptr) return BSX_ENULL;
+  if (!g->committed) return BSX_EINVAL;
+  if (g->family != BSX_FAM_SWEEP_MIXED || g->split_block < 0) return BSX_EMODE;
+  return bsx_sweep_launch_split(g, (hipStream_t)hip_stream);
 }
 
 extern "C" int bsx_group_step_pipelined(bsx_group_t* streams_of, bsx_group_t* advances_of, void* hip_stream) {

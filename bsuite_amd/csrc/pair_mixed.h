@@ -26,6 +26,8 @@ int bsx_mixed_put(bsx_group* g, int32_t family, int32_t index, const bsx_call_t*
 int bsx_mixed_launch_stream(bsx_group* g, hipStream_t st);
 // phase 0 of a BSX_FAM_SWEEP_MIXED group (small_obs.hip)
 int bsx_sweep_launch_phase0(bsx_group* g, hipStream_t st);
+// the split closed-loop step of a whole-sweep group (sweep_mixed.hip)
+int bsx_sweep_launch_split(bsx_group* g, hipStream_t st);
 // one launch: the phase-1 store stream of `streams_of` beside phase 0 of `advances_of` (small_obs.hip)
 int bsx_sweep_launch_pipelined(bsx_group* streams_of, bsx_group* advances_of, hipStream_t st);
 

@@ -54,7 +54,7 @@ __device__ __forceinline__ void sweep_phase0_body(const uint8_t* __restrict__ ta
                                                   const bsx_group_index& gi, uint64_t* counter, uint32_t* ticket,
                                                   const uint32_t block, const uint32_t n_blocks, float* s_obs,
                                                   unsigned int* s_cnt, deep_sea_fam::shared& s_ds, catch_fam::shared& s_ca,
-                                                  int32_t* s_tile_state) {
+                                                  int32_t* s_tile_state, const uint32_t ticket_index = 0xFFFFFFFFu) {
   BSX_LIFE(0);
   const bsx_group_slot w = bsx_group_find(gi, (int)block);
   const int tag = w.tag >= 0 ? w.tag : tags[w.seg];  // uniform per workgroup
@@ -100,7 +100,9 @@ __device__ __forceinline__ void sweep_phase0_body(const uint8_t* __restrict__ ta
   // (No fence: a workgroup's reads of the counter completed before its barrier, and a release fence here
   // would write back this XCD's whole L2 once per workgroup — measured 165 us instead of 25.)
   if (threadIdx.x == 0 && counter != nullptr) {
-    const uint32_t shard = block & 63u;
+    // (`n_blocks` workgroups take part, numbered 0 .. n_blocks-1 by ticket_index — `block` itself unless the launch runs a
+    // sub-range of the phase)
+    const uint32_t shard = (ticket_index != 0xFFFFFFFFu ? ticket_index : block) & 63u;
     const uint32_t in_shard = (n_blocks - shard + 63u) >> 6;            // workgroups with this shard id
     uint32_t* word = ticket + 32u * (shard + 1u);
     if (atomicAdd(word, 1u) == in_shard - 1u) {
@@ -115,19 +117,23 @@ __device__ __forceinline__ void sweep_phase0_body(const uint8_t* __restrict__ ta
   BSX_LIFE(7);
 }
 
+// block_base: the launch runs the workgroups [block_base, block_base + gridDim.x) of the group's phase-0 grid (the split
+// schedule launches the tail of the grid on its own; 0 = the whole phase).
 __global__ void __launch_bounds__(BSX_BLOCK) sweep_phase0_kernel(
     const uint8_t* __restrict__ table, const int32_t* __restrict__ tags, const bsx_group_index gi, uint64_t* counter,
-    uint32_t* ticket, uint64_t* trace) {
+    uint32_t* ticket, uint64_t* trace, const uint32_t block_base) {
   extern __shared__ __attribute__((aligned(16))) float s_obs[];
   __shared__ unsigned int s_cnt[2];
   __shared__ deep_sea_fam::shared s_ds;
   __shared__ catch_fam::shared s_ca;
   __shared__ int32_t s_tile_state[BSX_BLOCK];
-  if (trace != nullptr && threadIdx.x == 0) trace[3 * blockIdx.x] = wall_clock64();        // bsx_group_trace
-  sweep_phase0_body(table, tags, gi, counter, ticket, blockIdx.x, gridDim.x, s_obs, s_cnt, s_ds, s_ca, s_tile_state);
+  const uint32_t block = block_base + blockIdx.x;
+  if (trace != nullptr && threadIdx.x == 0) trace[3 * block] = wall_clock64();        // bsx_group_trace
+  // (the retirement ticket counts THIS launch's workgroups: shards by blockIdx.x, not by the phase-wide index)
+  sweep_phase0_body(table, tags, gi, counter, ticket, block, gridDim.x, s_obs, s_cnt, s_ds, s_ca, s_tile_state, blockIdx.x);
   if (trace != nullptr && threadIdx.x == 0) {
-    trace[3 * blockIdx.x + 1] = wall_clock64();
-    trace[3 * blockIdx.x + 2] = (uint64_t)tags[bsx_group_find(gi, (int)blockIdx.x).seg];
+    trace[3 * block + 1] = wall_clock64();
+    trace[3 * block + 2] = (uint64_t)tags[bsx_group_find(gi, (int)block).seg];
   }
 }
 
@@ -139,7 +145,7 @@ int bsx_sweep_launch_phase0(bsx_group* g, hipStream_t st) {
   }
 #endif
   sweep_phase0_kernel<<<dim3((unsigned)g->total_blocks), dim3(BSX_BLOCK), g->lds_bytes, st>>>(
-      (const uint8_t*)g->d_args, g->d_tags, g->index1(), g->shared_counter, g->d_ticket, g->trace);
+      (const uint8_t*)g->d_args, g->d_tags, g->index1(), g->shared_counter, g->d_ticket, g->trace, 0u);
   return (int)hipGetLastError();
 }
 
@@ -172,5 +178,34 @@ int bsx_sweep_launch_pipelined(bsx_group* streams_of, bsx_group* advances_of, hi
       (const uint8_t*)advances_of->d_args, advances_of->d_tags, advances_of->index1(), advances_of->shared_counter,
       advances_of->d_ticket, (uint32_t)advances_of->total_blocks, (uint32_t)place, (const uint8_t*)streams_of->d_args2, streams_of->d_tags,
       streams_of->index2());
+  return (int)hipGetLastError();
+}
+
+// Split closed-loop sweep step (bsx_group_step_split): TWO launches like bsx_group_step, cut differently.  Phase 0 holds
+// two kinds of workgroups: those whose segment has a share of the phase-1 store stream (the lane advance of deep_sea /
+// mnist / large catch boards, the packed rows of the chains) — the stream depends on them — and those that are a
+// small-observation segment's whole step, on which nothing in the step depends.  With the segments ordered so that the
+// second kind comes first in the phase-0 grid (g->split_block = the first workgroup of the first kind):
+//   launch 1   phase-0 workgroups [split_block, total): what the stream waits for, one dispatch round (~1500 workgroups
+//              of the 4213 at 2^20 lanes);
+//   launch 2   the store stream beside phase-0 workgroups [0, split_block) (sweep_pipelined_kernel with both halves
+//              taken from THIS group): the latency-bound small families hide beside the 850 MB of stores instead of
+//              standing in front of them; their last workgroup to retire bumps the call counter.
+// Everything in a step reads the actions of that step only, so the schedule is closed-loop: the TimeSteps of step s are
+// complete when launch 2 ends.
+int bsx_sweep_launch_split(bsx_group* g, hipStream_t st) {
+  const int64_t split = g->split_block;
+  if (split < 0 || split > g->total_blocks) return BSX_EMODE;
+  const int64_t n_tail = g->total_blocks - split;
+  if (n_tail > 0)
+    sweep_phase0_kernel<<<dim3((unsigned)n_tail), dim3(BSX_BLOCK), g->lds_bytes, st>>>(
+        (const uint8_t*)g->d_args, g->d_tags, g->index1(), split == 0 ? g->shared_counter : nullptr, g->d_ticket, nullptr, (uint32_t)split);
+  const uint64_t blocks = (uint64_t)split + (uint64_t)g->total_blocks2;
+  if (blocks == 0) return (int)hipGetLastError();
+  if (blocks > 0x7FFFFFFFull) return BSX_EINVAL;
+  static const int place = bsx_env_int("BSX_SPLIT_PLACE", 0);            // bsx_pipe_role_of: 0 = the phase-0 workgroups first
+  sweep_pipelined_kernel<<<dim3((unsigned)blocks), dim3(BSX_BLOCK), g->lds_bytes, st>>>(
+      (const uint8_t*)g->d_args, g->d_tags, g->index1(), g->shared_counter, g->d_ticket, (uint32_t)split, (uint32_t)place,
+      (const uint8_t*)g->d_args2, g->d_tags, g->index2());
   return (int)hipGetLastError();
 }

@@ -62,6 +62,11 @@ def assign_segments(costs: Sequence[float], world_size: int) -> List[int]:
   return rank_of
 
 
+# The closed-loop schedule `prepare_groups()` / `step_grouped()` run by default: False = phase 0 | store stream
+# (bsx_group_step), True = the split cut of the same two launches (bsx_group_step_split).
+DEFAULT_SPLIT = False
+
+
 class SweepBatch:
   """All (or some) bsuite_ids as lane segments on this rank's GPU."""
 
@@ -162,7 +167,7 @@ class SweepBatch:
   # -- grouped launches --------------------------------------------------------------------
   def prepare_groups(self, actions: Sequence[torch.Tensor], mix_small: bool = True, mix_pairs: bool = True,
                      mix_all: bool = True, pipelined: bool = False, heavy_first: bool = True,
-                     rows_in_stream: bool = True):
+                     rows_in_stream: bool = True, split: Optional[bool] = None):
     """Builds the launch groups.  With `mix_all` (default) ONE group for the whole sweep
     (BSX_FAM_SWEEP_MIXED): a sweep step is two launches — phase 0 advances every lane of every family
     and bumps the shared call counter, phase 1 is the observation store stream of the two-kernel
@@ -177,6 +182,12 @@ class SweepBatch:
     `rows_in_stream` (with `mix_all`; False: A/B): the wide rows of memory_chain / umbrella_chain segments are left
     packed by phase 0 and written by the phase-1 store stream (bsx_call_t.row_scratch) instead of being built as bit
     planes in LDS by phase 0 itself.
+
+    `split` (with `mix_all`, closed-loop): `step_grouped()` cuts the two launches differently (bsx_group_step_split) —
+    launch 1 = only the phase-0 workgroups the store stream depends on (lane advance of deep_sea / mnist / large catch
+    boards, packed rows of the chains), launch 2 = the store stream BESIDE the whole step of every other
+    small-observation segment.  Same results, same closed-loop contract (everything in step s reads the actions of
+    step s only; its TimeSteps are complete when launch 2 ends).
 
     `pipelined` (with `mix_all`): the sweep's actions are static, so sweep step s+1 does not need the
     observations of step s — ONE launch per step then carries the observation store stream of step s
@@ -222,7 +233,11 @@ class SweepBatch:
           # (small catch boards are written by phase 0 itself, 200 bytes per lane: they belong with the heavy ones)
           small_k = (raw_k._abi_name not in ('deep_sea', 'catch', 'mnist') or  # pylint: disable=protected-access
                      (raw_k._abi_name == 'catch' and numel_k <= _native.FUSED_CATCH_MAX_CELLS))  # pylint: disable=protected-access
-          return -numel_k if small_k else 1
+          # (segments with a share of the phase-1 store stream — the two-kernel families, and the chains' wide rows when the
+          # stream writes them — are the tail of the group: what bsx_group_step_split launches first, on its own)
+          if small_k and rows_in_stream and raw_k._row_scratch_words():  # pylint: disable=protected-access
+            return 1
+          return -numel_k if small_k else 2
         members = sorted(members, key=weight)
       def build(parity):
         handle = ctypes.c_void_p()
@@ -275,6 +290,7 @@ class SweepBatch:
     self._group_actions = list(actions)      # keep the static action tensors alive
     self._group_outs = outs
     self._pipelined = bool(pipelined)
+    self._split = bool(DEFAULT_SPLIT if split is None else split) and mix_all and not pipelined
     self._pipelined_outs = outs_of
     self._pipelined_step = 0
     return outs_of if pipelined else outs
@@ -295,8 +311,9 @@ class SweepBatch:
       self._pipelined_step = s + 1
       self._pending_steps += 1
       return self._pipelined_outs[s & 1]
+    step = _native.lib.bsx_group_step_split if getattr(self, '_split', False) else _native.lib.bsx_group_step
     for handle in self._groups:
-      rc = _native.lib.bsx_group_step(handle, stream)
+      rc = step(handle, stream)
       if rc != 0:
         _native.check(rc, 'bsx_group_step')
     self._bump(grouped=True)

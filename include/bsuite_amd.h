@@ -426,6 +426,13 @@ int bsx_group_step(bsx_group_t* g, void* hip_stream);
  * the small-observation groups have 1.  bsx_group_step == all phases in order on one stream. */
 int bsx_group_phases(const bsx_group_t* g);
 int bsx_group_step_phase(bsx_group_t* g, int32_t phase, void* hip_stream);
+/* Split closed-loop sweep step (ABI v12) of a BSX_FAM_SWEEP_MIXED group: two launches like bsx_group_step — same results,
+ * TimeSteps of the step complete when it returns to the stream — cut so that only what the store stream depends on
+ * stands in front of it: launch 1 runs the phase-0 workgroups of the segments that have a share of the stream (lane
+ * advance of deep_sea / mnist / large catch boards, packed rows of the chains), launch 2 the store stream BESIDE the
+ * whole step of every other small-observation segment, whose last workgroup bumps the call counter.  Needs the
+ * segments with a stream share to be the LAST segments of the group (set the others first): BSX_EMODE otherwise. */
+int bsx_group_step_split(bsx_group_t* g, void* hip_stream);
 /* Software-pipelined sweep step (ABI v9), for callers whose actions do not depend on the observations
  * (a rollout with given actions, BASELINE config 5): ONE launch runs phase 1 — the observation stream —
  * of `streams_of` beside phase 0 — every lane's advance — of `advances_of`.  Both are committed
@@ -501,6 +508,11 @@ const char* bsx_strerror(int code);
 /* Pure-store calibration: writes n_bytes of zeros with the same 16-B cooperative pattern the
  * observation writers use; the measured rate is the practical ceiling for store-bound families. */
 int bsx_calib_fill(void* dst, int64_t n_bytes, int32_t nontemporal, void* hip_stream);
+/* Copy calibration (ABI v12): reads n_bytes from src (one 16-byte load per thread) and writes them `writes_per_read`
+ * (1..3) times to dst, dst + n_bytes, ...: the read/write mix of the small-observation families' eager step (2 = a third
+ * read, two thirds written).  (1 + writes_per_read) * n_bytes / time is the ceiling of this box for kernels that mix
+ * reads into their writes — lower than the pure-fill rate. */
+int bsx_calib_copy(void* dst, const void* src, int64_t n_bytes, int32_t writes_per_read, void* hip_stream);
 /* *counter += delta on the stream: advances a device-resident call counter (bsx_stream_t.step_base)
  * so a captured hipGraph of step launches replays with fresh draw-stream coordinates. */
 int bsx_counter_add(uint64_t* counter, uint64_t delta, void* hip_stream);

@@ -62,7 +62,7 @@ def test_default_line_two_ranks_is_strong_with_weak_and_sweep_records():
   assert two['scaling'] == 'strong' and two['config']['lanes_per_gpu'] == 4096 and two['config']['global_lanes'] == 8192
   assert two['roofline']['alg_bytes'] == 3621 * 4096
   also = two['also']
-  assert list(also)[0] == 'catch/0' and 'error' not in also['catch/0'] and also['catch/0']['lanes_per_gpu'] == 4096
+  assert list(also)[0] == 'catch/0' and 'error' not in also['catch/0'] and two['also_common']['lanes_per_gpu'] == 4096
   assert also['weak']['scaling'] == 'weak' and also['weak']['lanes_per_gpu'] == 8192 and also['weak']['global_lanes'] == 16384
   sweep = also['sweep']
   assert sum(sweep['segments_per_rank']) == 468 and min(sweep['segments_per_rank']) > 0
@@ -81,12 +81,49 @@ def test_default_line_fits_the_drivers_tail():
                      env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=800)
   assert p.returncode == 0, p.stderr[-3000:]
   text = [l for l in p.stdout.splitlines() if l.startswith('{')][0]
-  assert len(text) < 7500, len(text)
+  assert len(text) < 7800, len(text)
   line = json.loads(text)
   assert list(line['also'])[0] == 'catch/0'
-  for k in ('catch/0', 'catch/0 r32', 'deep_sea/10 r16', 'cartpole/0', 'cartpole/0 r16', 'mountain_car/0', 'mountain_car/0 r16', 'sweep'):
+  # every BASELINE config and every family north_star names, each with its roofline
+  for k in ('catch/0', 'catch/0 r32', 'deep_sea/10 r16', 'cartpole/0', 'cartpole/0 r16', 'mountain_car/0', 'mountain_car/0 r16',
+            'bandit/0', 'bandit/0 r16', 'discounting_chain/0', 'discounting_chain/0 r16', 'memory_len/10', 'memory_len/10 r16',
+            'umbrella_length/10', 'umbrella_length/10 r16', 'mnist/0', 'sweep'):
     assert 'frac' in line['also'][k]['roofline'], (k, line['also'][k])
+  assert line['also_common']['lanes_per_gpu'] == 65536 and line['also_common']['roofline']['peak'] == 8000.0
+  assert line['also']['cartpole/0']['roofline']['frac_of_box_copy'] > 0 and line['host']['step_us'] > 0
   assert line['cpu_baseline']['kind'] in ('reference', 'port') and line['roofline']['frac'] > 0
+
+
+@pytest.mark.timeout(1500)
+def test_eight_self_launched_ranks_rehearsal():
+  """The run the driver makes on an 8-GPU node (`bench.py --gpus 8`), rehearsed with all eight ranks on the one GPU
+  there is here (gloo, BSX_BENCH_SINGLE_DEVICE): the default line parses, fits the driver's 8000-character tail, carries
+  the strong record, the weak record and the sweep sharded over eight ranks (every bsuite_id on exactly one rank), and —
+  draws, actions and episode phases being keyed by GLOBAL lane id / segment — reproduces the one-rank run's episode
+  counts and bsuite_info sums exactly.  Reference fan-out: bsuite/baselines/utils/pool.py:28-54."""
+  env = dict(os.environ)
+  env.pop('WORLD_SIZE', None)
+  env.pop('RANK', None)
+  env.update(BSX_BENCH_BACKEND='gloo', BSX_BENCH_SINGLE_DEVICE='1')
+  p = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--no-cpu-baseline', '--gpus', '8', '--lanes', '65536',
+                      '--steps', '8', '--warmup', '4'], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=1400)
+  assert p.returncode == 0, p.stderr[-3000:]
+  lines = [l for l in p.stdout.splitlines() if l.startswith('{')]
+  assert len(lines) == 1 and len(lines[0]) < 7800, (len(lines), [len(l) for l in lines])
+  eight = json.loads(lines[0])
+  assert eight['n_gpus'] == 8 and eight['scaling'] == 'strong'
+  assert eight['config']['lanes_per_gpu'] == 8192 and eight['config']['global_lanes'] == 65536
+  assert eight['roofline']['alg_bytes'] == 3621 * 8192
+  also = eight['also']
+  assert also['weak']['scaling'] == 'weak' and also['weak']['lanes_per_gpu'] == 65536 and also['weak']['global_lanes'] == 8 * 65536
+  sweep = also['sweep']
+  assert len(sweep['segments_per_rank']) == 8 and sum(sweep['segments_per_rank']) == 468 and min(sweep['segments_per_rank']) > 20
+  assert sweep['global_lanes'] == 65536
+  one = _bench('--gpus', '1', '--lanes', '65536', '--steps', '8', '--warmup', '4', '--no-also')
+  assert one['episodes_finished'] == eight['episodes_finished'] > 0
+  assert one['bsuite_info_sums'] == eight['bsuite_info_sums'] and one['timed_mix'] == eight['timed_mix']
+  one_sweep = _bench('--gpus', '1', '--workload', 'sweep', '--lanes', '65536', '--steps', '100', '--warmup', '20')
+  assert one_sweep['episodes_finished'] == sweep['episodes_finished'] > 0
 
 
 # ---------------------------------------------------------------------------------------------------

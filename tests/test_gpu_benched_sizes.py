@@ -1,7 +1,8 @@
 """GPU: parity AT THE SIZES bench.py measures.
 
 * BASELINE config 5 exactly as benched — all 468 bsuite_ids, 2^20 lanes, whole-sweep group, the
-  software-pipelined one-launch schedule AND the two-launch schedule, the action ring the bench feeds
+  software-pipelined one-launch schedule AND both closed-loop two-launch schedules (phase 0 | stream, and the split cut
+  of bsx_group_step_split), the action ring the bench feeds
   (bsx_call_t.action_ring) — 50 sweep steps: 8 sampled lanes of every segment against the C oracle
   (bit-exact for the integer / grid families), every lane of every segment against a stand-alone
   environment of that bsuite_id stepped eagerly, and `summary()` against per-segment stand-alone
@@ -30,8 +31,9 @@ PHYSICS = ('cartpole', 'cartpole_swingup', 'mountain_car')
 
 
 @pytest.mark.timeout(900)
-@pytest.mark.parametrize('pipelined', [True, False])
+@pytest.mark.parametrize('pipelined', [True, False, 'split'])
 def test_config5_full_sweep_as_benched(tmp_path, pipelined):
+  split, pipelined = pipelined == 'split', pipelined is True
   from bsuite_amd.utils import datasets
   from bsuite_amd import distributed as bdist
   imgs, labels = gu.mnist_dataset()
@@ -42,8 +44,8 @@ def test_config5_full_sweep_as_benched(tmp_path, pipelined):
   batch = sb.SweepBatch(None, B, seed=seed, env_kwargs=kw)
   assert len(batch.envs) == 468 and batch.lanes() == B
   acts = batch.random_actions(seed=1, ring=ring)
-  outs = batch.prepare_groups(acts, pipelined=pipelined)
-  assert len(batch._groups) == (2 if pipelined else 1)
+  outs = batch.prepare_groups(acts, pipelined=pipelined, split=split)
+  assert len(batch._groups) == (2 if pipelined else 1) and batch._split == split
 
   # the checker: 8 lanes of every segment through the C oracle, configured from the reference's experiment files
   rng = np.random.default_rng(5)
@@ -232,3 +234,54 @@ def test_physics_full_batch_full_episode_teacher_forced(family, horizon):
     clean = ~chk.tainted
     for k_, v in orc.bsuite_info().items():
       np.testing.assert_array_equal(info[k_][:n].cpu().numpy()[clean], v[clean], err_msg=k_)
+
+
+@pytest.mark.timeout(1500)
+def test_config5_eight_shards_equal_the_unsharded_sweep(tmp_path):
+  """BASELINE config 5 as the driver's 8-GPU run shards it: SweepBatch(rank=r, world_size=8) for r = 0..7, one after
+  another on the one GPU there is here, each stepping ITS bin-packed eighth of the 468 ids as one whole-sweep group —
+  every TimeStep field, bsuite_info column and episode counter of every segment bit-identical to the unsharded sweep
+  at 2^20 lanes (draws and actions are keyed by global lane id / segment index: bsuite_amd/sweep_batch.py).  The
+  shards partition the ids, and their loads (lanes x bytes per step) are within 1 % of each other."""
+  from bsuite_amd.utils import datasets
+  imgs, labels = gu.mnist_dataset()
+  datasets.write_idx_files(str(tmp_path), imgs.view(np.uint8), labels)
+  mn = dict(data_dir=str(tmp_path))
+  kw = dict(mnist=mn, mnist_noise=mn, mnist_scale=mn)
+  seed, steps, ring, world = 42, 21, 16, 8
+
+  def run(rank, world_size):
+    batch = sb.SweepBatch(None, B, seed=seed, env_kwargs=kw, rank=rank, world_size=world_size)
+    acts = batch.random_actions(seed=1, ring=ring)
+    outs = batch.prepare_groups(acts)
+    for _ in range(steps):
+      batch.step_grouped()
+    batch.sync()
+    res = {}
+    for (bid, _, lanes), ts, env in zip(batch.segments, outs, batch.envs):
+      info = env.bsuite_info()
+      res[bid] = dict(ts=tuple(x.clone() for x in (ts.step_type, ts.reward, ts.discount, ts.observation)),
+                      info={k: v.clone() for k, v in info.items()}, counters=eu.raw(env).episode_counters().clone(), lanes=lanes)
+    load = sum(l * sb.bytes_per_step(int(np.prod(e.observation_spec().shape))) for e, (_, _, l) in zip(batch.envs, batch.segments))
+    batch.release_groups()
+    return res, load
+
+  whole, total_load = run(0, 1)
+  assert len(whole) == 468
+  seen, loads = set(), []
+  for r in range(world):
+    part, load = run(r, world)
+    loads.append(load)
+    assert part and not (set(part) & seen)
+    seen |= set(part)
+    for bid, got in part.items():
+      want = whole[bid]
+      for x, y in zip(got['ts'], want['ts']):
+        assert torch.equal(x, y), (r, bid)
+      for k in want['info']:
+        assert torch.equal(got['info'][k], want['info'][k]), (r, bid, k)
+      assert torch.equal(got['counters'], want['counters']), (r, bid)
+    del part
+    torch.cuda.empty_cache()
+  assert seen == set(whole) and sum(loads) == total_load
+  assert max(loads) / (total_load / world) < 1.01, loads

@@ -124,3 +124,89 @@ def test_physics_full_batch_one_step_teacher_forced():
            ts.observation[:n].cpu().numpy())
     chk.check(got, (ost, orr, od, oo), eu.oracle_physics_state(orc, family), msg=family)
     chk.assert_few_ties(1e-4)
+
+
+@pytest.mark.parametrize('family,kwargs,extra', [('deep_sea', dict(size=30, mapping_seed=42), 1), ('catch', dict(), 257),
+                                                ('catch', dict(), 511), ('deep_sea', dict(size=12, mapping_seed=3), 257)])
+def test_two_lanes_per_thread_advance_on_ragged_batches(family, kwargs, extra):
+  """from 4096 workgroups up the lane advance runs two lanes per thread (bsx_advance2_kernel: lanes
+  b*512 + t and b*512 + 256 + t, a grid of (blocks + 1) / 2) — exercised so far at exactly 2^20 lanes only.  Ragged
+  batches just above it: the last workgroup has one full half + a partial one / a single lane / only its first half;
+  the tail lanes, the lanes around every 512-lane boundary and a random subsample against the oracle, bit-exact; LAST /
+  FIRST counts over ALL lanes against the step types."""
+  n, seed, T = B + extra, 13, 14
+  env = eu.make_env(family, kwargs, batch=n, lane_offset=0, seed=seed, num_buffers=1)
+  rng = np.random.default_rng(extra)
+  idx = np.unique(np.concatenate([rng.integers(0, n, size=2048), np.arange(n - 600, n), [0, 255, 256, 511, 512, B - 1, B]]))
+  idx_t = torch.from_numpy(idx.astype(np.int64)).cuda()
+  orc = coracle.OracleEnv(family, kwargs, idx.astype(np.uint64), seed=seed)
+  g = torch.Generator(device='cuda'); g.manual_seed(extra)
+  n_last = n_first = 0
+  for t in range(T):
+    a = torch.randint(orc.num_actions, (n,), generator=g, device='cuda', dtype=torch.int32)
+    ts = env.step(a)
+    n_last += int((ts.step_type == 2).sum()); n_first += int((ts.step_type == 0).sum())
+    ost, orr, od, oo = orc.call(a[idx_t].cpu().numpy(), t)
+    np.testing.assert_array_equal(ts.step_type[idx_t].cpu().numpy(), ost, err_msg=f't={t}')
+    live = ost != 0
+    np.testing.assert_array_equal(eu.f32_bits(ts.reward[idx_t].cpu().numpy()[live]), eu.f32_bits(orr[live].astype(np.float32)))
+    np.testing.assert_array_equal(ts.observation[idx_t].cpu().numpy(), oo, err_msg=f'obs t={t}')
+  c = eu.raw(env).episode_counters().cpu().numpy()
+  assert (int(c[0]), int(c[1])) == (n_last, n_first)
+  for k, v in orc.bsuite_info().items():
+    np.testing.assert_array_equal(env.bsuite_info()[k][idx_t].cpu().numpy(), v, err_msg=k)
+
+
+def test_mnist_full_batch():
+  """The MNIST bandit at 2^20 lanes (lane advance + the table-free observation stream) on the synthetic
+  idx dataset: invariants over all lanes, a subsample against the oracle bit for bit."""
+  from tests import golden_util as gu
+  imgs, labels = gu.mnist_dataset()
+  kw = dict(images=imgs, labels=labels)
+  T, seed = 9, 21
+  env = eu.make_env('mnist', kw, batch=B, lane_offset=0, seed=seed, num_buffers=1)
+  rng = np.random.default_rng(4)
+  idx = _subsample(rng, 2048)
+  idx_t = torch.from_numpy(idx).cuda()
+  orc = coracle.OracleEnv('mnist', kw, idx.astype(np.uint64), seed=seed)
+  g = torch.Generator(device='cuda'); g.manual_seed(8)
+  lut = torch.from_numpy(np.arange(256, dtype=np.uint8).view(np.int8).astype(np.float32) / 255).cuda()
+  for t in range(T):
+    a = torch.randint(10, (B,), generator=g, device='cuda', dtype=torch.int32)
+    ts = env.step(a)
+    first = ts.step_type == 0
+    assert bool((first | (ts.step_type == 2)).all())                        # reset / guess alternate (mnist.py:61-75)
+    obs = ts.observation.view(B, -1)
+    assert bool((obs[~first] == 0).all())                                   # zeros after the guess (:73)
+    assert bool(torch.isin(obs[first][:4096], lut).all())                   # every pixel is some int8 / 255
+    ost, orr, od, oo = orc.call(a[idx_t].cpu().numpy(), t)
+    np.testing.assert_array_equal(ts.step_type[idx_t].cpu().numpy(), ost, err_msg=f't={t}')
+    np.testing.assert_array_equal(eu.f32_bits(ts.observation[idx_t].cpu().numpy()), eu.f32_bits(oo), err_msg=f'obs t={t}')
+    live = ost != 0
+    np.testing.assert_array_equal(ts.reward[idx_t].cpu().numpy()[live], orr[live].astype(np.float32))
+  np.testing.assert_array_equal(env.bsuite_info()['total_regret'][idx_t].cpu().numpy(), orc.bsuite_info()['total_regret'])
+
+
+@pytest.mark.parametrize('family,kwargs', [('umbrella_chain', dict(chain_length=12, n_distractor=20)),      # umbrella_length/10
+                                           ('memory_chain', dict(memory_length=2, num_bits=40))])           # memory_size/16
+def test_wide_rows_full_batch(family, kwargs):
+  """The chains' wide rows at 2^20 lanes (lane advance + wide-row store stream, the benched path): a subsample against
+  the oracle bit for bit on every call across two episode ends."""
+  T, seed = 30 if family == 'umbrella_chain' else 9, 17
+  env = eu.make_env(family, kwargs, batch=B, lane_offset=0, seed=seed, num_buffers=1)
+  rng = np.random.default_rng(6)
+  idx = _subsample(rng, 2048)
+  idx_t = torch.from_numpy(idx).cuda()
+  orc = coracle.OracleEnv(family, kwargs, idx.astype(np.uint64), seed=seed)
+  g = torch.Generator(device='cuda'); g.manual_seed(3)
+  for t in range(T):
+    a = torch.randint(2, (B,), generator=g, device='cuda', dtype=torch.int32)
+    ts = env.step(a)
+    ost, orr, od, oo = orc.call(a[idx_t].cpu().numpy(), t)
+    np.testing.assert_array_equal(ts.step_type[idx_t].cpu().numpy(), ost, err_msg=f't={t}')
+    np.testing.assert_array_equal(eu.f32_bits(ts.observation[idx_t].cpu().numpy()), eu.f32_bits(oo), err_msg=f'obs t={t}')
+    live = ost != 0
+    np.testing.assert_array_equal(ts.reward[idx_t].cpu().numpy()[live], orr[live].astype(np.float32))
+  assert bool(eu.raw(env)._call_desc.row_scratch)
+  for k, v in orc.bsuite_info().items():
+    np.testing.assert_array_equal(env.bsuite_info()[k][idx_t].cpu().numpy(), v, err_msg=k)

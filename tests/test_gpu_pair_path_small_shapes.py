@@ -45,3 +45,35 @@ def test_256_lane_fused_tiles_at_small_shapes():
   tail = p.stdout[-3000:]
   assert p.returncode == 0, tail
   assert ' passed' in tail and 'failed' not in tail, tail
+
+
+@pytest.mark.timeout(900)
+def test_two_lanes_per_thread_advance_at_small_shapes():
+  """the two-lanes-per-thread lane advance (bsx_advance2_kernel) is size-gated at 4096 workgroups, so no
+  in-process test at a small shape reaches it: here every deep_sea / catch / mnist parity test of the pair path runs
+  with BSX_ADVANCE_LPT2_MIN_BLOCKS=1 (tuning build) — one-lane, ragged and several-thousand-lane batches, the `mine[h]`
+  guards and the (blocks + 1) / 2 grid included (fused steps and the single-launch deep_sea step switched off)."""
+  from bsuite_amd import build as _build
+  env = dict(os.environ, BSX_NATIVE_LIB=_build.build(tuning=True), BSX_ADVANCE_LPT2_MIN_BLOCKS='1', BSX_FUSED_TILE_MAX_CELLS='0',
+             BSX_DEEP_SEA_STEP1='0', PYTHONPATH=ROOT)
+  p = subprocess.run([sys.executable, '-m', 'pytest', '-q', '-x', '-m', 'gpu', '-p', 'no:cacheprovider',
+                      'tests/test_gpu_golden.py', 'tests/test_gpu_oracle_batch.py', 'tests/test_gpu_engine_features.py',
+                      '-k', 'deep_sea or catch or mnist or engine'],
+                     cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=800)
+  tail = p.stdout[-3000:]
+  assert p.returncode == 0, tail
+  assert ' passed' in tail and 'failed' not in tail, tail
+
+
+@pytest.mark.timeout(900)
+def test_wide_row_stream_chunk_counts():
+  """The wide-row store stream with 1 and 4 chunks per thread (tuning build; the product library has K = 2)."""
+  from bsuite_amd import build as _build
+  for k in ('1', '4'):
+    env = dict(os.environ, BSX_NATIVE_LIB=_build.build(tuning=True), BSX_ROW_STREAM_K=k, PYTHONPATH=ROOT)
+    p = subprocess.run([sys.executable, '-m', 'pytest', '-q', '-x', '-m', 'gpu', '-p', 'no:cacheprovider',
+                        'tests/test_gpu_wide_rows.py', '-k', 'bit_exact'],
+                       cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=400)
+    tail = p.stdout[-3000:]
+    assert p.returncode == 0, tail
+    assert ' passed' in tail and 'failed' not in tail, tail
