@@ -160,7 +160,7 @@ lib = _load()
 _P = ctypes.c_void_p
 _SIGS = {
     'bsx_abi_version': ([], ctypes.c_int),
-    'bsx_row_scratch_words': ([ctypes.c_int32, ctypes.c_int32], ctypes.c_int32),
+    'bsx_row_scratch_bytes': ([ctypes.c_int32, ctypes.c_int32, ctypes.c_int64], ctypes.c_int64),
     'bsx_bsuite_info': ([ctypes.c_int32, ctypes.c_int32, ctypes.c_int64, _P, _P, ctypes.c_int32, ctypes.c_int32, _P, _P],
                         ctypes.c_int),
     'bsx_strerror': ([ctypes.c_int], ctypes.c_char_p),

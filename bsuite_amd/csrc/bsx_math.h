@@ -28,8 +28,10 @@
 /* np.float32(np.int8(b)) / np.float32(255) — a pixel of the MNIST bandit's observation (bsuite/utils/datasets.py:55-56 parses
  * the idx bytes as int8, mnist.py:64 divides by 255 in f32) — correctly rounded, without a table and without a division:
  * q = x * RN(1/255), then one Newton step on the exact remainder (two fused multiply-adds).  Equal to the IEEE division
- * for all 256 bytes (tests/test_physics_math.py, against numpy), so a 16-byte chunk of the observation stream is four
- * {v_bfe_i32, v_cvt, 3 VALU} instead of four LDS reads behind a table fill and a workgroup barrier.
+ * for all 256 bytes (tests/test_physics_math.py, against numpy): a 16-byte chunk of the observation stream as four
+ * {v_bfe_i32, v_cvt, 3 VALU} instead of four LDS reads behind a table fill and a workgroup barrier.  Measured in round 5
+ * and NOT adopted (the stream is slower with it, profiles/r05/ab_mnist_arith.log): compiled into the tuning build only
+ * (BSX_MNIST_ARITH=1); the host side uses it to recognise the reference's table.
  * four_pixels: one aligned dword of the image table; k = 0..3: which byte. */
 BSX_HD float bsx_mnist_pixel_value(uint32_t four_pixels, int k) {
   const float x = (float)((int32_t)(four_pixels << (24 - 8 * k)) >> 24);

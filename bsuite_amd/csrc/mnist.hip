@@ -36,8 +36,7 @@ __global__ void __launch_bounds__(BSX_BLOCK) mnist_observe_group_kernel(const mn
                                                                         const bsx_group_index gi) {
   __shared__ float s_lut[MNIST_LUT_FLOATS];
   const bsx_group_slot w = bsx_group_find(gi, (int)blockIdx.x);
-  if (table[w.seg].arith) mnist_observe_body<K, VAR | 8>(table[w.seg], w.block, s_lut);      // uniform per workgroup
-  else mnist_observe_body<K, VAR>(table[w.seg], w.block, s_lut);
+  mnist_observe_body<K, VAR>(table[w.seg], w.block, s_lut);
 }
 
 static int mnist_variant() {
@@ -70,9 +69,9 @@ static int mnist_make(const bsx_mnist_t* cfg, const bsx_call_t* call, const int3
   a->images = cfg->images; a->labels = cfg->labels; a->num_data = cfg->num_data; a->num_pixels = cfg->num_pixels;
   o->obs = out.observation; o->state = state; o->images = cfg->images; o->n_lanes = call->n_lanes;
   o->cells = (uint32_t)cfg->num_pixels; o->cells_magic = bsx_div_magic(o->cells); o->dv = bsx_make_div64(o->cells);
-  // the reference's table (np.float32(int8) / 255, datasets.py:55-56 + mnist.py:64) is computed in the kernel; any other
-  // table a caller hands over is looked up in LDS
-  static const int arith_env = bsx_env_int("BSX_MNIST_ARITH", 1);
+  // A/B knob (tuning build): compute the reference's table (np.float32(int8) / 255, bsx_mnist_pixel_value) in the kernel
+  // instead of looking it up in LDS — exact, and measured slower (see pair_mixed.h): the product library always looks up
+  static const int arith_env = bsx_env_int("BSX_MNIST_ARITH", 0);
   o->arith = arith_env != 0; o->_pad = 0;
   for (int k = 0; k < 256; ++k) {
     o->lut[k] = cfg->pixel_lut[k];
@@ -103,7 +102,9 @@ extern "C" int bsx_mnist_step(const bsx_mnist_t* cfg, const bsx_call_t* call, co
     mnist_advance_kernel<<<dim3((unsigned)blocks_a), dim3(BSX_BLOCK), 0, st>>>(a);
     o.obs = out.observation + off * (int64_t)o.cells;
     const dim3 go((unsigned)blocks_o), bo(BSX_BLOCK);
+#if defined(BSX_TUNING)
     if (o.arith) { mnist_observe_kernel<MNIST_K, 3 | 8><<<go, bo, 0, st>>>(o); continue; }
+#endif
     switch (mnist_variant()) {
       case 1: mnist_observe_kernel<MNIST_K, 1><<<go, bo, 0, st>>>(o); break;
       case 2: mnist_observe_kernel<MNIST_K, 2><<<go, bo, 0, st>>>(o); break;

@@ -58,10 +58,16 @@ __device__ __forceinline__ void pair_mixed_stream_body(const uint8_t* __restrict
       // (variant 7 — no workgroup barrier, a per-wave LUT copy filled only when the wave shows an image — measured the
       // same as 3: sweep step 165.8-166.1 vs 164.2-166.2 us, profiles/r04/ab_sweep_mnist_stream_no_barrier.log; the
       // barrier was not what holds the mnist half of the stream at 5.4 TB/s)
-      if (reinterpret_cast<const mnist_observe_args*>(slot)->arith)     // uniform: the reference's table, computed (no LDS, no barrier)
+#if defined(BSX_TUNING)
+      // (A/B, tuning build only: the table-free pixel values of bsx_mnist_pixel_value — measured SLOWER than the LDS table,
+      // stand-alone 654 vs 595 us at 2^20 lanes and 177.4 vs 173.5 us per sweep step, profiles/r05/ab_mnist_arith.log: the
+      // stream pays more for 20 extra vector instructions per chunk than for the table fill and its barrier)
+      if (reinterpret_cast<const mnist_observe_args*>(slot)->arith) {
         mnist_observe_body<PAIR_MNIST_K, 3 | 8>(*reinterpret_cast<const mnist_observe_args*>(slot), w.block, s_lut);
-      else
-        mnist_observe_body<PAIR_MNIST_K, 3>(*reinterpret_cast<const mnist_observe_args*>(slot), w.block, s_lut);
+        break;
+      }
+#endif
+      mnist_observe_body<PAIR_MNIST_K, 3>(*reinterpret_cast<const mnist_observe_args*>(slot), w.block, s_lut);
 #endif
       break;
     // wide rows of the chains, left packed by phase 0 (whole-sweep groups; row_stream.h)

@@ -50,9 +50,10 @@
 //           per chunk: profiles/r02/ab_packed_records_v*.log).  The HEAD floats stay in the lane's
 //           registers and overwrite their (zero) places in the tile after a second barrier.
 //           LDS per workgroup: 32*numel bytes per plane (<= 8 KiB).
-//   ROWS    the same wide rows when the call brings a scratch column (bsx_call_t.row_scratch, ABI v12) and is a single
-//           step: the lane's thread stores the row in PACKED form there — no LDS, no barrier — and a store stream
-//           decodes it into the observation array in a second launch (row_stream.h).
+//   ROWS    the same wide rows when the call brings a scratch (bsx_call_t.row_scratch, ABI v12) and is a single step:
+//           every WAVE builds its 64 lanes' flat bit planes in wave-private LDS — no workgroup barrier — and stores
+//           them into the scratch; a store stream decodes them into the observation array in a second launch
+//           (row_stream.h).
 // A lane's handle on the tile's bit planes.
 struct bsx_bit_sink {
   uint32_t* planes;        // LDS: PLANES x `stride` words
@@ -416,7 +417,7 @@ template <class Env, bool ROLLOUT, int LOG, int NOISE, int MT, bool DIRECT_ARG, 
 __device__ __forceinline__ void small_obs_body(const typename Env::args& a, const int n_steps_arg,
                                                const uint32_t block_id, float* s_obs, unsigned int* s_cnt) {
   constexpr bool ROWS = ROWS_ARG && Env::PACKED && !ROLLOUT;         // wide rows, packed, into the call's row scratch
-  constexpr bool DIRECT = DIRECT_ARG || !Env::PACKED || ROWS;
+  constexpr bool DIRECT = DIRECT_ARG || !Env::PACKED;
   if constexpr (ROLLOUT && Env::HAS_REGS) {
     bsx_reset_pool* pool = nullptr;
     float* rows = nullptr;
@@ -453,23 +454,60 @@ __device__ __forceinline__ void small_obs_body(const typename Env::args& a, cons
   for (int t = 0; t < n_steps; ++t) {
     const int64_t oi = (int64_t)t * B + i;
     int type = -1;
-    if constexpr (DIRECT) {
+    if constexpr (ROWS) {
+      // Wide rows into the call's row scratch (bsx_rows.h) for the store stream of the next launch (row_stream.h): the
+      // advance of the PACKED path below without its workgroup barriers.  Every WAVE keeps its own flat bit planes in
+      // LDS — 64 lanes x numel bits = 2 * numel whole words per plane, LDS serves a wave's accesses in order — which
+      // its lanes OR their bits into and which it then stores as consecutive words of the global planes; the row
+      // elements that are genuine floats go to one f32 column each, the 0.0 / 1.0 HEAD elements of umbrella_chain (need,
+      // has) are plane bits like the distractors.
+      typedef typename Env::rows_t R;
+      const int wl = (int)(threadIdx.x & 63u);
+      const uint32_t wstride = 2u * (uint32_t)numel;                       // words per plane of one wave
+      uint32_t* __restrict__ wplanes = reinterpret_cast<uint32_t*>(s_obs) + (threadIdx.x >> 6) * ((uint32_t)R::PLANES * wstride);
+      for (uint32_t w = (uint32_t)wl; w < (uint32_t)R::PLANES * wstride; w += BSX_WAVE) wplanes[w] = 0u;
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      if (mine) {
+        double reward = 0.0;
+        float o[Env::HEAD];
+        const bsx_bit_sink sink{wplanes, (int)wstride, (uint32_t)(wl * numel + Env::HEAD)};
+        type = Env::template step<LOG, MT, true>(a, i, oi, lane, step0 + (uint64_t)t, o, reward, &sink);
+        bsx_emit_at<LOG, NOISE, F64, MT>(a.ctl, a.out, i, oi, lane, step0 + (uint64_t)t, type, reward);
+        float* __restrict__ heads = reinterpret_cast<float*>(a.rows + (uint64_t)R::PLANES * (uint64_t)a.row_plane_words);
+        uint32_t head_bits = 0u;
+#pragma unroll
+        for (int k = 0; k < Env::HEAD; ++k) {
+          bool is_float = false;
+#pragma unroll
+          for (int q = 0; q < R::NF; ++q)
+            if ((int)bsx_rows_fpos(R::KIND, q) == k) { heads[(int64_t)q * B + i] = o[k]; is_float = true; }
+          if (!is_float) head_bits |= (o[k] != 0.0f ? 1u : 0u) << k;     // (0.0 / 1.0: decode(1) == 1.0f for such a family)
+        }
+        if (R::NF < Env::HEAD) {
+          const bsx_bit_sink hs{wplanes, (int)wstride, (uint32_t)(wl * numel)};
+          hs.put(0, 0, head_bits, Env::HEAD);
+        }
+      }
+      bsx_count_types(a.ctl, type, s_cnt);
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      const int64_t wave_lane0 = lane0 + (int64_t)(threadIdx.x & ~63u);
+      if (wave_lane0 < B) {                                              // (uniform per wave)
+        uint32_t* __restrict__ gp = a.rows + (uint64_t)(wave_lane0 >> 6) * wstride;
+#pragma unroll
+        for (int p = 0; p < R::PLANES; ++p)
+          for (uint32_t w = (uint32_t)wl; w < wstride; w += BSX_WAVE) gp[(uint64_t)p * (uint64_t)a.row_plane_words + w] = wplanes[(uint32_t)p * wstride + w];
+      }
+    } else if constexpr (DIRECT) {
       // the waves of a block (and the steps of a fused rollout) never wait for each other
       if (mine) {
         double reward = 0.0;
         float o[8];
         BSX_LIFE_AFTER_S(2, (uint32_t)step0);                   // the argument slot and the call counter have arrived
-        if constexpr (ROWS) {
-          // the row leaves in packed form — HEAD floats + bit-plane words, <= 48 bytes — for the store stream of the
-          // next launch (row_stream.h); o[0 .. HEAD) are the HEAD floats
-          uint32_t* __restrict__ row = a.rows + (uint64_t)i * (uint32_t)a.row_words;
-          const bsx_row_sink sink{row + Env::HEAD, (uint32_t)a.row_w};
-          type = Env::template step<LOG, MT, true>(a, i, oi, lane, step0 + (uint64_t)t, o, reward, &sink);
-#pragma unroll
-          for (int k = 0; k < Env::HEAD; ++k) row[k] = __float_as_uint(o[k]);
-        } else {
-          type = Env::template step<LOG, MT>(a, i, oi, lane, step0 + (uint64_t)t, o, reward);
-        }
+        type = Env::template step<LOG, MT>(a, i, oi, lane, step0 + (uint64_t)t, o, reward);
         BSX_LIFE_AFTER_V(4, type);                              // loads + arithmetic (+ the state stores issued)
         bsx_emit_at<LOG, NOISE, F64, MT>(a.ctl, a.out, i, oi, lane, step0 + (uint64_t)t, type, reward);
         // (row-per-lane stores also in a big launch: staging the rows like the fused rollout does left the eager step
@@ -477,7 +515,7 @@ __device__ __forceinline__ void small_obs_body(const typename Env::args& a, cons
         // profiles/r03/ab_eager_rows_via_lds.log: one memory round trip per launch bounds it, not the write requests;
         // pooled resets in the eager step: 17.6 -> 19.1-19.6 us, the barriers wait for the slowest wave's loads,
         // profiles/r03/ab_eager_pooled_resets.log)
-        if constexpr (!ROWS) small_obs_store_row(a.out.observation + oi * (int64_t)numel, o, numel);
+        small_obs_store_row(a.out.observation + oi * (int64_t)numel, o, numel);
       }
       bsx_count_types(a.ctl, type, s_cnt);
     } else {
@@ -641,20 +679,25 @@ static size_t small_obs_lds(const typename Env::args& a) {
     return bsx_small_direct_shape(a.obs_numel) ? 0 : (size_t)(Env::PLANES + 1) * a.obs_numel * (BSX_BLOCK / 32) * 4 + (size_t)(BSX_BLOCK * Env::HEAD + 8) * 4;
   else return 0;
 }
-// does a single-step call of this segment take the row path (packed rows into a.rows + the wide-row store stream)?
+// does a single-step call of this segment take the row path (flat bit planes into a.rows + the wide-row store stream)?
 template <class Env>
 static bool small_obs_rows(const typename Env::args& a) {
   if constexpr (Env::PACKED) return a.rows != nullptr && !bsx_small_direct_shape(a.obs_numel);
   else return false;
+}
+// dynamic LDS of one workgroup on the row path: every wave's own PLANES x 2 * numel plane words
+template <class Env>
+static size_t small_obs_rows_lds(const typename Env::args& a) {
+  if constexpr (Env::PACKED) return (size_t)(BSX_BLOCK / BSX_WAVE) * Env::PLANES * 2 * (size_t)a.obs_numel * 4;
+  else return 0;
 }
 // the arguments of the wide-row store stream of a segment on the row path
 template <class Env>
 static bsx_row_seg small_obs_row_seg(const typename Env::args& a) {
   bsx_row_seg g{};
   if constexpr (Env::PACKED) {
-    g.obs = a.out.observation; g.rows = a.rows; g.n_lanes = a.ctl.n_lanes; g.numel = (uint32_t)a.obs_numel;
-    g.numel_magic = bsx_div_magic(g.numel); g.dv = bsx_make_div64(g.numel);
-    g.row_words = (uint32_t)a.row_words; g.w_words = (uint32_t)a.row_w;
+    g.obs = a.out.observation; g.planes = a.rows; g.n_lanes = a.ctl.n_lanes; g.plane_words = (uint64_t)a.row_plane_words;
+    g.numel = (uint32_t)a.obs_numel; g.numel_magic = bsx_div_magic(g.numel); g.dv = bsx_make_div64(g.numel);
   }
   return g;
 }
@@ -738,7 +781,7 @@ static int small_obs_group_put(bsx_group* g, int32_t family, int32_t index, cons
       // wide rows with a row scratch: phase 0 leaves them packed, the phase-1 store stream writes the observations
       const bsx_row_seg sg = small_obs_row_seg<Env>(a);
       return bsx_mixed_put(g, family, index, call, &a, sizeof(a), &sg, sizeof(sg), nb,
-                           bsx_flat_blocks((uint64_t)a.ctl.n_lanes * sg.numel, BSX_ROW_STREAM_K), 0);
+                           bsx_flat_blocks((uint64_t)a.ctl.n_lanes * sg.numel, BSX_ROW_STREAM_K), small_obs_rows_lds<Env>(a));
     }
     return bsx_mixed_put(g, family, index, call, &a, sizeof(a), nullptr, 0, nb, 0, small_obs_lds<Env>(a));   // phase 0 only
   }
@@ -856,8 +899,9 @@ static int launch_small_obs(const typename Env::args& a, int n_steps, void* hip_
       if (n_steps == 1 && small_obs_rows<Env>(a)) {
         // wide rows, a single step, a row scratch: lane advance (rows packed into the scratch) + the store stream
         // that decodes them (row_stream.h) instead of the one launch with the LDS bit planes and its three barriers
-        if (lean) small_obs_kernel<Env, false, 0, 0, 0, true, true><<<g, b, 0, st>>>(a, 1);
-        else small_obs_kernel<Env, false, -1, -1, -1, true, true><<<g, b, 0, st>>>(a, 1);
+        const size_t rlds = small_obs_rows_lds<Env>(a);
+        if (lean) small_obs_kernel<Env, false, 0, 0, 0, true, true><<<g, b, rlds, st>>>(a, 1);
+        else small_obs_kernel<Env, false, -1, -1, -1, true, true><<<g, b, rlds, st>>>(a, 1);
         const bsx_row_seg sg = small_obs_row_seg<Env>(a);
         static const int row_k = bsx_env_int("BSX_ROW_STREAM_K", BSX_ROW_STREAM_K);
         const int k = row_k == 1 || row_k == 4 ? row_k : 2;
@@ -912,7 +956,7 @@ struct memory_chain_env {
   struct args {
     bsx_ctl ctl; const int32_t* action; int32_t* state; uint64_t* context; bsx_timestep_t out;
     double* info; int32_t obs_numel; int32_t L; int32_t nb; uint32_t numel_magic;
-    uint32_t* rows; int32_t row_words; int32_t row_w;          // bsx_call_t.row_scratch (row_stream.h), or nullptr
+    uint32_t* rows; int64_t row_plane_words;                   // bsx_call_t.row_scratch (bsx_rows.h) + words per plane, or nullptr
   };
   // Packed rows: HEAD = [time, query]; element 2+b is 0 unless t == 0, then +-1 by context bit b: plane 0 says
   // "non-zero", plane 1 carries the context bit (memory_rows, row_stream.h).
@@ -988,7 +1032,7 @@ struct umbrella_chain_env {
   struct args {
     bsx_ctl ctl; const int32_t* action; int32_t* state; bsx_timestep_t out; double* info;
     int32_t obs_numel; int32_t L; int32_t nd; uint32_t numel_magic;
-    uint32_t* rows; int32_t row_words; int32_t row_w;          // bsx_call_t.row_scratch (row_stream.h), or nullptr
+    uint32_t* rows; int64_t row_plane_words;                   // bsx_call_t.row_scratch (bsx_rows.h) + words per plane, or nullptr
   };
   // Packed rows: HEAD = [need, has, time]; element 3+b is distractor bit b as 0.0 / 1.0 (one plane; umbrella_rows).
   typedef umbrella_rows rows_t;

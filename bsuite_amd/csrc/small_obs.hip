@@ -14,24 +14,22 @@
 // caller that buckets segments by class keeps working).
 extern "C" int bsx_group_small_class(int32_t numel) { (void)numel; return BSX_BLOCK; }
 
-// Words per lane of bsx_call_t.row_scratch (row_stream.h): 0 = no row path for this family / row length.
-extern "C" int32_t bsx_row_scratch_words(int32_t family, int32_t obs_numel) {
-  if (obs_numel < 1 || obs_numel > 256 || bsx_small_direct_shape(obs_numel)) return 0;
-  if (family == BSX_FAM_MEMORY_CHAIN) return bsx_row_words_of(obs_numel, BSX_ROWS_MEMORY);
-  if (family == BSX_FAM_UMBRELLA_CHAIN) return bsx_row_words_of(obs_numel, BSX_ROWS_UMBRELLA);
+// Bytes of bsx_call_t.row_scratch for n_lanes lanes (bsx_rows.h): 0 = no row path for this family / row length.
+extern "C" int64_t bsx_row_scratch_bytes(int32_t family, int32_t obs_numel, int64_t n_lanes) {
+  if (obs_numel < 1 || obs_numel > 256 || n_lanes < 1 || n_lanes > ((int64_t)1 << 40) || bsx_small_direct_shape(obs_numel)) return 0;
+  if (family == BSX_FAM_MEMORY_CHAIN) return (int64_t)(4 * bsx_rows_scratch_words(BSX_ROWS_MEMORY, n_lanes, obs_numel));
+  if (family == BSX_FAM_UMBRELLA_CHAIN) return (int64_t)(4 * bsx_rows_scratch_words(BSX_ROWS_UMBRELLA, n_lanes, obs_numel));
   return 0;
 }
 
 // The row path of a chain segment: the call's scratch, if it brings one and the row is wide.
 template <class Env>
 static int chain_rows(const bsx_call_t* call, int32_t family, typename Env::args* a) {
-  a->rows = nullptr; a->row_words = 0; a->row_w = 0;
-  const int32_t words = bsx_row_scratch_words(family, a->obs_numel);
-  if (call->row_scratch == nullptr || words == 0) return 0;
+  a->rows = nullptr; a->row_plane_words = 0;
+  if (call->row_scratch == nullptr || call->n_lanes < 1 || bsx_row_scratch_bytes(family, a->obs_numel, call->n_lanes) == 0) return 0;
   if ((reinterpret_cast<uintptr_t>(call->row_scratch) & 15u) != 0) return BSX_EALIGN;
-  if (call->n_lanes * (int64_t)words >= ((int64_t)1 << 40)) return BSX_EINVAL;
-  a->rows = (uint32_t*)call->row_scratch; a->row_words = words;
-  a->row_w = bsx_row_plane_words(a->obs_numel, Env::rows_t::KIND);
+  a->rows = (uint32_t*)call->row_scratch;
+  a->row_plane_words = (int64_t)bsx_rows_plane_words(call->n_lanes, a->obs_numel);
   return 0;
 }
 

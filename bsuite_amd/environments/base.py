@@ -247,9 +247,9 @@ class Environment(dm_env.EnvironmentBase):
         self._state['state'] = own
 
   def _row_scratch_words(self) -> int:
-    """uint32 words per lane of this family's row scratch (bsx_row_scratch_words), 0 = the family has no row path."""
+    """uint32 words of this environment's row scratch (bsx_row_scratch_bytes / 4), 0 = the family has no row path."""
     fam = _native.FAMILY_IDS.get(self._abi_name, -1)
-    return int(_native.lib.bsx_row_scratch_words(fam, int(np.prod(self._obs_shape)))) if fam >= 0 else 0
+    return int(_native.lib.bsx_row_scratch_bytes(fam, int(np.prod(self._obs_shape)), self._batch)) // 4 if fam >= 0 else 0
 
   def _row_scratch(self, fresh: bool = False) -> Optional[torch.Tensor]:
     """The row scratch of this environment (allocated on first use; contents are irrelevant between calls), or a
@@ -259,7 +259,7 @@ class Environment(dm_env.EnvironmentBase):
       return None
     if fresh or self._rows is None:
       with torch.cuda.device(self._device):
-        t = torch.empty(self._batch * words, dtype=torch.int32, device=self._device)
+        t = torch.empty(words, dtype=torch.int32, device=self._device)
       if fresh:
         return t
       self._rows = t

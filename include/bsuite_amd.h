@@ -190,17 +190,17 @@ typedef struct {
                                BSX_EINVAL; with n_steps > 1 or obs_paint: BSX_EMODE.                 */
   int32_t flags;            /* BSX_CALL_* bits (ABI v11; was padding, 0 = the v10 behaviour)                  */
   void* row_scratch;        /* device or NULL (ABI v12), memory_chain / umbrella_chain with an observation row of more
-                               than 8 floats: n_lanes x bsx_row_scratch_words(family, obs_numel) uint32, 16-byte
-                               aligned, contents irrelevant between calls.  With it a single step()/reset() call is
-                               lane advance + store stream, like deep_sea / catch: every lane's thread leaves its row
-                               PACKED in the scratch (the HEAD floats + one or two bit planes, <= 48 bytes) and a
-                               barrier-free store stream decodes it into `out.observation` (csrc/row_stream.h) — at
-                               2^20 lanes faster than the one launch that builds the rows as bit planes in LDS
-                               (three workgroup barriers per step), which NULL selects and which rollouts
-                               (n_steps > 1) always take.  In a BSX_FAM_SWEEP_MIXED group such a segment's rows are
-                               decoded by the phase-1 store stream; the two groups of a pipelined pair must bring
-                               DIFFERENT scratches (bsx_group_step_pipelined: BSX_EMODE); the single-launch groups
-                               ignore it.  Ignored by the other families and by short rows.                     */
+                               than 8 floats: bsx_row_scratch_bytes(family, obs_numel, n_lanes) bytes, 16-byte aligned,
+                               contents irrelevant between calls.  With it a single step()/reset() call is lane advance
+                               + store stream, like deep_sea / catch: every wave of the advance leaves its 64 lanes'
+                               rows in the scratch as FLAT BIT PLANES (bit e of a plane = element e of the observation
+                               array; the genuine floats of a row in one f32 column each: csrc/bsx_rows.h) and a
+                               barrier-free store stream decodes them into `out.observation` (csrc/row_stream.h).
+                               NULL selects the one launch that builds the rows as bit planes in LDS (three workgroup
+                               barriers per step), which rollouts (n_steps > 1) always take.  In a BSX_FAM_SWEEP_MIXED
+                               group such a segment's rows are decoded by the phase-1 store stream; the two groups of
+                               a pipelined pair must bring DIFFERENT scratches (bsx_group_step_pipelined: BSX_EMODE);
+                               the single-launch groups ignore it.  Ignored by the other families and by short rows. */
 } bsx_call_t;
 
 /* bsx_call_t.flags */
@@ -500,10 +500,11 @@ int bsx_abi_version(void);
  * episode_return.  Asynchronous on hip_stream like every entry point; info_out may not alias info. */
 int bsx_bsuite_info(int32_t family, int32_t variant, int64_t n_lanes, const int32_t* state, const double* info,
                     int32_t n_info, int32_t folded, double* info_out, void* hip_stream);
-/* uint32 words per lane of bsx_call_t.row_scratch for a `family` (BSX_FAM_*) observation row of `obs_numel` floats:
- * HEAD floats + bit-plane words, rounded up to 4 (memory_chain: 2 + 2*ceil(nb/32); umbrella_chain: 3 + ceil(nd/32));
- * 0 = this family / row length has no row path (the scratch would be ignored). */
-int32_t bsx_row_scratch_words(int32_t family, int32_t obs_numel);
+/* Bytes of bsx_call_t.row_scratch for `n_lanes` lanes of a `family` (BSX_FAM_*) observation row of `obs_numel` floats:
+ * PLANES bit planes of ceil(n_lanes / 64) * 2 * obs_numel uint32 (memory_chain 2, umbrella_chain 1) + one f32 column
+ * [n_lanes] per genuine float of the row (memory_chain 2: time, query; umbrella_chain 1: time).  0 = this family / row
+ * length has no row path (the scratch would be ignored). */
+int64_t bsx_row_scratch_bytes(int32_t family, int32_t obs_numel, int64_t n_lanes);
 const char* bsx_strerror(int code);
 /* Pure-store calibration: writes n_bytes of zeros with the same 16-B cooperative pattern the
  * observation writers use; the measured rate is the practical ceiling for store-bound families. */

@@ -150,7 +150,7 @@ int main(void) {
     for (i = 0; i < B; ++i) EXPECT(h_cinfo_out[i] == h_info[i]);
     EXPECT(bsx_bsuite_info(BSX_FAM_CATCH, 0, B, NULL, d_cinfo, 1, 1, d_cinfo_out, NULL) == BSX_ENULL);
     EXPECT(bsx_bsuite_info(99, 0, B, d_state, d_cinfo, 1, 1, d_cinfo_out, NULL) == BSX_EINVAL);
-    EXPECT(bsx_row_scratch_words(BSX_FAM_UMBRELLA_CHAIN, 23) == 4 && bsx_row_scratch_words(BSX_FAM_CATCH, 50) == 0);
+    EXPECT(bsx_row_scratch_bytes(BSX_FAM_UMBRELLA_CHAIN, 23, 64) == 4 * (2 * 23 + 64) && bsx_row_scratch_bytes(BSX_FAM_CATCH, 50, 64) == 0);
   }
   printf("abi_host_demo: ok (%d lanes x %d calls of deep_sea N=%d, catch total_regret via bsx_bsuite_info, through the C ABI)\n", B, N + 2, N);
   return 0;

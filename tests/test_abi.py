@@ -95,7 +95,7 @@ def test_argument_errors_without_touching_the_gpu():
   call.row_scratch = 24
   assert lib.bsx_umbrella_chain_step(ctypes.byref(uc), ctypes.byref(call), 16, 16, uout, 16) == -3   # BSX_EALIGN
   call.row_scratch = None
-  assert lib.bsx_row_scratch_words(_native.FAMILY_IDS['umbrella_chain'], 23) == 4
+  assert lib.bsx_row_scratch_bytes(_native.FAMILY_IDS['umbrella_chain'], 23, 64) == 4 * (2 * 23 + 64)
   assert lib.bsx_bsuite_info(_native.FAMILY_IDS['catch'], 0, 8, None, 16, 1, 1, 16, None) == -2      # pending part needs the state column
   assert lib.bsx_bsuite_info(_native.FAMILY_IDS['catch'], 0, 0, None, None, 1, 1, None, None) == 0  # empty batch
   assert lib.bsx_bsuite_info(12, 0, 8, 16, 16, 1, 1, 16, None) == -1

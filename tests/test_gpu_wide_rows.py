@@ -1,6 +1,7 @@
 """GPU: the wide observation rows of memory_chain / umbrella_chain on the ROW path (ABI v12, bsx_call_t.row_scratch;
 csrc/row_stream.h, csrc/bsx_rows.h): the lane's thread leaves its row packed in a scratch column and a barrier-free
-store stream decodes it — against the C oracle, bit-exact, at every row shape class (one / two / several bit words,
+store stream decodes it (round 5, second form: every wave of the advance builds its 64 lanes' FLAT bit planes in
+wave-private LDS, csrc/bsx_rows.h) — against the C oracle, bit-exact, at every row shape class (one / two / several bit words,
 rows that are and are not multiples of 16 bytes, the widest rows the ABI takes), ragged / one-lane / several-thousand-lane
 batches with a 64-bit lane offset, explicit reset() calls, both reward wrappers, the Logging wrapper, the MT19937-exact
 mode and a captured HIP graph; equal, call for call, to the one-launch LDS path the same environment takes without a
@@ -192,7 +193,7 @@ def test_c_abi_checks_the_scratch():
   raw = eu.raw(env)
   raw._ensure_allocated()
   scratch = raw._row_scratch()
-  assert scratch.numel() == 512 * _native.lib.bsx_row_scratch_words(_native.FAMILY_IDS['umbrella_chain'], 23)
+  assert scratch.numel() * 4 == _native.lib.bsx_row_scratch_bytes(_native.FAMILY_IDS['umbrella_chain'], 23, 512) == 4 * (8 * 46 + 512)
   raw._call_desc.row_scratch = scratch.data_ptr() + 4             # not 16-byte aligned
   with pytest.raises(RuntimeError, match='aligned'):
     env.step(torch.zeros(512, dtype=torch.int32, device='cuda'))
@@ -217,7 +218,9 @@ def test_sweep_rows_in_the_store_stream_equal_rows_built_in_phase0(pipelined, la
     acts = batch.random_actions(seed=3, ring=4)
     o = batch.prepare_groups(acts, pipelined=pipelined, rows_in_stream=rows_in_stream)
     n_stream = sum(1 for v in batch._row_scratch.values() if v is not None)
-    assert n_stream == ((9 * (2 if pipelined else 1)) if rows_in_stream else 0)      # memory_len/6 has a 3-float row
+    wide = sum(1 for e in batch.envs if eu.raw(e)._abi_name in ('memory_chain', 'umbrella_chain') and np.prod(e.observation_spec().shape) > 8)
+    assert wide == 7                                                                  # (memory_len/6, memory_size/2, umbrella_distract/3: short rows)
+    assert n_stream == ((wide * (2 if pipelined else 1)) if rows_in_stream else 0)
     for _ in range(reps):
       last = batch.step_grouped()
     batch.sync()
