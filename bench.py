@@ -678,7 +678,8 @@ class Rank:
                             for e, (_, _, l) in zip(batch.envs, batch.segments)))
     timed = {}
     for name, pipelined in (('closed', False), ('split', False), ('pipelined', True)):
-      batch.prepare_groups(acts, pipelined=pipelined, rows_in_stream=(self.args.row_path != 'off'), split=(name == 'split'))
+      batch.prepare_groups(acts, pipelined=pipelined, rows_in_stream=(None if self.args.row_path == 'auto' else self.args.row_path == 'on'),
+                           split=(name == 'split'))
 
       def run(n):
         for _ in range(n):
@@ -733,7 +734,7 @@ class Rank:
     if args.row_path != 'auto':
       # A/B of the chains' wide rows: lane advance + store stream (bsx_call_t.row_scratch) for every batch / never
       from bsuite_amd.environments import base as _base
-      _base.Environment.row_path_min_bytes = 0 if args.row_path == 'on' else 1 << 62
+      _base.Environment.row_path_min_bytes = 0 if args.row_path == 'on' else None
     if args.workload == 'sweep':
       rec = self.measure_sweep(args.lanes, args.steps, args.warmup)
       if self.rank == 0:
@@ -869,9 +870,9 @@ def main():
                   help="'delta' (deep_sea, catch): persistent observation buffers patched in place; a "
                        'separate mode with its own byte accounting, NOT the dense contract of the headline')
   ap.add_argument('--row-path', default='auto', choices=['auto', 'on', 'off'],
-                  help="memory_chain / umbrella_chain rows of more than 8 floats: 'auto' = lane advance + store stream "
-                       "(bsx_call_t.row_scratch) from 8 MiB of observations per step and in the sweep group; 'off' = "
-                       'always the one-launch LDS bit planes (A/B)')
+                  help="memory_chain / umbrella_chain rows of more than 8 floats: 'on' = lane advance + wide-row store stream "
+                       "(bsx_call_t.row_scratch), also for the sweep group's segments; 'auto' / 'off' = the product default, "
+                       'the one-launch LDS bit planes (A/B: measured faster)')
   ap.add_argument('--rollout', type=int, default=0,
                   help='advance this many steps per entry-point call with env.rollout(actions[T,B]) '
                        '(fused T-step kernel for the small-observation families)')

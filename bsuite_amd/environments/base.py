@@ -65,10 +65,14 @@ class Environment(dm_env.EnvironmentBase):
   scalar_host_buffers = True   # scalar view: TimeStep / action buffers in pinned host memory mapped into the device (class
                                # attribute: set False before the first step to A/B against device buffers + read-backs)
   # memory_chain / umbrella_chain with a row of more than 8 floats: from this many bytes of observations per step() a call
-  # brings a row scratch (bsx_call_t.row_scratch) and is lane advance + store stream instead of the one launch that builds
-  # the rows in LDS (csrc/row_stream.h); below it the second launch costs more than the barriers it removes.  Segments of
-  # a whole-sweep group always bring one (their store stream is the group's).
-  row_path_min_bytes = 8 << 20
+  # brings a row scratch (bsx_call_t.row_scratch) and is lane advance + wide-row store stream (csrc/row_stream.h) instead
+  # of the one launch that builds the rows as bit planes in LDS.  None = never, the default: measured in both of its
+  # forms in round 5, the pair path loses to the one launch at every size (2^20 lanes: umbrella_length 35.7 vs 31.0 us,
+  # umbrella_distract 100-106 vs 97.3, memory_size 50.8 vs 44.9; profiles/r05/ab_wide_rows_v2_flat_planes.log) — its
+  # lane advance alone takes 18 us (4096 workgroups of Philox + an f64 division, 3.5 waves per SIMD), as long as the
+  # one launch needs for advance AND stores once other workgroups' stores hide behind it.  Kept as an option (tests,
+  # A/B: bench.py --row-path on).
+  row_path_min_bytes = None
   _rows = None
   _info_keys = ()          # names of the f64 info columns, in native column order
   _info_int_keys = ()      # keys the reference reports as Python ints
@@ -361,7 +365,7 @@ class Environment(dm_env.EnvironmentBase):
         counters=self._counters.data_ptr(), hip_stream=None)
     if self._reward_f64 is not None:
       self._call_desc.reward_f64 = self._reward_f64.data_ptr()
-    if (not self._scalar and self._row_scratch_words()
+    if (not self._scalar and self.row_path_min_bytes is not None and self._row_scratch_words()
         and B * int(np.prod(self._obs_shape)) * 4 >= self.row_path_min_bytes):
       self._call_desc.row_scratch = self._row_scratch().data_ptr()
     if self._wrap_mt_seeds is not None:

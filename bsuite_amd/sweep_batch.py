@@ -63,8 +63,12 @@ def assign_segments(costs: Sequence[float], world_size: int) -> List[int]:
 
 
 # The closed-loop schedule `prepare_groups()` / `step_grouped()` run by default: False = phase 0 | store stream
-# (bsx_group_step), True = the split cut of the same two launches (bsx_group_step_split).
-DEFAULT_SPLIT = False
+# (bsx_group_step), True = the split cut of the same two launches (bsx_group_step_split): 2.8-4.5 us per
+# sweep step faster in every same-call comparison of round 5 (profiles/r05/ab_sweep_v1.log, ab_sweep_v2.log).
+# DEFAULT_ROWS_IN_STREAM: the chains' wide rows written by the group's store stream instead of phase 0 (measured
+# 0.8-2 us SLOWER per sweep step in both of its forms, same logs: off).
+DEFAULT_SPLIT = True
+DEFAULT_ROWS_IN_STREAM = False
 
 
 class SweepBatch:
@@ -167,7 +171,7 @@ class SweepBatch:
   # -- grouped launches --------------------------------------------------------------------
   def prepare_groups(self, actions: Sequence[torch.Tensor], mix_small: bool = True, mix_pairs: bool = True,
                      mix_all: bool = True, pipelined: bool = False, heavy_first: bool = True,
-                     rows_in_stream: bool = True, split: Optional[bool] = None):
+                     rows_in_stream: Optional[bool] = None, split: Optional[bool] = None):
     """Builds the launch groups.  With `mix_all` (default) ONE group for the whole sweep
     (BSX_FAM_SWEEP_MIXED): a sweep step is two launches — phase 0 advances every lane of every family
     and bumps the shared call counter, phase 1 is the observation store stream of the two-kernel
@@ -179,9 +183,9 @@ class SweepBatch:
     argument tables.  Returns the per-segment output TimeSteps (tensors that every `step_grouped()`
     overwrites).
 
-    `rows_in_stream` (with `mix_all`; False: A/B): the wide rows of memory_chain / umbrella_chain segments are left
-    packed by phase 0 and written by the phase-1 store stream (bsx_call_t.row_scratch) instead of being built as bit
-    planes in LDS by phase 0 itself.
+    `rows_in_stream` (with `mix_all`; default DEFAULT_ROWS_IN_STREAM = False): the wide rows of memory_chain /
+    umbrella_chain segments are left as flat bit planes in a scratch by phase 0 and written by the phase-1 store stream
+    (bsx_call_t.row_scratch) instead of being built and written by phase 0 itself.
 
     `split` (with `mix_all`, closed-loop): `step_grouped()` cuts the two launches differently (bsx_group_step_split) —
     launch 1 = only the phase-0 workgroups the store stream depends on (lane advance of deep_sea / mnist / large catch
@@ -202,6 +206,7 @@ class SweepBatch:
     from bsuite_amd import _native  # pylint: disable=import-outside-toplevel
     from bsuite_amd import dm_env_compat as dm_env  # pylint: disable=import-outside-toplevel
     self.release_groups()
+    rows_in_stream = DEFAULT_ROWS_IN_STREAM if rows_in_stream is None else bool(rows_in_stream)
     torch.cuda.set_device(self.device)       # the argument tables are allocated on the current device
     buckets = {}
     for k, env in enumerate(self.envs):

@@ -189,9 +189,12 @@ def test_mnist_full_batch():
 
 @pytest.mark.parametrize('family,kwargs', [('umbrella_chain', dict(chain_length=12, n_distractor=20)),      # umbrella_length/10
                                            ('memory_chain', dict(memory_length=2, num_bits=40))])           # memory_size/16
-def test_wide_rows_full_batch(family, kwargs):
-  """The chains' wide rows at 2^20 lanes (lane advance + wide-row store stream, the benched path): a subsample against
-  the oracle bit for bit on every call across two episode ends."""
+@pytest.mark.parametrize('row_path', [False, True])
+def test_wide_rows_full_batch(family, kwargs, row_path, monkeypatch):
+  """The chains' wide rows at 2^20 lanes — the one launch with the LDS bit planes (the benched path) and the opt-in lane
+  advance + wide-row store stream: a subsample against the oracle bit for bit on every call across two episode ends."""
+  from bsuite_amd.environments import base
+  monkeypatch.setattr(base.Environment, 'row_path_min_bytes', 0 if row_path else None)
   T, seed = 30 if family == 'umbrella_chain' else 9, 17
   env = eu.make_env(family, kwargs, batch=B, lane_offset=0, seed=seed, num_buffers=1)
   rng = np.random.default_rng(6)
@@ -207,6 +210,6 @@ def test_wide_rows_full_batch(family, kwargs):
     np.testing.assert_array_equal(eu.f32_bits(ts.observation[idx_t].cpu().numpy()), eu.f32_bits(oo), err_msg=f'obs t={t}')
     live = ost != 0
     np.testing.assert_array_equal(ts.reward[idx_t].cpu().numpy()[live], orr[live].astype(np.float32))
-  assert bool(eu.raw(env)._call_desc.row_scratch)
+  assert bool(eu.raw(env)._call_desc.row_scratch) == row_path
   for k, v in orc.bsuite_info().items():
     np.testing.assert_array_equal(env.bsuite_info()[k][idx_t].cpu().numpy(), v, err_msg=k)

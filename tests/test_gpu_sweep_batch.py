@@ -73,7 +73,7 @@ def test_sweep_rank_assignment_is_a_partition():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize('mode', ['whole_sweep', 'whole_sweep_split', 'whole_sweep_pipelined', 'whole_sweep_graph', 'eager', 'streams', 'graph', 'graph_phased', 'per_family',
+@pytest.mark.parametrize('mode', ['whole_sweep', 'whole_sweep_split', 'whole_sweep_split_rows', 'whole_sweep_pipelined', 'whole_sweep_graph', 'eager', 'streams', 'graph', 'graph_phased', 'per_family',
                                   'pairs_per_family'])
 def test_grouped_sweep_equals_standalone_envs(tmp_path, mode):
   """One grouped launch per family advances every segment exactly like its standalone environment
@@ -91,8 +91,9 @@ def test_grouped_sweep_equals_standalone_envs(tmp_path, mode):
   acts = batch.random_actions(seed=2)
   outs = batch.prepare_groups(acts, mix_small=(mode != 'per_family'), mix_pairs=(mode not in ('per_family', 'pairs_per_family')),
                               mix_all=mode.startswith('whole_sweep'), pipelined=(mode == 'whole_sweep_pipelined'),
-                              split=(mode == 'whole_sweep_split'))
-  assert batch._split == (mode == 'whole_sweep_split')
+                              split=mode.startswith('whole_sweep_split'), rows_in_stream=(mode == 'whole_sweep_split_rows'))
+  assert batch._split == mode.startswith('whole_sweep_split')
+  assert any(v is not None for v in batch._row_scratch.values()) == (mode == 'whole_sweep_split_rows')
   ahead = 0
   if mode == 'whole_sweep_pipelined':
     # two groups (state columns swapped, own TimeStep buffers) alternate: ONE launch per sweep step carries

@@ -106,7 +106,10 @@ def _stepped(env):
   return env
 
 
-def test_threshold_by_bytes():
+def test_threshold_by_bytes(monkeypatch):
+  assert base.Environment.row_path_min_bytes is None                       # the product default: never (measured slower)
+  assert not _on_row_path(_stepped(bsuite_amd.load_from_id('umbrella_length/10', batch=1 << 17, seed=1)))
+  monkeypatch.setattr(base.Environment, 'row_path_min_bytes', 8 << 20)
   small = _stepped(bsuite_amd.load_from_id('umbrella_length/10', batch=4096, seed=1))                # 92 B x 4096 < 8 MiB
   assert not _on_row_path(small)
   big = _stepped(bsuite_amd.load_from_id('umbrella_length/10', batch=1 << 17, seed=1))              # 12 MB
@@ -216,7 +219,7 @@ def test_sweep_rows_in_the_store_stream_equal_rows_built_in_phase0(pipelined, la
   for rows_in_stream in (True, False):
     batch = sb.SweepBatch(IDS, total, seed=seed)
     acts = batch.random_actions(seed=3, ring=4)
-    o = batch.prepare_groups(acts, pipelined=pipelined, rows_in_stream=rows_in_stream)
+    o = batch.prepare_groups(acts, pipelined=pipelined, rows_in_stream=rows_in_stream, split=False)
     n_stream = sum(1 for v in batch._row_scratch.values() if v is not None)
     wide = sum(1 for e in batch.envs if eu.raw(e)._abi_name in ('memory_chain', 'umbrella_chain') and np.prod(e.observation_spec().shape) > 8)
     assert wide == 7                                                                  # (memory_len/6, memory_size/2, umbrella_distract/3: short rows)

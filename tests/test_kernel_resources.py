@@ -46,10 +46,10 @@ BUDGET = {
     # config 5: the whole sweep as one launch group
     'sweep_phase0_kernel': 64,
     'sweep_pipelined_kernel': 64,
-    'pair_mixed_stream_kernel': 64,      # (8 x 16-byte chunks per thread in its mnist half, table-free pixel values: 60)
-    # the chains' wide rows: lane advance (rows packed into the scratch) + the wide-row store stream
-    'small_obs_kernel<umbrella_chain_env, false, 0, 0, 0, true, true>': 40,
-    'small_obs_kernel<memory_chain_env, false, 0, 0, 0, true, true>': 40,
+    'pair_mixed_stream_kernel': 32,
+    # the chains' wide rows, opt-in pair path: lane advance (flat bit planes into the scratch) + the wide-row store stream
+    'small_obs_kernel<umbrella_chain_env, false, 0, 0, 0, true, true>': 64,
+    'small_obs_kernel<memory_chain_env, false, 0, 0, 0, true, true>': 64,
     'bsx_row_stream_kernel<umbrella_rows, 2>': 32,
     'bsx_row_stream_kernel<memory_rows, 2>': 32,
     'small_obs_mixed_group_kernel': 80,
