@@ -677,7 +677,10 @@ class Rank:
     local_bytes = float(sum(l * sb.bytes_per_step(int(np.prod(e.observation_spec().shape)))
                             for e, (_, _, l) in zip(batch.envs, batch.segments)))
     timed = {}
+    only = getattr(self.args, 'sweep_schedule', 'all')            # (profiling passes time ONE schedule: its kernels' dispatches then are its own)
     for name, pipelined in (('closed', False), ('split', False), ('pipelined', True)):
+      if only not in ('all', name):
+        continue
       batch.prepare_groups(acts, pipelined=pipelined, rows_in_stream=(None if self.args.row_path == 'auto' else self.args.row_path == 'on'),
                            split=(name == 'split'))
 
@@ -705,6 +708,15 @@ class Rank:
     main, other = ('split', 'closed') if sb.DEFAULT_SPLIT else ('closed', 'split')
     modes = {'closed': 'closed-loop, 2 launches/step: phase 0 | store stream',
              'split': 'closed-loop, 2 launches/step: advance of the stream families | store stream + small families'}
+    if only != 'all':
+      wall, step_ms = timed[only]
+      rec = {'value': total_lanes * steps / wall, 'ms_per_step': wall / steps * 1e3, 'steps': steps,
+             'mode': modes.get(only, 'open-loop, 1 launch/step'), 'global_lanes': int(total_lanes),
+             'segments_per_rank': [int(x) for x in g[:, 2].tolist()], 'action_ring': ring, 'alg_bytes_busiest_rank': max_rank_bytes,
+             'roofline': roof(step_ms, tr['sweep_' + only]), 'pipelined': {'open_loop': True}, 'episodes_finished': float(g[:, 3].sum())}
+      del batch, acts
+      torch.cuda.empty_cache()
+      return rec
     (wall, step_ms), (wall_o, step_ms_o), (wall_p, step_ms_p) = timed[main], timed[other], timed['pipelined']
     rec = {'value': total_lanes * steps / wall, 'ms_per_step': wall / steps * 1e3, 'steps': steps, 'mode': modes[main],
            'global_lanes': int(total_lanes), 'segments_per_rank': [int(x) for x in g[:, 2].tolist()], 'action_ring': ring,
@@ -869,6 +881,8 @@ def main():
   ap.add_argument('--observation-mode', default='dense', choices=['dense', 'delta'],
                   help="'delta' (deep_sea, catch): persistent observation buffers patched in place; a "
                        'separate mode with its own byte accounting, NOT the dense contract of the headline')
+  ap.add_argument('--sweep-schedule', default='all', choices=['all', 'closed', 'split', 'pipelined'],
+                  help='--workload sweep: time this schedule only (profiling passes); the default times all three')
   ap.add_argument('--row-path', default='auto', choices=['auto', 'on', 'off'],
                   help="memory_chain / umbrella_chain rows of more than 8 floats: 'on' = lane advance + wide-row store stream "
                        "(bsx_call_t.row_scratch), also for the sweep group's segments; 'auto' / 'off' = the product default, "

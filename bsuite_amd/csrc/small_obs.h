@@ -418,7 +418,8 @@ __device__ __forceinline__ void small_obs_body(const typename Env::args& a, cons
                                                const uint32_t block_id, float* s_obs, unsigned int* s_cnt) {
   constexpr bool ROWS = ROWS_ARG && Env::PACKED && !ROLLOUT;         // wide rows, packed, into the call's row scratch
   constexpr bool DIRECT = DIRECT_ARG || !Env::PACKED;
-  if constexpr (ROLLOUT && Env::HAS_REGS) {
+  // (a family whose row length is a parameter — memory_chain — is register-resident in the rows its own thread stores)
+  if constexpr (ROLLOUT && Env::HAS_REGS && (DIRECT_ARG || !Env::PACKED)) {
     bsx_reset_pool* pool = nullptr;
     float* rows = nullptr;
     if constexpr (BIG && Env::POOLED_RESETS && MT == 0) {
@@ -704,7 +705,8 @@ static bsx_row_seg small_obs_row_seg(const typename Env::args& a) {
 // ... and of a fused rollout: the tables a register-resident family stages (cartpole: the time fractions)
 template <class Env>
 static size_t small_obs_rollout_lds(const typename Env::args& a) {
-  if constexpr (Env::HAS_REGS) return Env::table_bytes(a);
+  if constexpr (Env::HAS_REGS && Env::PACKED) return bsx_small_direct_shape(a.obs_numel) ? Env::table_bytes(a) : small_obs_lds<Env>(a);
+  else if constexpr (Env::HAS_REGS) return Env::table_bytes(a);
   else return small_obs_lds<Env>(a);
 }
 
@@ -864,8 +866,9 @@ static int launch_small_obs(const typename Env::args& a, int n_steps, void* hip_
   if constexpr (Env::HAS_REGS) {
     Env_variant = Env::variant_of(a);
     if (a.ctl.n_lanes * (int64_t)a.obs_numel * 4 < ((int64_t)1 << 32)) regs_v = Env_variant;
+    if (Env::PACKED && !bsx_small_direct_shape(a.obs_numel)) regs_v = -1;      // wide rows: the LDS bit planes, step by step
     static const int eager2_min_blocks = bsx_env_int("BSX_EAGER2_MIN_BLOCKS", BSX_EAGER2_MIN_BLOCKS_DEFAULT);
-    eager2 = eager2_min_blocks > 0 && (a.ctl.n_lanes + BSX_BLOCK - 1) / BSX_BLOCK >= eager2_min_blocks;
+    eager2 = eager2_min_blocks > 0 && Env_variant >= 0 && (a.ctl.n_lanes + BSX_BLOCK - 1) / BSX_BLOCK >= eager2_min_blocks;
   }
   const int64_t blocks = (a.ctl.n_lanes + BSX_BLOCK - 1) / BSX_BLOCK;
   if (blocks > 0x7FFFFFFF) return BSX_EINVAL;
@@ -951,8 +954,14 @@ struct bandit_env {
 // ------------------------------------------------------------------------------ memory_chain
 #define MC_RESET_BIT (1 << 28)
 struct memory_chain_env {
-  static constexpr bool HAS_REGS = false, PACKED = true;
-  struct regs { int unused; };
+  // Register-resident in a fused rollout of SHORT rows (num_bits <= 6: the row is stored by the lane's own thread) — every
+  // memory_len id has one context bit.  The generic rollout re-read the lane's state word and context from L2 on every
+  // step behind a drain of the previous step's stores (three dependent round trips per step): memory_len/10 took 13.6 us
+  // per step inside rollout(16) against 12.3 us for an eager step() (profiles/r05/bench_default_call1.json).
+  static constexpr bool HAS_REGS = true, PACKED = true, POOLED_RESETS = false, ROWS_VIA_LDS = false;
+  static constexpr int N_VARIANTS = 1;
+  __host__ __device__ static constexpr int numel_of(int) { return 3; }     // variant 0: one context bit, rows of 3 floats
+  struct regs { int32_t st; uint64_t ctx; double inf[2]; };                // inf: total_perfect, total_regret in a fused rollout
   struct args {
     bsx_ctl ctl; const int32_t* action; int32_t* state; uint64_t* context; bsx_timestep_t out;
     double* info; int32_t obs_numel; int32_t L; int32_t nb; uint32_t numel_magic;
@@ -984,6 +993,77 @@ struct memory_chain_env {
       for (int b = 0; b < a.nb; ++b)                            // :69-70
         o[2 + b] = (t == 0) ? (float)(2 * (int)((ctx >> b) & 1ull) - 1) : 0.0f;
     }
+  }
+  // ---- the register-resident form (small_obs_regs_rollout): state word + context in registers for the T steps
+  static int variant_of(const args& a) { return a.nb == 1 ? 0 : -1; }
+  template <bool NOFORCE = false>
+  __device__ static __forceinline__ bool wants_reset(const args&, const regs&) { return false; }
+  __device__ static __forceinline__ void clear(regs& r) { r.st = 0; r.ctx = 0ull; }
+  __device__ static __forceinline__ bool reset_pending(const regs& r) { return (r.st & MC_RESET_BIT) != 0; }
+  __device__ static __forceinline__ void reset_part(const args&, uint64_t, uint64_t, int, unsigned, bsx_reset_pool*) {}
+  // the time fraction 1 - t / L (an f64 division per step) from a table in LDS that the workgroup fills once per launch with
+  // that same division
+  static constexpr int TABLE_MAX_BYTES = 16384;
+  __host__ __device__ static bool table_fits(const args& a) { return ((int64_t)a.L + 1) * 4 <= TABLE_MAX_BYTES; }
+  static size_t table_bytes(const args& a) { return table_fits(a) ? ((size_t)a.L + 1) * 4 : 0; }
+  __device__ static __forceinline__ bsx_lds_table stage_tables(const args& a, float* s_dyn) {
+    BSX_NO_CONTRACT
+    for (int k = threadIdx.x; k <= a.L; k += BSX_BLOCK) s_dyn[k] = (float)(1.0 - (double)k / (double)a.L);
+    return (bsx_lds_table)s_dyn;
+  }
+  template <int V = -1>
+  __device__ static __forceinline__ void load_info(const args& a, int64_t i, regs& r) { r.inf[0] = a.info[i]; r.inf[1] = a.info[a.ctl.n_lanes + i]; }
+  template <int V = -1>
+  __device__ static __forceinline__ void store_info(const args& a, int64_t i, const regs& r) { a.info[i] = r.inf[0]; a.info[a.ctl.n_lanes + i] = r.inf[1]; }
+  __device__ static __forceinline__ void load(const args& a, int64_t i, regs& r) { r.st = a.state[i]; r.ctx = a.context[i]; }
+  __device__ static __forceinline__ void store(const args& a, int64_t i, const regs& r) { a.state[i] = r.st; a.context[i] = r.ctx; }
+  // One reset()/step() of the lane in `rg` (memory_chain.py:60-97; the same transitions, draws and info updates as step()
+  // below — tests/test_gpu_rollout.py holds rollout(T) to T step() calls bit for bit).  Short rows only: o[0 .. nb + 2).
+  template <int LOG, int MT, bool IREGS = false, bool TAB = false, bool POOL = false, int V = -1, bool NOFORCE = false>
+  __device__ static __forceinline__ int core(const args& a, regs& rg, const int act, int64_t i, uint64_t lane, uint64_t step,
+                                             float* o, double& reward, bsx_lds_table s_tf = (bsx_lds_table)0,
+                                             const bsx_reset_pool* = nullptr) {
+    BSX_NO_CONTRACT
+    const int nb = V == 0 ? 1 : a.nb;
+    const int32_t st = rg.st;
+    int t = st & 0xFFFFF, query = (st >> 20) & 0xFF;
+    uint64_t ctx = rg.ctx;
+    const bool reset = (!NOFORCE && a.ctl.force_reset) || (st & MC_RESET_BIT);
+    if (reset) {                                                // :91-97
+      bsx_draws d;
+      bsx_draws_begin<MT>(&d, a.ctl, i, lane, step);
+      ctx = 0;
+      if (MT == 0 || d.mt == nullptr) {
+        ctx = (uint64_t)bsx_word(&d) & ((1ull << nb) - 1ull);   // BernVec(nb), nb <= 6 here: the low bits of one word
+      } else {
+        uint32_t w = 0;
+        for (int b = 0; b < nb; ++b) ctx |= (uint64_t)bsx_bern_vec_bit(&d, b, &w) << b;
+      }
+      query = (int)bsx_randint(&d, (uint32_t)nb);
+      bsx_draws_end<MT>(&d, a.ctl, i);
+      t = 0;
+      rg.ctx = ctx;
+    }
+    // the observation of the state BEFORE the step's increment (:74; after a reset: of the fresh state)
+    if constexpr (TAB) o[0] = s_tf[t];                          // (t <= L)
+    else o[0] = (float)(1.0 - (double)t / (double)a.L);         // :64
+    o[1] = (t == a.L - 1) ? (float)query : 0.0f;                // :66-67
+#pragma unroll
+    for (int b = 0; b < 6; ++b)
+      if (b < nb) o[2 + b] = (t == 0) ? (float)(2 * (int)((ctx >> b) & 1ull) - 1) : 0.0f;   // :69-70
+    if (reset) { rg.st = t | (query << 20); return BSX_FIRST; }
+    t += 1;                                                     // :75
+    if (t - 1 < a.L) { rg.st = t | (query << 20); return BSX_MID; }   // :77-79
+    const bool hit = act == (int)((ctx >> query) & 1ull);
+    reward = hit ? 1.0 : -1.0;                                  // :83-88
+    if constexpr (IREGS) {
+      if (hit) rg.inf[0] += 1.0; else rg.inf[1] += 2.0;
+    } else {
+      const bool quiet = a.L >= 8 && bsx_info_quiet<LOG>(a.ctl);
+      if (hit) bsx_info_add(quiet, &a.info[i], 1.0); else bsx_info_add(quiet, &a.info[a.ctl.n_lanes + i], 2.0);
+    }
+    rg.st = t | (query << 20) | MC_RESET_BIT;
+    return BSX_LAST;
   }
   template <int LOG, int MT, bool PACK = false, class Sink = bsx_bit_sink>
   __device__ static int step(const args& a, int64_t i, int64_t oi, uint64_t lane, uint64_t step, float* o, double& reward,

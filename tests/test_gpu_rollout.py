@@ -22,6 +22,9 @@ CASES = [
     ('bandit', dict(mapping_seed=2), ('noise', 0.5), 11),
     ('memory_chain', dict(memory_length=3, num_bits=3), None, 2),      # numel 5: unaligned slices
     ('memory_chain', dict(memory_length=2, num_bits=40), None, 2),     # packed records, 42-float rows
+    ('memory_chain', dict(memory_length=12, num_bits=1), None, 2),     # memory_len/10: the register-resident rollout, variant 0
+    ('memory_chain', dict(memory_length=9, num_bits=1), ('noise', 0.3), 2),
+    ('memory_chain', dict(memory_length=1, num_bits=6), ('scale', 2.0), 2),     # 8 floats: the widest row a thread stores itself
     ('umbrella_chain', dict(chain_length=4, n_distractor=20), ('scale', 3.0), 2),
     ('discounting_chain', dict(mapping_seed=1), None, 5),
     ('cartpole', dict(), None, 3),
@@ -217,3 +220,33 @@ print('placements ok')
   p = subprocess.run([sys.executable, '-c', code], cwd=root, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT,
                      text=True, timeout=300)
   assert p.returncode == 0 and 'placements ok' in p.stdout, p.stdout[-2000:]
+
+
+@pytest.mark.parametrize('kwargs', [dict(memory_length=12, num_bits=1), dict(memory_length=3, num_bits=1), dict(memory_length=5000, num_bits=1),
+                                    dict(memory_length=4, num_bits=2), dict(memory_length=2, num_bits=5), dict(memory_length=7, num_bits=6)])
+@pytest.mark.parametrize('batch,T', [(1, 40), (333, 90), (5000, 64), (1 << 20, 16)])      # the last one: as benched (`memory_len/10 r16`)
+def test_memory_chain_register_resident_rollout_equals_steps(kwargs, batch, T):
+  """No wrapper: the lean fused rollout of memory_chain with a short row (num_bits <= 6) keeps the lane's state word and
+  context in registers for the T steps, the time fractions in an LDS table (memory_length 5000: no table, the division
+  stays) and the bsuite_info columns in registers; == T step() calls bit for bit, state, info and counters included."""
+  if batch == 1 << 20 and kwargs != dict(memory_length=12, num_bits=1):
+    pytest.skip('full size: the benched shape only')
+  g = torch.Generator(device='cuda'); g.manual_seed(5)
+  acts = torch.randint(2, (T, batch), generator=g, device='cuda', dtype=torch.int32)
+  a = eu.make_env('memory_chain', kwargs, batch=batch, lane_offset=3, seed=8)
+  b = eu.make_env('memory_chain', kwargs, batch=batch, lane_offset=3, seed=8)
+  for t in range(3):
+    a.step(acts[t]); b.step(acts[t])
+  for rep in range(2):                                       # twice: the state a rollout leaves is what the next one loads
+    ro = a.rollout(acts)
+    for t in range(T):
+      ts = b.step(acts[t])
+      if batch <= 5000 or t in (0, 1, T - 1):
+        for x, y in zip((ro.step_type[t], ro.reward[t], ro.discount[t], ro.observation[t]),
+                        (ts.step_type, ts.reward, ts.discount, ts.observation)):
+          assert torch.equal(x, y), f'{kwargs} rep={rep} t={t}'
+  for k, v in a.bsuite_info().items():
+    torch.testing.assert_close(v, b.bsuite_info()[k], rtol=0, atol=0)
+  for k in ('state', 'context'):
+    assert torch.equal(eu.raw(a)._state[k], eu.raw(b)._state[k]), k
+  torch.testing.assert_close(eu.raw(a).episode_counters(), eu.raw(b).episode_counters(), rtol=0, atol=0)

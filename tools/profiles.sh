@@ -14,7 +14,11 @@ timeout 400 python bench.py > $out/bench_default.json 2> $out/bench_default.err;
 # the headline under rocprofv3: kernel averages over the timed launches + the bench line of the same run
 timeout 400 python tools/kernel_stats.py $out/bench_headline_kernel_stats.csv -- --steps 200 --warmup 20 $A > /dev/null 2>$out/kernel_stats.err
 timeout 400 python tools/kernel_stats.py $out/bench_catch_kernel_stats.csv -- --workload catch --steps 200 --warmup 20 $A > /dev/null 2>>$out/kernel_stats.err
-timeout 400 python tools/kernel_stats.py $out/bench_sweep_kernel_stats.csv --last 100 -- --workload sweep --steps 100 --warmup 20 > /dev/null 2>>$out/kernel_stats.err
+# the sweep, one schedule per trace (split = the default closed-loop cut: sweep_phase0_kernel is its first launch — the
+# workgroups the stream waits for — and sweep_pipelined_kernel its second: the store stream beside the small families)
+for sch in split closed pipelined; do
+  timeout 400 python tools/kernel_stats.py $out/bench_sweep_${sch}_kernel_stats.csv --last 100 -- --workload sweep --sweep-schedule $sch --steps 100 --warmup 20 > /dev/null 2>>$out/kernel_stats.err
+done
 # a rank's share of an 8-GPU strong-scaled run (2^17 lanes): deep_sea is ONE launch there (deep_sea_step1_kernel), catch the fused tile step
 timeout 300 python tools/kernel_stats.py $out/deep_sea_2p17_kernel_stats.csv -- --lanes 131072 --steps 200 --warmup 20 $A > /dev/null 2>>$out/kernel_stats.err
 timeout 300 python tools/kernel_stats.py $out/catch_2p17_kernel_stats.csv -- --workload catch --lanes 131072 --steps 200 --warmup 20 $A > /dev/null 2>>$out/kernel_stats.err
@@ -26,8 +30,19 @@ pm traffic cartpole $out/cartpole_pmc_traffic.json --kernels "small_obs_kernel<c
 # (mountain_car lock-step: staggering its 1001-call episodes is ~10^4 torch launches, minutes under a PMC pass; in 24
 #  calls no lane resets either way)
 pm traffic mountain_car $out/mountain_car_pmc_traffic.json --kernels "small_obs_kernel<mountain_car_env" --alg-bytes $((49*B)) -- --steps 20 --warmup 4 $A --no-stagger --workload mountain_car
-pm traffic sweep_closed $out/sweep_closed_pmc_traffic.json --kernels sweep_phase0_kernel pair_mixed_stream_kernel --alg-bytes 885580000 --last 40 -- --workload sweep --steps 40 --warmup 10
-pm traffic sweep_pipelined $out/sweep_pipelined_pmc_traffic.json --kernels sweep_pipelined_kernel --alg-bytes 885580000 --last 40 -- --workload sweep --steps 40 --warmup 10
+pm traffic sweep_closed $out/sweep_closed_pmc_traffic.json --kernels sweep_phase0_kernel pair_mixed_stream_kernel --alg-bytes 885580000 --last 40 -- --workload sweep --sweep-schedule closed --steps 40 --warmup 10
+pm traffic sweep_split $out/sweep_split_pmc_traffic.json --kernels sweep_phase0_kernel sweep_pipelined_kernel --alg-bytes 885580000 --last 40 -- --workload sweep --sweep-schedule split --steps 40 --warmup 10
+pm traffic sweep_pipelined $out/sweep_pipelined_pmc_traffic.json --kernels sweep_pipelined_kernel --alg-bytes 885580000 --last 40 -- --workload sweep --sweep-schedule pipelined --steps 40 --warmup 10
+# the other families north_star names, and the mnist bandit of the sweep: traffic + kernel averages
+pm traffic bandit $out/bandit_pmc_traffic.json --kernels "small_obs_kernel<bandit_env" --alg-bytes $((25*B)) -- --steps 20 --warmup 4 $A --workload bandit
+pm traffic discounting_chain $out/discounting_chain_pmc_traffic.json --kernels "small_obs_kernel<discounting_chain_env" --alg-bytes $((29*B)) -- --steps 20 --warmup 4 $A --no-stagger --workload discounting_chain
+pm traffic memory_len $out/memory_len_pmc_traffic.json --kernels "small_obs_kernel<memory_chain_env" --alg-bytes $((49*B)) -- --steps 20 --warmup 4 $A --workload memory_len
+pm traffic umbrella_length $out/umbrella_length_pmc_traffic.json --kernels "small_obs_kernel<umbrella_chain_env" --alg-bytes $((113*B)) -- --steps 20 --warmup 4 $A --workload umbrella_length
+pm traffic mnist $out/mnist_pmc_traffic.json --kernels mnist_advance_kernel mnist_observe_kernel --alg-bytes $((3157*B)) -- --steps 20 --warmup 4 $A --workload mnist
+for w in bandit discounting_chain memory_len umbrella_length mnist; do
+  timeout 300 python tools/kernel_stats.py $out/${w}_kernel_stats.csv -- --workload $w --steps 200 --warmup 20 $A > /dev/null 2>>$out/kernel_stats.err
+done
+pm sq umbrella_length_eager $out/umbrella_length_eager_pmc_sq.json --kernels "small_obs_kernel<umbrella_chain_env" -- --workload umbrella_length --steps 20 --warmup 4 $A
 # issue-side counters of the fused rollouts (bound "valu") and of the eager physics steps
 for w in cartpole mountain_car; do
   ns=""; [ $w = mountain_car ] && ns="--no-stagger"
