@@ -926,13 +926,56 @@ static int launch_small_obs(const typename Env::args& a, int n_steps, void* hip_
 }
 
 // ------------------------------------------------------------------------------ bandit
-struct bandit_env {
-  static constexpr bool HAS_REGS = false, PACKED = false;
-  struct regs { int unused; };
+// A family with a one-word state and no table, register-resident in a fused rollout (small_obs_regs_rollout): what the
+// interface needs beyond regs / load / store / core.
+struct small_regs_defaults {
+  static constexpr bool POOLED_RESETS = false, ROWS_VIA_LDS = false;
+  static constexpr int N_VARIANTS = 1, TABLE_MAX_BYTES = 0;
+  __device__ static __forceinline__ void reset_part(const void*, uint64_t, uint64_t, int, unsigned, bsx_reset_pool*) {}
+};
+
+struct bandit_env : small_regs_defaults {
+  // (register-resident in a fused rollout: the generic loop re-read the reset flag from L2 behind a drain of the previous
+  // step's stores and read-modify-wrote the f64 regret column on every second step — 16 of the step's 33 bytes)
+  static constexpr bool HAS_REGS = true, PACKED = false;
+  __host__ __device__ static constexpr int numel_of(int) { return 1; }
+  struct regs { int32_t st; double inf0; };                    // inf0: total_regret in a fused rollout
   struct args {
     bsx_ctl ctl; const int32_t* action; int32_t* state; bsx_timestep_t out; double* info;
     int32_t obs_numel; int32_t num_actions; double rewards[BSX_BANDIT_MAX_ACTIONS];
   };
+  static int variant_of(const args&) { return 0; }
+  template <bool NOFORCE = false>
+  __device__ static __forceinline__ bool wants_reset(const args&, const regs&) { return false; }
+  __device__ static __forceinline__ void clear(regs& r) { r.st = 0; }
+  __device__ static __forceinline__ bool reset_pending(const regs& r) { return r.st != 0; }
+  __device__ static __forceinline__ void reset_part(const args&, uint64_t, uint64_t, int, unsigned, bsx_reset_pool*) {}
+  __host__ __device__ static bool table_fits(const args&) { return false; }
+  static size_t table_bytes(const args&) { return 0; }
+  __device__ static __forceinline__ bsx_lds_table stage_tables(const args&, float*) { return (bsx_lds_table)0; }
+  template <int V = -1>
+  __device__ static __forceinline__ void load_info(const args& a, int64_t i, regs& r) { r.inf0 = a.info[i]; }
+  template <int V = -1>
+  __device__ static __forceinline__ void store_info(const args& a, int64_t i, const regs& r) { a.info[i] = r.inf0; }
+  __device__ static __forceinline__ void load(const args& a, int64_t i, regs& r) { r.st = a.state[i]; }
+  __device__ static __forceinline__ void store(const args& a, int64_t i, const regs& r) { a.state[i] = r.st; }
+  // (the same transitions as step() below; tests/test_gpu_rollout.py holds rollout(T) to T step() calls bit for bit)
+  template <int LOG, int MT, bool IREGS = false, bool TAB = false, bool POOL = false, int V = -1, bool NOFORCE = false>
+  __device__ static __forceinline__ int core(const args& a, regs& rg, int act, int64_t i, uint64_t, uint64_t,
+                                             float* o, double& reward, bsx_lds_table = (bsx_lds_table)0,
+                                             const bsx_reset_pool* = nullptr) {
+    BSX_NO_CONTRACT
+    o[0] = 1.0f;                                                // bandit.py:54 (ones)
+    if ((!NOFORCE && a.ctl.force_reset) || rg.st) { rg.st = 0; return BSX_FIRST; }
+    if (act < 0 || act >= a.num_actions) {                      // reference: IndexError (bandit.py:61)
+      bsx_note_invalid_action(a.ctl, i);
+      act = act < 0 ? 0 : a.num_actions - 1;
+    }
+    reward = a.rewards[act];                                    // :61
+    if constexpr (IREGS) rg.inf0 += 1.0 - reward; else a.info[i] += 1.0 - reward;   // :62
+    rg.st = 1;
+    return BSX_LAST;                                            // :64
+  }
   template <int LOG, int MT>
   __device__ static int step(const args& a, int64_t i, int64_t oi, uint64_t, uint64_t step, float* o, double& reward) {
     BSX_NO_CONTRACT
@@ -1183,13 +1226,57 @@ struct umbrella_chain_env {
 
 // ------------------------------------------------------------------------------ discounting_chain
 #define DC_RESET_BIT (1 << 12)
-struct discounting_chain_env {
-  static constexpr bool HAS_REGS = false, PACKED = false;
-  struct regs { int unused; };
+struct discounting_chain_env : small_regs_defaults {
+  static constexpr bool HAS_REGS = true, PACKED = false;        // (register-resident in a fused rollout, like the bandit)
+  __host__ __device__ static constexpr int numel_of(int) { return 2; }
+  struct regs { int32_t st; };
   struct args {
     bsx_ctl ctl; const int32_t* action; int32_t* state; bsx_timestep_t out;
     int32_t obs_numel; int32_t bonus;
   };
+  static int variant_of(const args&) { return 0; }
+  template <bool NOFORCE = false>
+  __device__ static __forceinline__ bool wants_reset(const args&, const regs&) { return false; }
+  __device__ static __forceinline__ void clear(regs& r) { r.st = 0; }
+  __device__ static __forceinline__ bool reset_pending(const regs& r) { return (r.st & DC_RESET_BIT) != 0; }
+  __device__ static __forceinline__ void reset_part(const args&, uint64_t, uint64_t, int, unsigned, bsx_reset_pool*) {}
+  __host__ __device__ static bool table_fits(const args&) { return false; }
+  static size_t table_bytes(const args&) { return 0; }
+  __device__ static __forceinline__ bsx_lds_table stage_tables(const args&, float*) { return (bsx_lds_table)0; }
+  template <int V = -1>
+  __device__ static __forceinline__ void load_info(const args&, int64_t, regs&) {}
+  template <int V = -1>
+  __device__ static __forceinline__ void store_info(const args&, int64_t, const regs&) {}
+  __device__ static __forceinline__ void load(const args& a, int64_t i, regs& r) { r.st = a.state[i]; }
+  __device__ static __forceinline__ void store(const args& a, int64_t i, const regs& r) { a.state[i] = r.st; }
+  template <int LOG, int MT, bool IREGS = false, bool TAB = false, bool POOL = false, int V = -1, bool NOFORCE = false>
+  __device__ static __forceinline__ int core(const args& a, regs& rg, const int act, int64_t i, uint64_t, uint64_t,
+                                             float* o, double& reward, bsx_lds_table = (bsx_lds_table)0,
+                                             const bsx_reset_pool* = nullptr) {
+    BSX_NO_CONTRACT
+    const int32_t st = rg.st;
+    int t = st & 0xFF, ctx = ((st >> 8) & 0xF) - 1;
+    if ((!NOFORCE && a.ctl.force_reset) || (st & DC_RESET_BIT)) {   // discounting_chain.py:69-73
+      o[0] = -1.0f; o[1] = 0.0f;
+      rg.st = 0;
+      return BSX_FIRST;
+    }
+    if (t == 0) {                                               // :76-77
+      ctx = act;
+      if (ctx < 0 || ctx > 4) {                                 // reference: IndexError at the reward lookup
+        bsx_note_invalid_action(a.ctl, i);
+        ctx = ctx < 0 ? 0 : 4;
+      }
+    }
+    t += 1;
+    const int when = ctx == 0 ? 1 : ctx == 1 ? 3 : ctx == 2 ? 10 : ctx == 3 ? 30 : 100;   // :49
+    if (t == when) reward = (ctx == a.bonus) ? 1.0 + 0.1 : 1.0;                            // :57-58,80-83
+    o[0] = (float)ctx;                                          // :65
+    o[1] = (float)((double)t / 100.0);                          // :66
+    const int type = (t == 100) ? BSX_LAST : BSX_MID;           // :86-88
+    rg.st = t | ((ctx + 1) << 8) | (type == BSX_LAST ? DC_RESET_BIT : 0);
+    return type;
+  }
   template <int LOG, int MT>
   __device__ static int step(const args& a, int64_t i, int64_t oi, uint64_t, uint64_t step, float* o, double& reward) {
     BSX_NO_CONTRACT

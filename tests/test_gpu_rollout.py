@@ -250,3 +250,33 @@ def test_memory_chain_register_resident_rollout_equals_steps(kwargs, batch, T):
   for k in ('state', 'context'):
     assert torch.equal(eu.raw(a)._state[k], eu.raw(b)._state[k]), k
   torch.testing.assert_close(eu.raw(a).episode_counters(), eu.raw(b).episode_counters(), rtol=0, atol=0)
+
+
+@pytest.mark.parametrize('family,kwargs,na', [('bandit', dict(mapping_seed=4), 11), ('discounting_chain', dict(mapping_seed=3), 5)])
+@pytest.mark.parametrize('batch,T', [(1, 40), (333, 230), (5000, 64), (1 << 20, 16)])          # the last one: as benched (`... r16`)
+def test_bandit_and_discounting_chain_register_resident_rollouts(family, kwargs, na, batch, T):
+  """No wrapper: the lean fused rollouts of the bandit and of discounting_chain keep the lane's state word (and the
+  bandit's regret column) in registers for the T steps; == T step() calls bit for bit — out-of-spec actions included,
+  which both clamp and count (bandit.py:61, discounting_chain.py:80)."""
+  g = torch.Generator(device='cuda'); g.manual_seed(6)
+  acts = torch.randint(na, (T, batch), generator=g, device='cuda', dtype=torch.int32)
+  if batch == 333:
+    acts[3, ::7] = -2
+    acts[4, 1::5] = 1 << 20                                   # outside 0..15: the run re-reads its actions step by step
+    acts[T - 1, ::3] = na
+  a = eu.make_env(family, kwargs, batch=batch, lane_offset=11, seed=2)
+  b = eu.make_env(family, kwargs, batch=batch, lane_offset=11, seed=2)
+  a.step(acts[0]); b.step(acts[0])
+  for rep in range(2):
+    ro = a.rollout(acts)
+    for t in range(T):
+      ts = b.step(acts[t])
+      if batch <= 5000 or t in (0, 1, T - 1):
+        for x, y in zip((ro.step_type[t], ro.reward[t], ro.discount[t], ro.observation[t]),
+                        (ts.step_type, ts.reward, ts.discount, ts.observation)):
+          assert torch.equal(x, y), f'{family} rep={rep} t={t}'
+  for k, v in a.bsuite_info().items():
+    torch.testing.assert_close(v, b.bsuite_info()[k], rtol=0, atol=0)
+  assert torch.equal(eu.raw(a)._state['state'], eu.raw(b)._state['state'])
+  torch.testing.assert_close(eu.raw(a).episode_counters(), eu.raw(b).episode_counters(), rtol=0, atol=0)
+  torch.testing.assert_close(eu.raw(a).invalid_action_count(), eu.raw(b).invalid_action_count(), rtol=0, atol=0)
