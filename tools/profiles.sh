@@ -7,7 +7,7 @@ set -u
 out=$PWD/gpurun_out/final; mkdir -p $out
 B=1048576
 A="--no-cpu-baseline --no-also"
-if [ "${1:-}" != quick ]; then
+if [ "${1:-}" != quick ] && [ -z "${SKIP_PYTEST:-}" ]; then
   ( time timeout 1700 python -m pytest tests -m gpu -q --durations=8 ) > $out/pytest_gpu.log 2>&1; tail -3 $out/pytest_gpu.log
 fi
 timeout 400 python bench.py > $out/bench_default.json 2> $out/bench_default.err; wc -c $out/bench_default.json
@@ -35,7 +35,7 @@ pm traffic sweep_split $out/sweep_split_pmc_traffic.json --kernels sweep_phase0_
 pm traffic sweep_pipelined $out/sweep_pipelined_pmc_traffic.json --kernels sweep_pipelined_kernel --alg-bytes 885580000 --last 40 -- --workload sweep --sweep-schedule pipelined --steps 40 --warmup 10
 # the other families north_star names, and the mnist bandit of the sweep: traffic + kernel averages
 pm traffic bandit $out/bandit_pmc_traffic.json --kernels "small_obs_kernel<bandit_env" --alg-bytes $((25*B)) -- --steps 20 --warmup 4 $A --workload bandit
-pm traffic discounting_chain $out/discounting_chain_pmc_traffic.json --kernels "small_obs_kernel<discounting_chain_env" --alg-bytes $((29*B)) -- --steps 20 --warmup 4 $A --no-stagger --workload discounting_chain
+pm traffic discounting_chain $out/discounting_chain_pmc_traffic.json --kernels "small_obs_kernel<discounting_chain_env" --alg-bytes $((29*B)) -- --steps 20 --warmup 4 $A --workload discounting_chain
 pm traffic memory_len $out/memory_len_pmc_traffic.json --kernels "small_obs_kernel<memory_chain_env" --alg-bytes $((49*B)) -- --steps 20 --warmup 4 $A --workload memory_len
 pm traffic umbrella_length $out/umbrella_length_pmc_traffic.json --kernels "small_obs_kernel<umbrella_chain_env" --alg-bytes $((113*B)) -- --steps 20 --warmup 4 $A --workload umbrella_length
 pm traffic mnist $out/mnist_pmc_traffic.json --kernels mnist_advance_kernel mnist_observe_kernel --alg-bytes $((3157*B)) -- --steps 20 --warmup 4 $A --workload mnist
@@ -54,8 +54,10 @@ if [ "${1:-}" != quick ]; then
     timeout 100 python bench.py --workload $w --steps 200 --warmup 40 $A 2>/dev/null | tail -1 | python -c "
 import sys,json; d=json.loads(sys.stdin.read()); r=d['roofline']; print('%-18s eager  %.3e env-steps/s  %.2f us/step  %.0f GB/s  frac %.3f' % ('$w', d['value'], r['kernel_ms']*1e3, r['achieved'], r['frac']))"
   done > $out/bench_all_workloads_eager.log
-  timeout 400 python tools/strong_scaling_proxy.py $out/strong_scaling_proxy.json > $out/strong_scaling_proxy.log 2>&1
+  timeout 900 python tools/strong_scaling_proxy.py $out/strong_scaling_proxy.json > $out/strong_scaling_proxy.log 2>&1
   BSX_BENCH_BACKEND=gloo BSX_BENCH_SINGLE_DEVICE=1 timeout 400 python bench.py --gpus 2 --no-cpu-baseline 2>/dev/null | grep '^{' > $out/bench_2ranks_on_one_gpu_gloo.json
+  # the driver's 8-GPU command, rehearsed with eight ranks on the one GPU (the numbers mean nothing; the line's shape does)
+  BSX_BENCH_BACKEND=gloo BSX_BENCH_SINGLE_DEVICE=1 timeout 900 python bench.py --gpus 8 --steps 20 --warmup 5 --no-cpu-baseline 2>/dev/null | grep '^{' > $out/bench_8ranks_on_one_gpu_gloo.json
   timeout 300 python tools/physics_error.py > $out/physics_error.log 2>&1; cp gpurun_out/physics_error.json $out/ 2>/dev/null
   timeout 300 python tools/fuzz_gpu.py --seconds ${FUZZ_SECONDS:-300} --seed 11 > $out/fuzz_gpu.log 2>&1; tail -1 $out/fuzz_gpu.log
   # the engine against the UNMODIFIED reference, live: 8 x LIVE_CASES random cases (families, kwargs, wrappers, resets, policies)
