@@ -74,6 +74,18 @@ class Environment(dm_env.EnvironmentBase):
   # A/B: bench.py --row-path on).
   row_path_min_bytes = None
   _rows = None
+  # Families with a single-launch step (deep_sea, catch): the bit of the packed state word that carries the parity of the
+  # call index that reads the word next, and all the bits of the word that are the library's bookkeeping (never part of a
+  # state_dict).  The flag BSX_CALL_STATE_TAGGED is only set where every call index is exactly the previous one plus 1 —
+  # a repeated index finds the words already carrying the next tag.  That holds for an environment that owns its counter
+  # (the host count, or a device counter bumped after every call, captured or not) and does not hold
+  #  * for a segment of a shared counter (SweepBatch bumps once per sweep step; nothing stops a caller from stepping one
+  #    segment twice in between): never tagged;
+  #  * while a HIP graph is being captured with the HOST count (every replay repeats the captured index): the captured
+  #    call is the two-launch step, whose advance keeps the tags valid for the eager calls that follow.
+  _state_tag_bit = None
+  _state_lib_bits = 0
+  _tag_calls = False
   _info_keys = ()          # names of the f64 info columns, in native column order
   _info_int_keys = ()      # keys the reference reports as Python ints
 
@@ -379,6 +391,10 @@ class Environment(dm_env.EnvironmentBase):
     self._argv = [list(self._native_args(self._call_desc, 0, p)) for p in self._out_ptrs]
     self._call_stream, self._call_wrap = self._call_desc.stream, self._call_desc.wrap     # views of the same memory
     self._wrap_applied = None
+    if self._state_tag_bit is not None:
+      self._tag_calls = self._shared_step_counter is None
+      self._call_desc.flags = _native.CALL_STATE_TAGGED if self._tag_calls else 0
+    self._tag_host_count = self._tag_calls and not self._device_step_counter
     self._dev_index = self._device.index
     self._timesteps = None if self._scalar else [
         dm_env.TimeStep(step_type=o['step_type'], reward=o['reward'], discount=o['discount'], observation=o['observation'])
@@ -400,6 +416,8 @@ class Environment(dm_env.EnvironmentBase):
     if self._delta:
       call.obs_paint = self._paint[b].data_ptr()
     call.force_reset = 1 if force_reset else 0
+    if self._tag_host_count:                       # (deep_sea / catch with the host-side call count: not while capturing)
+      call.flags = 0 if torch.cuda.is_current_stream_capturing() else _native.CALL_STATE_TAGGED
     if self._wrap is not self._wrap_applied:       # the wrappers install a NEW tuple when they change it
       w = self._call_wrap
       w.kind, w.param, w.seed, w.param2 = self._wrap
@@ -701,6 +719,8 @@ class Environment(dm_env.EnvironmentBase):
     """Everything needed to resume this batch bit-exactly (device tensors are cloned)."""
     self._ensure_allocated()
     d = {k: v.clone() for k, v in self._state.items()}
+    if self._state_lib_bits:
+      d['state'] &= ~self._state_lib_bits          # (a dict is not tied to a call index or to a batch's call schedule)
     d['__info'] = self._info.clone()
     d['__counters'] = self._counters.clone()
     d['__step_index'] = self.device_step_index()
@@ -724,6 +744,11 @@ class Environment(dm_env.EnvironmentBase):
     self._info.copy_(d['__info'])
     self._counters.copy_(d['__counters'])
     self._step_index = int(d['__step_index'])
+    if self._state_tag_bit is not None:
+      st = self._state['state']
+      st &= ~self._state_lib_bits
+      if self._step_index & 1:
+        st |= self._state_tag_bit
     if self._device_step_counter:
       self._step_base.fill_(self._step_index)
     self._seed = int(d['__seed'])

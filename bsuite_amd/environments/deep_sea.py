@@ -72,41 +72,11 @@ class DeepSea(base.Environment):
   _pipelined_rollout = True
 
   # Bit 18 of the packed state word = the parity of the call index that reads it next (csrc/deep_sea_fam.h: every
-  # advance writes it).  This class keeps that true for words that arrive from elsewhere (load_state_dict), which is
-  # what BSX_CALL_STATE_TAGGED promises the library: a deterministic, un-wrapped step() is then ONE launch
-  # (deep_sea_step1_kernel) instead of lane advance + observation stream.
-  _TAG = 1 << 18
-
-  # The single-launch step is only correct when every call index is exactly the previous one plus 1 (a repeated index
-  # finds the words already carrying the next tag).  That holds for an environment that owns its counter — the host
-  # count, or a device counter bumped after every call (captured or not) — and does not hold
-  #  * for a segment of a shared counter (SweepBatch bumps once per sweep step; nothing stops a caller from stepping
-  #    one segment twice in between): never tagged;
-  #  * while a HIP graph is being captured with the HOST count (every replay repeats the captured index): the
-  #    captured call is the two-launch step, whose advance keeps the tags valid for the eager calls that follow.
-  def _ensure_allocated(self):
-    fresh = not self._allocated
-    super()._ensure_allocated()
-    if fresh:
-      self._tag_calls = self._shared_step_counter is None
-      self._call_desc.flags = _native.CALL_STATE_TAGGED if self._tag_calls else 0
-
-  def _call(self, action_ptr, force_reset):
-    if self._tag_calls and not self._device_step_counter:
-      self._call_desc.flags = 0 if torch.cuda.is_current_stream_capturing() else _native.CALL_STATE_TAGGED
-    return super()._call(action_ptr, force_reset)
-
-  def state_dict(self):
-    d = super().state_dict()
-    d['state'] &= ~self._TAG                 # (a dict is not tied to a call index)
-    return d
-
-  def load_state_dict(self, d):
-    super().load_state_dict(d)
-    st = self._state['state']
-    st &= ~self._TAG
-    if self._step_index & 1:
-      st |= self._TAG
+  # advance writes it).  The base class keeps that true for words that arrive from elsewhere (load_state_dict) and sets
+  # BSX_CALL_STATE_TAGGED where call indices are guaranteed consecutive (base.Environment._state_tag_bit): a
+  # deterministic, un-wrapped step() is then ONE launch (deep_sea_step1_kernel) instead of lane advance + observation stream.
+  _state_tag_bit = 1 << 18
+  _state_lib_bits = 1 << 18
 
   def _native_args(self, call, action_ptr, out):
     return (ctypes.byref(self._cfg), ctypes.byref(call), action_ptr, self._state['state'].data_ptr(), out, self._info.data_ptr())
