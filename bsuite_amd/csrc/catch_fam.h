@@ -15,23 +15,6 @@
 // put a memory round trip in the middle of every wave's advance.  total_regret = info + 2 * pending.
 #define CATCH_PENDING_SHIFT 25
 #define CATCH_PENDING_MAX 127
-// ball_x, ball_y, paddle_x are below 64 (rows, columns <= 64): the two top bits of each byte of the state word are the
-// library's (ABI v12).  Bit 7: the parity of the call index that will READ the word next — every advance writes
-// ((step + 1) & 1) there, like deep_sea's bit 18 — which lets the single-launch step (catch_step1_kernel, catch.hip) tell a
-// word its lane's writer has already advanced in this launch from one it has not.  Bits 6, 14, 15, 22: the ball column
-// of the lane's NEXT episode, drawn ahead of time by that kernel's writer thread (bit 6 says a value is parked; bits
-// 14, 15, 22 hold it: columns <= 8) so that the threads that merely need the lane's new state on the call that resets it
-// do not each walk a Philox block.  The draw itself is the one the stream specifies for that call — (seed, lane, the
-// reset call's index), word 0 — computed early, not changed.  Every other advance writes the parked bits as 0.
-#define CATCH_FIELD_MASK 0x3F
-#define CATCH_TAG_SHIFT 7
-#define CATCH_TAG_BIT (1 << CATCH_TAG_SHIFT)
-#define CATCH_PARK_VALID (1 << 6)
-#define CATCH_LIB_BITS (CATCH_TAG_BIT | CATCH_PARK_VALID | (3 << 14) | (3 << 22))
-__host__ __device__ __forceinline__ int32_t catch_park_bits(uint32_t x) {          // x < 8
-  return (int32_t)(CATCH_PARK_VALID | ((x & 3u) << 14) | (((x >> 2) & 1u) << 22));
-}
-__host__ __device__ __forceinline__ uint32_t catch_parked(int32_t st) { return (((uint32_t)st >> 14) & 3u) | ((((uint32_t)st >> 22) & 1u) << 2); }
 
 struct catch_fam {
   struct args {
@@ -51,41 +34,33 @@ struct catch_fam {
 
   // LEAN: counter-based draws only (the MT19937-exact mode is compiled out); NOMT: the same for a call that is not
   // lean otherwise (Logging / RewardNoise on the counter-based stream)
-  // STEP1: the single-launch step (catch_step1_kernel): a reset takes the ball column parked in the state word when there
-  // is one; `commit` = this thread is the lane's writer (it alone touches the info column and the error word, and — on
-  // the calls whose index is a multiple of `rows`, the episode period — parks the draw of the lane's next reset).
-  template <bool LEAN = false, bool NOMT = false, bool STEP1 = false>
+  template <bool LEAN = false, bool NOMT = false>
   __device__ static __forceinline__ int advance(const args& a, const shared&, int64_t i, uint64_t lane,
                                                 uint64_t step, int32_t st, int act, int32_t& nst,
-                                                double& reward, const bool commit = true, const bool park_now = false) {
+                                                double& reward) {
     const int rows = a.rows, cols = a.columns;
-    int ball_x = st & CATCH_FIELD_MASK, ball_y = (st >> 8) & CATCH_FIELD_MASK, paddle_x = (st >> 16) & CATCH_FIELD_MASK;
+    int ball_x = st & 0xFF, ball_y = (st >> 8) & 0xFF, paddle_x = (st >> 16) & 0xFF;
     uint32_t pending = ((uint32_t)st >> CATCH_PENDING_SHIFT) & 0x7Fu;
     const bool fold = LEAN || a.ctl.log.steps == nullptr;      // uniform
     int type;
     reward = 0.0;
     if (a.ctl.force_reset || (st & CATCH_RESET_BIT)) {         // catch.py:80-81 -> :68-76
-      if (STEP1 && (st & CATCH_PARK_VALID)) {
-        ball_x = (int)catch_parked(st);                         // :71, drawn ahead (the same word of the same stream)
-      } else {
-        bsx_draws d;
-        bsx_draws_begin<(LEAN || NOMT) ? 0 : -1>(&d, a.ctl, i, lane, step);
-        ball_x = (int)bsx_randint(&d, (uint32_t)cols);          // :71
-        bsx_draws_end<(LEAN || NOMT) ? 0 : -1>(&d, a.ctl, i);
-      }
+      bsx_draws d;
+      bsx_draws_begin<(LEAN || NOMT) ? 0 : -1>(&d, a.ctl, i, lane, step);
+      ball_x = (int)bsx_randint(&d, (uint32_t)cols);            // :71
+      bsx_draws_end<(LEAN || NOMT) ? 0 : -1>(&d, a.ctl, i);
       ball_y = 0;
       paddle_x = cols / 2;
       type = BSX_FIRST;
     } else {
-      if ((act < 0 || act > 2) && commit) bsx_note_invalid_action(a.ctl, i);   // reference: IndexError (catch.py:84)
+      if (act < 0 || act > 2) bsx_note_invalid_action(a.ctl, i);   // reference: IndexError (catch.py:84)
       const int dx = act - 1;                                   // _ACTIONS :27
       paddle_x = paddle_x + dx;                                 // :85 np.clip
       paddle_x = paddle_x < 0 ? 0 : (paddle_x > cols - 1 ? cols - 1 : paddle_x);
       ball_y += 1;                                              // :88
       if (ball_y == rows - 1) {                                 // :91-95
         reward = (paddle_x == ball_x) ? 1.0 : -1.0;
-        if (!commit) {                                          // (a reader of the single-launch step: the transition only)
-        } else if (!fold) {
+        if (!fold) {
           a.info[i] += (1.0 - reward);                          // :94 (per episode under the Logging wrapper)
         } else if (paddle_x != ball_x) {
           // (also tried: a fire-and-forget global_atomic_add_f64 per miss — 100k scattered 8-byte atomics per step cost
@@ -98,14 +73,7 @@ struct catch_fam {
       }
     }
     nst = (int32_t)((uint32_t)(ball_x | (ball_y << 8) | (paddle_x << 16) | (type == BSX_LAST ? CATCH_RESET_BIT : 0)) |
-                    (pending << CATCH_PENDING_SHIFT) | (((uint32_t)(step + 1) & 1u) << CATCH_TAG_SHIFT));
-    if (STEP1 && commit && park_now) {
-      // the lane's next reset happens on call `at`: episodes take exactly `rows` calls (a reset + rows - 1 steps, catch.py:88-97)
-      const uint64_t at = step + (type == BSX_LAST ? 1ull : (uint64_t)(rows - ball_y));
-      bsx_draws d;
-      bsx_draws_init(&d, a.ctl.seed, lane, at, BSX_STREAM_ENV);
-      nst |= catch_park_bits(bsx_randint(&d, (uint32_t)cols));
-    }
+                    (pending << CATCH_PENDING_SHIFT));
     return type;
   }
   template <bool LEAN, bool NOMT>
@@ -118,8 +86,8 @@ struct catch_fam {
 struct catch_hot {
   int rows, cols;
   __device__ __forceinline__ void operator()(int32_t st, int& a, int& b) const {
-    a = ((st >> 8) & CATCH_FIELD_MASK) * cols + (st & CATCH_FIELD_MASK);   // ball   (catch.py:111)
-    b = (rows - 1) * cols + ((st >> 16) & CATCH_FIELD_MASK);               // paddle (catch.py:112)
+    a = ((st >> 8) & 0xFF) * cols + (st & 0xFF);          // ball   (catch.py:111)
+    b = (rows - 1) * cols + ((st >> 16) & 0xFF);          // paddle (catch.py:112)
   }
 };
 

@@ -43,12 +43,6 @@ class Catch(base.Environment):
   _abi_name = 'catch'
   _supports_delta = True
   _pipelined_rollout = True
-  # The two top bits of each byte of the packed state word are the library's (csrc/catch_fam.h): bit 7 = the parity of the
-  # call index that reads the word next (BSX_CALL_STATE_TAGGED, like deep_sea's bit 18), bits 6 / 14 / 15 / 22 = the ball
-  # column of the lane's next episode, parked by the single-launch step (catch_step1_kernel).  A state_dict carries none of
-  # them; load_state_dict re-tags and un-parks (a parked draw belongs to the call schedule of the batch it was made in).
-  _state_tag_bit = 1 << 7
-  _state_lib_bits = (3 << 6) | (3 << 14) | (3 << 22)
 
   def _native_args(self, call, action_ptr, out):
     return (ctypes.byref(self._cfg), ctypes.byref(call), action_ptr, self._state['state'].data_ptr(), out, self._info.data_ptr())

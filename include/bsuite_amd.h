@@ -204,15 +204,7 @@ typedef struct {
 } bsx_call_t;
 
 /* bsx_call_t.flags */
-#define BSX_CALL_STATE_TAGGED 1 /* catch (ABI v12; bit 7 of the state word, initial word 1<<24 at an even index): the same promise
-                                  as for deep_sea below.  A lean (no Logging, no RewardNoise, counter-based draws) single
-                                  step() of a batch beyond the fused-tile range (more than 128 MiB of boards per step) with
-                                  columns <= 8 and a float count that is a multiple of 4 is then ONE launch
-                                  (catch_step1_kernel, csrc/catch.hip): the store stream's threads recompute the transition
-                                  of the lanes whose rows they write, and the reset draw of a lane's next episode is made
-                                  ahead of time — the same word of the same stream — and parked in the state word.  reset()
-                                  calls, rollouts, groups and everything else take lane advance + store stream.
-                                  deep_sea: the caller guarantees that bit 18 of EVERY lane's packed state word equals
+#define BSX_CALL_STATE_TAGGED 1 /* deep_sea: the caller guarantees that bit 18 of EVERY lane's packed state word equals
                                   the parity of this call's index (stream.step_index + *step_base) — true for a
                                   column that starts as (1<<17) | (index & 1) << 18 and is only ever advanced by
                                   this library with consecutive call indices (every advance writes the next
@@ -249,11 +241,7 @@ typedef struct {
   int32_t rows;     /* catch.py:46 (default 10); 2..64 */
   int32_t columns;  /* catch.py:47 (default 5);  1..64 */
 } bsx_catch_t;
-/* state: int32 [B] = ball_x | ball_y<<8 | paddle_x<<16 | reset_next<<24 | pending_misses<<25 (initialise to 1<<24);
- *        ball_x, ball_y, paddle_x are 6-bit fields: the two top bits of each of the three low bytes are the library's
- *        (ABI v12) — bit 7 = parity of the next call's index (written by every advance, see BSX_CALL_STATE_TAGGED),
- *        bits 6, 14, 15, 22 = the ball column of the lane's next episode parked by the single-launch step, bit 23 unused;
- *        mask the fields with 0x3F and write the library's bits as 0 when you build a state word yourself
+/* state: int32 [B] = ball_x | ball_y<<8 | paddle_x<<16 | reset_next<<24 | pending_misses<<25 (initialise to 1<<24)
  * info : double [1,B] = total_regret (catch.py:116-117).  Accounting (ABI v10): with call->logging the column is
  *        updated at every episode end like the reference.  Without it the lane counts its misses (regret 2 each, a
  *        catch costs 0: catch.py:92-94) in bits 25..31 of the state word and adds 2*127 to the column once per 127
