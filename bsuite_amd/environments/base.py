@@ -74,7 +74,7 @@ class Environment(dm_env.EnvironmentBase):
   # A/B: bench.py --row-path on).
   row_path_min_bytes = None
   _rows = None
-  # Families with a single-launch step (deep_sea, catch): the bit of the packed state word that carries the parity of the
+  # Families with a single-launch step (deep_sea): the bit of the packed state word that carries the parity of the
   # call index that reads the word next, and all the bits of the word that are the library's bookkeeping (never part of a
   # state_dict).  The flag BSX_CALL_STATE_TAGGED is only set where every call index is exactly the previous one plus 1 —
   # a repeated index finds the words already carrying the next tag.  That holds for an environment that owns its counter
@@ -416,7 +416,7 @@ class Environment(dm_env.EnvironmentBase):
     if self._delta:
       call.obs_paint = self._paint[b].data_ptr()
     call.force_reset = 1 if force_reset else 0
-    if self._tag_host_count:                       # (deep_sea / catch with the host-side call count: not while capturing)
+    if self._tag_host_count:                       # (deep_sea with the host-side call count: not while capturing)
       call.flags = 0 if torch.cuda.is_current_stream_capturing() else _native.CALL_STATE_TAGGED
     if self._wrap is not self._wrap_applied:       # the wrappers install a NEW tuple when they change it
       w = self._call_wrap
