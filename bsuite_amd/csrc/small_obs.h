@@ -1196,6 +1196,9 @@ struct umbrella_chain_env {
     int t = st & 0xFFFFF, need = (st >> 20) & 1, has = (st >> 21) & 1;
     bsx_draws d;
     bsx_draws_begin<MT>(&d, a.ctl, i, lane, step);
+    // (every path below draws from block 0 of the lane's stream: computed once, before the lanes of a wave — at different
+    // episode phases in any real batch — part ways; 659 -> see profiles/r05/ab_umbrella_shared_philox_block.log)
+    bsx_draws_prime(&d);
     if (a.ctl.force_reset || (st & UC_RESET_BIT)) {             // :87-92
       t = 0;
       need = (int)bsx_bern(&d);

@@ -295,7 +295,8 @@ class SweepBatch:
     self._group_actions = list(actions)      # keep the static action tensors alive
     self._group_outs = outs
     self._pipelined = bool(pipelined)
-    self._split = bool(DEFAULT_SPLIT if split is None else split) and mix_all and not pipelined
+    # (the split cut needs the segments with a share of the store stream at the tail of the group: the heavy_first order)
+    self._split = bool(DEFAULT_SPLIT if split is None else split) and mix_all and not pipelined and heavy_first
     self._pipelined_outs = outs_of
     self._pipelined_step = 0
     return outs_of if pipelined else outs

@@ -144,6 +144,16 @@ BSX_HD uint32_t bsx_word(bsx_draws* d) {
   return i == 0 ? d->blk.v[0] : i == 1 ? d->blk.v[1] : i == 2 ? d->blk.v[2] : d->blk.v[3];
 }
 
+/* Computes block 0 of the stream NOW (counter-based mode; a no-op in MT19937-exact mode).  For a family whose every path
+ * draws from block 0 — umbrella_chain: the reset, a MID step and a LAST step alike — calling this before the paths diverge
+ * makes a wave whose lanes are at different episode phases walk the ten Philox rounds once instead of once per path.  The
+ * words handed out afterwards are the same words. */
+BSX_HD void bsx_draws_prime(bsx_draws* d) {
+  if (d->mt) return;
+  d->blk = bsx_philox4x32_10(d->c0, d->c1, d->c2, d->c3hi, d->k0, d->k1);
+  d->have = 0;
+}
+
 BSX_HD uint64_t bsx_k53(bsx_draws* d) {
   uint32_t a = bsx_word(d), b = bsx_word(d);
   return ((uint64_t)(a >> 5) << 26) | (uint64_t)(b >> 6);
