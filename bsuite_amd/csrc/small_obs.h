@@ -59,6 +59,7 @@ struct bsx_bit_sink {
   uint32_t* planes;        // LDS: PLANES x `stride` words
   int stride;              // words per plane = 8 * numel
   uint32_t base;           // flat bit index of the lane's element HEAD
+  const float* tf = nullptr;  // LDS: the family's time fractions 1 - t / L for t = 0..L (small_obs_body, PACKED), or null
   static constexpr bool ALWAYS = false;    // the tile is zero-filled before every step: only non-zero words need a put
   // ORs bits [32k, 32k+n) of the lane's bit string (n in 1..32, the low n bits of w) into plane p
   __device__ __forceinline__ void put(int p, int k, uint32_t w, int n) const {
@@ -527,6 +528,20 @@ __device__ __forceinline__ void small_obs_body(const typename Env::args& a, cons
       const int stride = numel * (BSX_BLOCK / 32);                       // words per plane
       uint32_t* __restrict__ head_plane = planes + PLANES * stride;
       float* __restrict__ s_head = reinterpret_cast<float*>(head_plane + stride) + 4;
+      // ... then the time fractions 1 - t / L, t = 0..L, when the chain is short enough (small_obs_lds): every lane's row
+      // holds one, an f64 division per lane-step that the workgroup's first L + 1 threads now do once per launch
+      // (umbrella_length: 13 threads of one wave instead of all four waves)
+      // (single steps only: inside the fused rollout's step loop the table made umbrella_length r16 9 % SLOWER, 25.1 ->
+      // 27.4 us per step, while the eager step gained 2.6 %: profiles/r05/ab_chain_time_fraction_table.log)
+      const float* s_tf = nullptr;
+      if (!ROLLOUT && Env::tf_table_fits(a)) {
+        float* tab = s_head + BSX_BLOCK * HEAD + 4;
+        s_tf = tab;
+        if (t == 0) {
+          BSX_NO_CONTRACT
+          for (int k = threadIdx.x; k <= a.L; k += BSX_BLOCK) tab[k] = (float)(1.0 - (double)k / (double)a.L);
+        }
+      }
       if (t == 0) {
         for (int w = threadIdx.x; w < (PLANES + 1) * stride; w += BSX_BLOCK) planes[w] = 0u;
       } else {
@@ -537,7 +552,7 @@ __device__ __forceinline__ void small_obs_body(const typename Env::args& a, cons
       if (mine) {
         double reward = 0.0;
         float head[HEAD];
-        const bsx_bit_sink sink{planes, stride, (uint32_t)((int)threadIdx.x * numel + HEAD)};
+        const bsx_bit_sink sink{planes, stride, (uint32_t)((int)threadIdx.x * numel + HEAD), s_tf};
         type = Env::template step<LOG, MT, true>(a, i, oi, lane, step0 + (uint64_t)t, head, reward, &sink);
         bsx_emit_at<LOG, NOISE, F64, MT>(a.ctl, a.out, i, oi, lane, step0 + (uint64_t)t, type, reward);
 #pragma unroll
@@ -676,8 +691,9 @@ __global__ void __launch_bounds__(BSX_BLOCK) small_obs_lean_rollout_kernel(const
 // Dynamic LDS of one workgroup stepping `a`.
 template <class Env>
 static size_t small_obs_lds(const typename Env::args& a) {
-  if constexpr (Env::PACKED)     // PLANES data planes + the HEAD-position plane + the lanes' HEAD floats (padded)
-    return bsx_small_direct_shape(a.obs_numel) ? 0 : (size_t)(Env::PLANES + 1) * a.obs_numel * (BSX_BLOCK / 32) * 4 + (size_t)(BSX_BLOCK * Env::HEAD + 8) * 4;
+  if constexpr (Env::PACKED)     // PLANES data planes + the HEAD-position plane + the lanes' HEAD floats (padded) + the time fractions
+    return bsx_small_direct_shape(a.obs_numel) ? 0 : (size_t)(Env::PLANES + 1) * a.obs_numel * (BSX_BLOCK / 32) * 4 + (size_t)(BSX_BLOCK * Env::HEAD + 8) * 4 +
+                                                     (Env::tf_table_fits(a) ? ((size_t)a.L + 1) * 4 : 0);
   else return 0;
 }
 // does a single-step call of this segment take the row path (flat bit planes into a.rows + the wide-row store stream)?
@@ -994,6 +1010,18 @@ struct bandit_env : small_regs_defaults {
   }
 };
 
+// The time fraction 1 - t / L of the chains' rows (memory_chain.py:64, umbrella_chain.py:64): from the workgroup's LDS
+// table where the PACKED path staged one (bsx_bit_sink::tf), else the f64 division itself.  Evaluated ONCE per step(),
+// before the reset / step paths part ways.
+template <bool PACK, class Sink>
+__device__ __forceinline__ float bsx_chain_time_fraction(int t, int L, const Sink* sink) {
+  BSX_NO_CONTRACT
+  if constexpr (PACK) {
+    if (sink->tf != nullptr) return sink->tf[t];               // (t <= L; uniform branch)
+  }
+  return (float)(1.0 - (double)t / (double)L);
+}
+
 // ------------------------------------------------------------------------------ memory_chain
 #define MC_RESET_BIT (1 << 28)
 struct memory_chain_env {
@@ -1012,13 +1040,15 @@ struct memory_chain_env {
   };
   // Packed rows: HEAD = [time, query]; element 2+b is 0 unless t == 0, then +-1 by context bit b: plane 0 says
   // "non-zero", plane 1 carries the context bit (memory_rows, row_stream.h).
+  // (PACKED path: the time fractions in LDS when the chain has at most 1024 steps)
+  __host__ __device__ static bool tf_table_fits(const args& a) { return a.L <= 1023; }
   typedef memory_rows rows_t;
   static constexpr int HEAD = rows_t::HEAD, PLANES = rows_t::PLANES;
   __device__ static float decode(uint32_t nonzero, uint32_t bit) { return rows_t::decode(nonzero, bit); }
   template <bool PACK, class Sink>
   __device__ static void observe(const args& a, float* o, int t, int query, uint64_t ctx, const Sink* sink) {
     BSX_NO_CONTRACT
-    o[0] = (float)(1.0 - (double)t / (double)a.L);              // memory_chain.py:64
+    // (o[0], the time fraction of :64, is step()'s: bsx_chain_time_fraction)
     o[1] = (t == a.L - 1) ? (float)query : 0.0f;                // :66-67
     if constexpr (PACK) {
       if (Sink::ALWAYS || t == 0) {                             // :69-70 (a row in device memory is written in full)
@@ -1114,7 +1144,9 @@ struct memory_chain_env {
     int32_t st = a.state[i];
     int t = st & 0xFFFFF, query = (st >> 20) & 0xFF;
     uint64_t ctx = a.context[i];
-    if (a.ctl.force_reset || (st & MC_RESET_BIT)) {             // :91-97
+    const bool resets = a.ctl.force_reset || (st & MC_RESET_BIT);
+    o[0] = bsx_chain_time_fraction<PACK>(resets ? 0 : t, a.L, sink);   // :64 — of the state BEFORE the increment (:74), or of the fresh one
+    if (resets) {                                               // :91-97
       bsx_draws d;
       bsx_draws_begin<MT>(&d, a.ctl, i, lane, step);
       ctx = 0;
@@ -1158,6 +1190,7 @@ struct umbrella_chain_env {
     uint32_t* rows; int64_t row_plane_words;                   // bsx_call_t.row_scratch (bsx_rows.h) + words per plane, or nullptr
   };
   // Packed rows: HEAD = [need, has, time]; element 3+b is distractor bit b as 0.0 / 1.0 (one plane; umbrella_rows).
+  __host__ __device__ static bool tf_table_fits(const args& a) { return a.L <= 1023; }
   typedef umbrella_rows rows_t;
   static constexpr int HEAD = rows_t::HEAD, PLANES = rows_t::PLANES;
   __device__ static float decode(uint32_t bit, uint32_t) { return rows_t::decode(bit, 0u); }
@@ -1166,7 +1199,7 @@ struct umbrella_chain_env {
     BSX_NO_CONTRACT
     o[0] = (float)need;                                         // umbrella_chain.py:62
     o[1] = (float)has;                                          // :63
-    o[2] = (float)(1.0 - (double)t / (double)a.L);              // :64
+    // (o[2], the time fraction of :64, is step()'s: bsx_chain_time_fraction)
     uint32_t w = 0;
     if constexpr (PACK) {
       if (MT == 0 || d->mt == nullptr) {
@@ -1199,7 +1232,9 @@ struct umbrella_chain_env {
     // (every path below draws from block 0 of the lane's stream: computed once, before the lanes of a wave — at different
     // episode phases in any real batch — part ways; 659 -> see profiles/r05/ab_umbrella_shared_philox_block.log)
     bsx_draws_prime(&d);
-    if (a.ctl.force_reset || (st & UC_RESET_BIT)) {             // :87-92
+    const bool resets = a.ctl.force_reset || (st & UC_RESET_BIT);
+    o[2] = bsx_chain_time_fraction<PACK>(resets ? 0 : t + 1, a.L, sink);   // :64 — of the state AFTER the increment (:69)
+    if (resets) {                                               // :87-92
       t = 0;
       need = (int)bsx_bern(&d);
       has = (int)bsx_bern(&d);
