@@ -1048,7 +1048,8 @@ struct memory_chain_env {
   template <bool PACK, class Sink>
   __device__ static void observe(const args& a, float* o, int t, int query, uint64_t ctx, const Sink* sink) {
     BSX_NO_CONTRACT
-    // (o[0], the time fraction of :64, is step()'s: bsx_chain_time_fraction)
+    // (PACK: o[0], the time fraction of :64, is step()'s — bsx_chain_time_fraction)
+    if constexpr (!PACK) o[0] = (float)(1.0 - (double)t / (double)a.L);   // memory_chain.py:64
     o[1] = (t == a.L - 1) ? (float)query : 0.0f;                // :66-67
     if constexpr (PACK) {
       if (Sink::ALWAYS || t == 0) {                             // :69-70 (a row in device memory is written in full)
@@ -1145,7 +1146,8 @@ struct memory_chain_env {
     int t = st & 0xFFFFF, query = (st >> 20) & 0xFF;
     uint64_t ctx = a.context[i];
     const bool resets = a.ctl.force_reset || (st & MC_RESET_BIT);
-    o[0] = bsx_chain_time_fraction<PACK>(resets ? 0 : t, a.L, sink);   // :64 — of the state BEFORE the increment (:74), or of the fresh one
+    // :64 — of the state BEFORE the increment (:74), or of the fresh one (short rows: observe() does it, where it always was)
+    if constexpr (PACK) o[0] = bsx_chain_time_fraction<PACK>(resets ? 0 : t, a.L, sink);
     if (resets) {                                               // :91-97
       bsx_draws d;
       bsx_draws_begin<MT>(&d, a.ctl, i, lane, step);
