@@ -630,11 +630,17 @@ __global__ void __launch_bounds__(BSX_BLOCK) small_obs_kernel(const typename Env
   small_obs_body<Env, ROLLOUT, LOG, NOISE, MT, DIRECT, false, -1, -1, ROWS>(a, n_steps, blockIdx.x, s_obs, s_cnt);
 }
 
-// Eager step of a register-resident family, TWO lanes per thread (lean calls of 2^19+ lanes): thread t of workgroup b
-// advances lanes b*512 + t and b*512 + 256 + t, the loads of BOTH issued before the first use.  At 2^20 lanes the
-// one-lane kernel is 4096 workgroups = two dispatch rounds of a launch whose every wave is one dependent chain
-// {column loads -> step -> stores}; this one is a single round with twice the bytes in flight per wave.
-template <class Env, int V>
+// Eager step of a register-resident family, LPT = 2 or 4 lanes per thread (lean calls of 2^19+ lanes): thread t of
+// workgroup b advances lanes b*LPT*256 + h*256 + t, the loads of ALL of them issued before the first use.  At 2^20 lanes
+// the one-lane kernel is 4096 workgroups = two dispatch rounds of a launch whose every wave is one dependent chain
+// {column loads -> step -> stores}; this one is a single round with LPT times the bytes in flight per wave.
+// r04 measured cartpole / mountain_car only, called them equal and left it off.  Round 5, same call, two repetitions, with
+// bandit, discounting_chain and memory_len now register-resident (profiles/r05/ab_eager_lanes_per_thread.log), 1 -> 2 lanes
+// per thread at 2^20 lanes: bandit 9.55 -> 8.65 us, discounting_chain 8.7 -> 7.2, memory_len 12.0 -> 10.2, mountain_car
+// 9.95 -> 9.0, cartpole 18.9 -> 18.5 (noise); at 2^19: bandit 6.3 -> 6.1, memory_len 7.75 -> 7.1, mountain_car 6.7 -> 6.4,
+// discounting_chain equal, cartpole 10.8 -> 11.2 (SLOWER); at 2^18 all equal.  Four lanes per thread are never better than
+// two (discounting_chain 8.1, memory_len 10.4 at 2^20; everything slower at 2^19).  Env::EAGER_LPT_MIN_BLOCKS per family.
+template <class Env, int V, int LPT>
 __global__ void __launch_bounds__(BSX_BLOCK) small_obs_eager2_kernel(const typename Env::args a) {
   __shared__ unsigned int s_cnt[2];
   if (threadIdx.x < 2) s_cnt[threadIdx.x] = 0;
@@ -642,23 +648,24 @@ __global__ void __launch_bounds__(BSX_BLOCK) small_obs_eager2_kernel(const typen
   const int numel = Env::numel_of(V);
   const int64_t B = a.ctl.n_lanes;
   const uint64_t step = bsx_step_of(a.ctl);
-  int64_t i[2];
-  bool mine[2];
-  typename Env::regs rg[2];
-  int act[2], type[2] = {-1, -1};
+  int64_t i[LPT];
+  bool mine[LPT];
+  typename Env::regs rg[LPT];
+  int act[LPT], type[LPT];
 #pragma unroll
-  for (int h = 0; h < 2; ++h) {
-    i[h] = (int64_t)blockIdx.x * (2 * BSX_BLOCK) + h * BSX_BLOCK + threadIdx.x;
+  for (int h = 0; h < LPT; ++h) {
+    i[h] = (int64_t)blockIdx.x * (LPT * BSX_BLOCK) + h * BSX_BLOCK + threadIdx.x;
     mine[h] = i[h] < B;
     Env::clear(rg[h]);
     act[h] = 0;
+    type[h] = -1;
     if (mine[h]) {
       Env::load(a, i[h], rg[h]);
       if (!a.ctl.force_reset) act[h] = bsx_action(a.ctl, a.action, i[h], step);
     }
   }
 #pragma unroll
-  for (int h = 0; h < 2; ++h) {
+  for (int h = 0; h < LPT; ++h) {
     if (mine[h]) {
       double reward = 0.0;
       float o[8];
@@ -853,17 +860,23 @@ static void launch_regs_rollout(const typename Env::args& a, int n_steps, int v,
   }
 }
 
-// two lanes per thread from this many (one-lane) workgroups up; 0 = never
-#ifndef BSX_EAGER2_MIN_BLOCKS_DEFAULT
-#define BSX_EAGER2_MIN_BLOCKS_DEFAULT 0
-#endif
-template <class Env>
-static void launch_eager2(const typename Env::args& a, int v, hipStream_t st) {
+// LPT lanes per thread for the lean eager step of a register-resident family (Env::EAGER_LPT_MIN_BLOCKS: from this many
+// one-lane workgroups up, 0 = never; Env::EAGER_LPT)
+template <class Env, int LPT>
+static void launch_eager_lpt(const typename Env::args& a, int v, hipStream_t st) {
   if constexpr (Env::HAS_REGS) {
-    const dim3 g((unsigned)((a.ctl.n_lanes + 2 * BSX_BLOCK - 1) / (2 * BSX_BLOCK))), b(BSX_BLOCK);
-    if (v == 1) small_obs_eager2_kernel<Env, small_obs_v1<Env>()><<<g, b, 0, st>>>(a);
-    else small_obs_eager2_kernel<Env, 0><<<g, b, 0, st>>>(a);
+    const dim3 g((unsigned)((a.ctl.n_lanes + LPT * BSX_BLOCK - 1) / (LPT * BSX_BLOCK))), b(BSX_BLOCK);
+    if (v == 1) small_obs_eager2_kernel<Env, small_obs_v1<Env>(), LPT><<<g, b, 0, st>>>(a);
+    else small_obs_eager2_kernel<Env, 0, LPT><<<g, b, 0, st>>>(a);
   }
+}
+template <class Env>
+static void launch_eager2(const typename Env::args& a, int v, int lpt, hipStream_t st) {
+#ifdef BSX_TUNING
+  if (lpt == 4) { launch_eager_lpt<Env, 4>(a, v, st); return; }      // measured: never better than 2 (see below)
+#endif
+  (void)lpt;
+  launch_eager_lpt<Env, 2>(a, v, st);
 }
 
 template <class Env>
@@ -879,12 +892,15 @@ static int launch_small_obs(const typename Env::args& a, int n_steps, void* hip_
   // (and address every [B, numel] slab with 32-bit byte offsets: a slab of 4 GiB or more takes the generic loop)
   int regs_v = -1, Env_variant = 0;
   bool eager2 = false;
+  int eager_lpt = 2;
   if constexpr (Env::HAS_REGS) {
     Env_variant = Env::variant_of(a);
     if (a.ctl.n_lanes * (int64_t)a.obs_numel * 4 < ((int64_t)1 << 32)) regs_v = Env_variant;
     if (Env::PACKED && !bsx_small_direct_shape(a.obs_numel)) regs_v = -1;      // wide rows: the LDS bit planes, step by step
-    static const int eager2_min_blocks = bsx_env_int("BSX_EAGER2_MIN_BLOCKS", BSX_EAGER2_MIN_BLOCKS_DEFAULT);
+    static const int eager2_min_blocks = bsx_env_int("BSX_EAGER2_MIN_BLOCKS", Env::EAGER_LPT_MIN_BLOCKS);
+    static const int eager_lpt_knob = bsx_env_int("BSX_EAGER_LPT", Env::EAGER_LPT);
     eager2 = eager2_min_blocks > 0 && Env_variant >= 0 && (a.ctl.n_lanes + BSX_BLOCK - 1) / BSX_BLOCK >= eager2_min_blocks;
+    eager_lpt = eager_lpt_knob;
   }
   const int64_t blocks = (a.ctl.n_lanes + BSX_BLOCK - 1) / BSX_BLOCK;
   if (blocks > 0x7FFFFFFF) return BSX_EINVAL;
@@ -900,7 +916,7 @@ static int launch_small_obs(const typename Env::args& a, int n_steps, void* hip_
   // faster.
 #define SMALL_OBS_LAUNCH(D)                                                                                \
   {                                                                                                        \
-    if (n_steps == 1 && lean && eager2) launch_eager2<Env>(a, Env_variant, st);                            \
+    if (n_steps == 1 && lean && eager2) launch_eager2<Env>(a, Env_variant, eager_lpt, st);                 \
     else if (n_steps == 1 && lean) small_obs_kernel<Env, false, 0, 0, 0, D><<<g, b, lds, st>>>(a, 1);      \
     else if (n_steps == 1) small_obs_kernel<Env, false, -1, -1, -1, D><<<g, b, lds, st>>>(a, 1);           \
     else if (logging && noise && !mt) small_obs_kernel<Env, true, 1, 1, 0, D><<<g, b, lds, st>>>(a, n_steps); \
@@ -947,6 +963,7 @@ static int launch_small_obs(const typename Env::args& a, int n_steps, void* hip_
 struct small_regs_defaults {
   static constexpr bool POOLED_RESETS = false, ROWS_VIA_LDS = false;
   static constexpr int N_VARIANTS = 1, TABLE_MAX_BYTES = 0;
+  static constexpr int EAGER_LPT_MIN_BLOCKS = 2048, EAGER_LPT = 2;   // lean eager step: lanes per thread (launch_small_obs)
   __device__ static __forceinline__ void reset_part(const void*, uint64_t, uint64_t, int, unsigned, bsx_reset_pool*) {}
 };
 
@@ -1030,6 +1047,7 @@ struct memory_chain_env {
   // step behind a drain of the previous step's stores (three dependent round trips per step): memory_len/10 took 13.6 us
   // per step inside rollout(16) against 12.3 us for an eager step() (profiles/r05/bench_default_call1.json).
   static constexpr bool HAS_REGS = true, PACKED = true, POOLED_RESETS = false, ROWS_VIA_LDS = false;
+  static constexpr int EAGER_LPT_MIN_BLOCKS = 2048, EAGER_LPT = 2;
   static constexpr int N_VARIANTS = 1;
   __host__ __device__ static constexpr int numel_of(int) { return 3; }     // variant 0: one context bit, rows of 3 floats
   struct regs { int32_t st; uint64_t ctx; double inf[2]; };                // inf: total_perfect, total_regret in a fused rollout
@@ -1268,6 +1286,7 @@ struct umbrella_chain_env {
 #define DC_RESET_BIT (1 << 12)
 struct discounting_chain_env : small_regs_defaults {
   static constexpr bool HAS_REGS = true, PACKED = false;        // (register-resident in a fused rollout, like the bandit)
+  static constexpr int EAGER_LPT_MIN_BLOCKS = 4096;              // (two lanes per thread: equal at 2^19 lanes)
   __host__ __device__ static constexpr int numel_of(int) { return 2; }
   struct regs { int32_t st; };
   struct args {
@@ -1366,6 +1385,7 @@ struct cartpole_env {
   // The lane's state in registers: step() = load + core + store; the fused rollout loads once, runs core
   // T times and stores once (small_obs_body), instead of a round trip through L2 every step.
   static constexpr bool HAS_REGS = true, PACKED = false, POOLED_RESETS = true, ROWS_VIA_LDS = true;
+  static constexpr int EAGER_LPT_MIN_BLOCKS = 0, EAGER_LPT = 2;      // (equal within noise at 2^20 lanes, 4 % slower at 2^19)
   // compile-time variants of the lean fused rollout (small_obs_regs_rollout, V): 0 = classic, 1 = swing-up
   static constexpr int N_VARIANTS = 2;
   __host__ __device__ static constexpr int numel_of(int v) { return v == 1 ? 8 : 6; }
@@ -1576,6 +1596,7 @@ struct mountain_car_env {
   // (resets are rare — 1000-step episodes — and one Philox block: not pooled; the 12-byte rows of a wave are one dense
   // 768-byte range already: staging them gained nothing, profiles/r03/ab_rows_via_lds.log)
   static constexpr bool HAS_REGS = true, PACKED = false, POOLED_RESETS = false, ROWS_VIA_LDS = false;
+  static constexpr int EAGER_LPT_MIN_BLOCKS = 2048, EAGER_LPT = 2;
   static constexpr int N_VARIANTS = 1;
   __host__ __device__ static constexpr int numel_of(int) { return 3; }
   static int variant_of(const args&) { return 0; }

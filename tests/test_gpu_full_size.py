@@ -134,10 +134,13 @@ def test_two_lanes_per_thread_advance_on_ragged_batches(family, kwargs, extra):
   batches just above it: the last workgroup has one full half + a partial one / a single lane / only its first half;
   the tail lanes, the lanes around every 512-lane boundary and a random subsample against the oracle, bit-exact; LAST /
   FIRST counts over ALL lanes against the step types."""
-  n, seed, T = B + extra, 13, 14
+  _ragged_batch_against_oracle(family, kwargs, B + extra, extra, boundary=B)
+
+
+def _ragged_batch_against_oracle(family, kwargs, n, extra, boundary, seed=13, T=14):
   env = eu.make_env(family, kwargs, batch=n, lane_offset=0, seed=seed, num_buffers=1)
   rng = np.random.default_rng(extra)
-  idx = np.unique(np.concatenate([rng.integers(0, n, size=2048), np.arange(n - 600, n), [0, 255, 256, 511, 512, B - 1, B]]))
+  idx = np.unique(np.concatenate([rng.integers(0, n, size=2048), np.arange(n - 600, n), [0, 255, 256, 511, 512, boundary - 1, boundary]]))
   idx_t = torch.from_numpy(idx.astype(np.int64)).cuda()
   orc = coracle.OracleEnv(family, kwargs, idx.astype(np.uint64), seed=seed)
   g = torch.Generator(device='cuda'); g.manual_seed(extra)
@@ -155,6 +158,18 @@ def test_two_lanes_per_thread_advance_on_ragged_batches(family, kwargs, extra):
   assert (int(c[0]), int(c[1])) == (n_last, n_first)
   for k, v in orc.bsuite_info().items():
     np.testing.assert_array_equal(env.bsuite_info()[k][idx_t].cpu().numpy(), v, err_msg=k)
+
+
+@pytest.mark.parametrize('family,kwargs,n', [('bandit', dict(mapping_seed=0), (1 << 19) + 257), ('bandit', dict(mapping_seed=0), B + 1),
+                                            ('memory_chain', dict(memory_length=12, num_bits=1), (1 << 19) + 511),
+                                            ('discounting_chain', dict(mapping_seed=0), B + 257),
+                                            ('discounting_chain', dict(mapping_seed=3), (1 << 19) + 1)])
+def test_two_lanes_per_thread_eager_step_on_ragged_batches(family, kwargs, n):
+  """The lean eager step of the register-resident families runs two lanes per thread from 2048 one-lane workgroups up
+  (discounting_chain: 4096; small_obs_eager2_kernel, csrc/small_obs.h): ragged batches on either side of the gates, the
+  last workgroup with a partial first half / a single lane, against the oracle bit for bit (the physics families take the
+  same kernel at 2^20 lanes in test_physics_full_batch_one_step_teacher_forced)."""
+  _ragged_batch_against_oracle(family, kwargs, n, n & 1023, boundary=n & ~1023)
 
 
 def test_mnist_full_batch():

@@ -77,3 +77,22 @@ def test_wide_row_stream_chunk_counts():
     tail = p.stdout[-3000:]
     assert p.returncode == 0, tail
     assert ' passed' in tail and 'failed' not in tail, tail
+
+
+@pytest.mark.timeout(900)
+def test_two_lanes_per_thread_eager_step_at_small_shapes():
+  """small_obs_eager2_kernel (the lean eager step of bandit / discounting_chain / memory_len / cartpole / mountain_car
+  with two lanes per thread) is size-gated at 2048+ workgroups: every parity test of those families once more with
+  BSX_EAGER2_MIN_BLOCKS=1 (tuning build) — one-lane and ragged batches, both variants of cartpole; and with four lanes
+  per thread, the form that was measured and not adopted."""
+  from bsuite_amd import build as _build
+  for lpt in ('2', '4'):
+    env = dict(os.environ, BSX_NATIVE_LIB=_build.build(tuning=True), BSX_EAGER2_MIN_BLOCKS='1', BSX_EAGER_LPT=lpt, PYTHONPATH=ROOT)
+    p = subprocess.run([sys.executable, '-m', 'pytest', '-q', '-x', '-m', 'gpu', '-p', 'no:cacheprovider',
+                        'tests/test_gpu_golden.py', 'tests/test_gpu_oracle_batch.py', 'tests/test_gpu_dm_env_conformance.py',
+                        'tests/test_gpu_engine_features.py',
+                        '-k', 'bandit or discounting or memory or cartpole or mountain_car or swingup'],
+                       cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=400)
+    tail = p.stdout[-3000:]
+    assert p.returncode == 0, tail
+    assert ' passed' in tail and 'failed' not in tail, tail

@@ -37,6 +37,11 @@ BUDGET = {
     # configs 3/4: the physics families, eager and fused rollout (lean instantiations)
     'small_obs_kernel<cartpole_env, false, 0, 0, 0, true, false>': 40,
     'small_obs_kernel<mountain_car_env, false, 0, 0, 0, true, false>': 32,
+    # ... and the lean eager step with two lanes per thread (2^19+ lanes; cartpole's exists, ungated: measured equal)
+    'small_obs_eager2_kernel<bandit_env, 0, 2>': 32,
+    'small_obs_eager2_kernel<discounting_chain_env, 0, 2>': 32,
+    'small_obs_eager2_kernel<memory_chain_env, 0, 2>': 40,
+    'small_obs_eager2_kernel<mountain_car_env, 0, 2>': 32,
     # ... their lean fused rollouts: <family, BIG (pooled resets, staged rows), variant, table in LDS>
     'small_obs_lean_rollout_kernel<cartpole_env, true, 0, true>': 64,       # 8 waves: 16 workgroups per CU at 2^20 lanes = 8 + 8
     'small_obs_lean_rollout_kernel<cartpole_env, true, 1, true>': 72,       # swing-up (8-float rows, per-step info): 7 waves

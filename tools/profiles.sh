@@ -29,14 +29,14 @@ pm traffic catch $out/catch_pmc_traffic.json --kernels "bsx_advance2_kernel<catc
 pm traffic cartpole $out/cartpole_pmc_traffic.json --kernels "small_obs_kernel<cartpole_env" --alg-bytes $((85*B)) -- --steps 20 --warmup 4 $A --workload cartpole
 # (mountain_car lock-step: staggering its 1001-call episodes is ~10^4 torch launches, minutes under a PMC pass; in 24
 #  calls no lane resets either way)
-pm traffic mountain_car $out/mountain_car_pmc_traffic.json --kernels "small_obs_kernel<mountain_car_env" --alg-bytes $((49*B)) -- --steps 20 --warmup 4 $A --no-stagger --workload mountain_car
+pm traffic mountain_car $out/mountain_car_pmc_traffic.json --kernels "small_obs_kernel<mountain_car_env" "small_obs_eager2_kernel<mountain_car_env" --alg-bytes $((49*B)) -- --steps 20 --warmup 4 $A --no-stagger --workload mountain_car
 pm traffic sweep_closed $out/sweep_closed_pmc_traffic.json --kernels sweep_phase0_kernel pair_mixed_stream_kernel --alg-bytes 885580000 --last 40 -- --workload sweep --sweep-schedule closed --steps 40 --warmup 10
 pm traffic sweep_split $out/sweep_split_pmc_traffic.json --kernels sweep_phase0_kernel sweep_pipelined_kernel --alg-bytes 885580000 --last 40 -- --workload sweep --sweep-schedule split --steps 40 --warmup 10
 pm traffic sweep_pipelined $out/sweep_pipelined_pmc_traffic.json --kernels sweep_pipelined_kernel --alg-bytes 885580000 --last 40 -- --workload sweep --sweep-schedule pipelined --steps 40 --warmup 10
 # the other families north_star names, and the mnist bandit of the sweep: traffic + kernel averages
-pm traffic bandit $out/bandit_pmc_traffic.json --kernels "small_obs_kernel<bandit_env" --alg-bytes $((25*B)) -- --steps 20 --warmup 4 $A --workload bandit
-pm traffic discounting_chain $out/discounting_chain_pmc_traffic.json --kernels "small_obs_kernel<discounting_chain_env" --alg-bytes $((29*B)) -- --steps 20 --warmup 4 $A --workload discounting_chain
-pm traffic memory_len $out/memory_len_pmc_traffic.json --kernels "small_obs_kernel<memory_chain_env" --alg-bytes $((49*B)) -- --steps 20 --warmup 4 $A --workload memory_len
+pm traffic bandit $out/bandit_pmc_traffic.json --kernels "small_obs_kernel<bandit_env" "small_obs_eager2_kernel<bandit_env" --alg-bytes $((25*B)) -- --steps 20 --warmup 4 $A --workload bandit
+pm traffic discounting_chain $out/discounting_chain_pmc_traffic.json --kernels "small_obs_kernel<discounting_chain_env" "small_obs_eager2_kernel<discounting_chain_env" --alg-bytes $((29*B)) -- --steps 20 --warmup 4 $A --workload discounting_chain
+pm traffic memory_len $out/memory_len_pmc_traffic.json --kernels "small_obs_kernel<memory_chain_env" "small_obs_eager2_kernel<memory_chain_env" --alg-bytes $((49*B)) -- --steps 20 --warmup 4 $A --workload memory_len
 pm traffic umbrella_length $out/umbrella_length_pmc_traffic.json --kernels "small_obs_kernel<umbrella_chain_env" --alg-bytes $((113*B)) -- --steps 20 --warmup 4 $A --workload umbrella_length
 pm traffic mnist $out/mnist_pmc_traffic.json --kernels mnist_advance_kernel mnist_observe_kernel --alg-bytes $((3157*B)) -- --steps 20 --warmup 4 $A --workload mnist
 for w in bandit discounting_chain memory_len umbrella_length mnist; do
@@ -47,7 +47,7 @@ pm sq umbrella_length_eager $out/umbrella_length_eager_pmc_sq.json --kernels "sm
 for w in cartpole mountain_car; do
   ns=""; [ $w = mountain_car ] && ns="--no-stagger"
   pm sq ${w}_rollout16 $out/${w}_rollout16_pmc_sq.json --kernels "small_obs_lean_rollout_kernel<${w}_env" --last 4 -- --workload $w --rollout 16 --steps 64 --warmup 16 $A $ns
-  pm sq ${w}_eager $out/${w}_eager_pmc_sq.json --kernels "small_obs_kernel<${w}_env, false" -- --workload $w --steps 20 --warmup 4 $A $ns
+  pm sq ${w}_eager $out/${w}_eager_pmc_sq.json --kernels "small_obs_kernel<${w}_env, false" "small_obs_eager2_kernel<${w}_env" -- --workload $w --steps 20 --warmup 4 $A $ns
 done
 if [ "${1:-}" != quick ]; then
   for w in bandit discounting_chain memory_len umbrella_length umbrella_distract memory_size cartpole mountain_car catch deep_sea mnist; do
