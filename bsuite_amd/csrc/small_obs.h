@@ -60,7 +60,6 @@ struct bsx_bit_sink {
   int stride;              // words per plane = 8 * numel
   uint32_t base;           // flat bit index of the lane's element HEAD
   const float* tf = nullptr;  // LDS: the family's time fractions 1 - t / L for t = 0..L (small_obs_body, PACKED), or null
-  static constexpr bool ALWAYS = false;    // the tile is zero-filled before every step: only non-zero words need a put
   // ORs bits [32k, 32k+n) of the lane's bit string (n in 1..32, the low n bits of w) into plane p
   __device__ __forceinline__ void put(int p, int k, uint32_t w, int n) const {
     uint32_t word, lo, hi;
@@ -1070,15 +1069,13 @@ struct memory_chain_env {
     if constexpr (!PACK) o[0] = (float)(1.0 - (double)t / (double)a.L);   // memory_chain.py:64
     o[1] = (t == a.L - 1) ? (float)query : 0.0f;                // :66-67
     if constexpr (PACK) {
-      if (Sink::ALWAYS || t == 0) {                             // :69-70 (a row in device memory is written in full)
-        const uint32_t nz = t == 0 ? 0xFFFFFFFFu : 0u;
-        const uint64_t cx = t == 0 ? ctx : 0ull;
+      if (t == 0) {                                             // :69-70 (the tile is zero-filled before every step)
         const int n0 = a.nb < 32 ? a.nb : 32;
-        sink->put(0, 0, nz, n0);
-        sink->put(1, 0, (uint32_t)cx, n0);
+        sink->put(0, 0, 0xFFFFFFFFu, n0);
+        sink->put(1, 0, (uint32_t)ctx, n0);
         if (a.nb > 32) {
-          sink->put(0, 1, nz, a.nb - 32);
-          sink->put(1, 1, (uint32_t)(cx >> 32), a.nb - 32);
+          sink->put(0, 1, 0xFFFFFFFFu, a.nb - 32);
+          sink->put(1, 1, (uint32_t)(ctx >> 32), a.nb - 32);
         }
       }
     } else {

@@ -186,16 +186,32 @@ int bsx_sweep_launch_pipelined(bsx_group* streams_of, bsx_group* advances_of, hi
 // mnist / large catch boards, the packed rows of the chains) — the stream depends on them — and those that are a
 // small-observation segment's whole step, on which nothing in the step depends.  With the segments ordered so that the
 // second kind comes first in the phase-0 grid (g->split_block = the first workgroup of the first kind):
-//   launch 1   phase-0 workgroups [split_block, total): what the stream waits for, one dispatch round (~1500 workgroups
-//              of the 4213 at 2^20 lanes);
-//   launch 2   the store stream beside phase-0 workgroups [0, split_block) (sweep_pipelined_kernel with both halves
+//   launch 1   phase-0 workgroups [split, total), split <= split_block: what the stream waits for (920 workgroups of the
+//              4213 at 2^20 lanes) + what else fits the same dispatch round (below);
+//   launch 2   the store stream beside phase-0 workgroups [0, split) (sweep_pipelined_kernel with both halves
 //              taken from THIS group): the latency-bound small families hide beside the 850 MB of stores instead of
 //              standing in front of them; their last workgroup to retire bumps the call counter.
 // Everything in a step reads the actions of that step only, so the schedule is closed-loop: the TimeSteps of step s are
 // complete when launch 2 ends.
+#ifndef BSX_SPLIT_ROUND_DEFAULT
+#define BSX_SPLIT_ROUND_DEFAULT 2420    // workgroups of launch 1 when phase 0 does not fit one dispatch round; 0 = the lane advance only
+#endif
 int bsx_sweep_launch_split(bsx_group* g, hipStream_t st) {
-  const int64_t split = g->split_block;
-  if (split < 0 || split > g->total_blocks) return BSX_EMODE;
+  if (g->split_block < 0 || g->split_block > g->total_blocks) return BSX_EMODE;
+  // Launch 1 is one dispatch round whatever it holds (the machine has 2048 workgroup slots at this kernel's 8 waves per
+  // SIMD, and the first to retire make room while the dispatcher is still placing), and the lane advance fills less than
+  // half of it: when phase 0 is MORE than one round, launch 1 is topped up with small-observation workgroups — the last,
+  // lightest ones of their part of the grid — which then no longer compete with the store stream in launch 2.  Same
+  // call, five repetitions at 2^20 lanes (920 advance workgroups; profiles/r05/ab_sweep_split_point*.log): 164.2 us per
+  // sweep step with none, 163.0 with 1200, 162.0 with 1500 (every repetition below every one of the plain split), 163.2
+  // with 1800, noise from 2200 up; with ALL of them (= phase 0 | stream) 168.  On a second box, three repetitions
+  // (ab_sweep_split_order.log): 168.5 -> 166.9 (launch 1 = 2420 workgroups), 166.7 (3000), 168.3 (3600); with the small
+  // segments in narrow-rows-first order, i.e. the WIDE rows topping launch 1 up, 167.1 -> 167.4 / 170.6 / 169.1: not that.
+  static const int round = bsx_env_int("BSX_SPLIT_ROUND", BSX_SPLIT_ROUND_DEFAULT);
+  int64_t extra = 0;
+  if (g->total_blocks > round) extra = round - (g->total_blocks - g->split_block);
+  if (extra < 0) extra = 0;
+  const int64_t split = g->split_block > extra ? g->split_block - extra : 0;
   const int64_t n_tail = g->total_blocks - split;
   if (n_tail > 0)
     sweep_phase0_kernel<<<dim3((unsigned)n_tail), dim3(BSX_BLOCK), g->lds_bytes, st>>>(

@@ -96,3 +96,21 @@ def test_two_lanes_per_thread_eager_step_at_small_shapes():
     tail = p.stdout[-3000:]
     assert p.returncode == 0, tail
     assert ' passed' in tail and 'failed' not in tail, tail
+
+
+@pytest.mark.timeout(900)
+def test_split_sweep_step_with_a_topped_up_first_launch():
+  """bsx_group_step_split tops launch 1 up with small-observation workgroups when phase 0 is more than one dispatch round
+  (BSX_SPLIT_ROUND_DEFAULT workgroups, csrc/sweep_mixed.hip) — in-process only the 2^20-lane tests get there
+  (test_gpu_benched_sizes.py).  The sweep-group tests once more through the tuning build with the round at 3 and 20
+  workgroups: launch 1 = the lane advance alone / + a few / + all of the small segments' workgroups, the call counter
+  bumped from whichever launch retires the last of them."""
+  from bsuite_amd import build as _build
+  for r in ('3', '20'):
+    env = dict(os.environ, BSX_NATIVE_LIB=_build.build(tuning=True), BSX_SPLIT_ROUND=r, PYTHONPATH=ROOT)
+    p = subprocess.run([sys.executable, '-m', 'pytest', '-q', '-x', '-m', 'gpu', '-p', 'no:cacheprovider',
+                        'tests/test_gpu_sweep_batch.py', '-k', 'split or sweep'],
+                       cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=400)
+    tail = p.stdout[-3000:]
+    assert p.returncode == 0, tail
+    assert ' passed' in tail and 'failed' not in tail, tail
