@@ -413,11 +413,10 @@ __device__ __forceinline__ void small_obs_regs_rollout(const typename Env::args&
 // TABSEL: the register-resident families' table (cartpole's time fractions) is staged in LDS (1) or read from device
 // memory (0) — the launcher knows; -1 = both loops in the kernel, chosen per launch by table_fits().
 template <class Env, bool ROLLOUT, int LOG, int NOISE, int MT, bool DIRECT_ARG, bool BIG = false, int V = -1, int TABSEL = -1,
-          bool ROWS_ARG = false, bool WTILE_ARG = false>
+          bool ROWS_ARG = false>
 __device__ __forceinline__ void small_obs_body(const typename Env::args& a, const int n_steps_arg,
                                                const uint32_t block_id, float* s_obs, unsigned int* s_cnt) {
   constexpr bool ROWS = ROWS_ARG && Env::PACKED && !ROLLOUT;         // wide rows, packed, into the call's row scratch
-  constexpr bool WTILE = WTILE_ARG && Env::PACKED && !ROLLOUT && !ROWS;   // wide rows, one tile of 64 lanes per WAVE
   constexpr bool DIRECT = DIRECT_ARG || !Env::PACKED;
   // (a family whose row length is a parameter — memory_chain — is register-resident in the rows its own thread stores)
   if constexpr (ROLLOUT && Env::HAS_REGS && (DIRECT_ARG || !Env::PACKED)) {
@@ -502,93 +501,6 @@ __device__ __forceinline__ void small_obs_body(const typename Env::args& a, cons
 #pragma unroll
         for (int p = 0; p < R::PLANES; ++p)
           for (uint32_t w = (uint32_t)wl; w < wstride; w += BSX_WAVE) gp[(uint64_t)p * (uint64_t)a.row_plane_words + w] = wplanes[(uint32_t)p * wstride + w];
-      }
-    } else if constexpr (WTILE) {
-      // Wide rows, a single step, ONE TILE PER WAVE: the bit planes of the row path above (flat planes of the wave's 64
-      // lanes in wave-private LDS, 2 * numel words each, bsx_rows.h) and, right behind them, the store stream of
-      // row_stream.h over the wave's own 64 x numel floats — a chunk is one aligned nibble of each plane plus the float
-      // heads that fall into it, read from the wave's LDS.  No workgroup barrier between the step and the stores (the
-      // PACKED path below has three per step, and every wave's stores wait for the slowest wave's loads): the waves of
-      // a workgroup share only the time-fraction table and the episode counters.
-      typedef typename Env::rows_t R;
-      const int wl = (int)(threadIdx.x & 63u);
-      const uint32_t wstride = 2u * (uint32_t)numel;                       // words per plane of one wave
-      const uint32_t wwords = (uint32_t)R::PLANES * wstride + (uint32_t)(BSX_WAVE * R::NF);
-      uint32_t* __restrict__ wplanes = reinterpret_cast<uint32_t*>(s_obs) + (threadIdx.x >> 6) * wwords;
-      float* __restrict__ whead = reinterpret_cast<float*>(wplanes + (uint32_t)R::PLANES * wstride);   // [NF][64]
-      const float* s_tf = nullptr;
-      if (Env::tf_table_fits(a)) {                                         // (small_obs_lds has room for it: see there)
-        BSX_NO_CONTRACT
-        float* tab = s_obs + (BSX_BLOCK / BSX_WAVE) * wwords;
-        s_tf = tab;
-        for (int k = threadIdx.x; k <= a.L; k += BSX_BLOCK) tab[k] = (float)(1.0 - (double)k / (double)a.L);
-      }
-      for (uint32_t w = (uint32_t)wl; w < (uint32_t)R::PLANES * wstride; w += BSX_WAVE) wplanes[w] = 0u;
-      __syncthreads();                                                     // the table (the planes are the wave's own)
-      if (mine) {
-        double reward = 0.0;
-        float o[Env::HEAD];
-        const bsx_bit_sink sink{wplanes, (int)wstride, (uint32_t)(wl * numel + Env::HEAD), s_tf};
-        type = Env::template step<LOG, MT, true>(a, i, oi, lane, step0 + (uint64_t)t, o, reward, &sink);
-        bsx_emit_at<LOG, NOISE, F64, MT>(a.ctl, a.out, i, oi, lane, step0 + (uint64_t)t, type, reward);
-        uint32_t head_bits = 0u;
-#pragma unroll
-        for (int k = 0; k < Env::HEAD; ++k) {
-          bool is_float = false;
-#pragma unroll
-          for (int q = 0; q < R::NF; ++q)
-            if ((int)bsx_rows_fpos(R::KIND, q) == k) { whead[q * BSX_WAVE + wl] = o[k]; is_float = true; }
-          if (!is_float) head_bits |= (o[k] != 0.0f ? 1u : 0u) << k;     // (0.0 / 1.0: decode(1) == 1.0f for such a family)
-        }
-        if (R::NF < Env::HEAD) {
-          const bsx_bit_sink hs{wplanes, (int)wstride, (uint32_t)(wl * numel)};
-          hs.put(0, 0, head_bits, Env::HEAD);
-        }
-      }
-      bsx_count_types(a.ctl, type, s_cnt);
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-      __builtin_amdgcn_wave_barrier();
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-      const int64_t wave_lane0 = lane0 + (int64_t)(threadIdx.x & ~63u);
-      const int64_t wave_left = B - wave_lane0;
-      if (wave_left > 0) {                                                 // (uniform per wave)
-        const int lanes_w = wave_left < BSX_WAVE ? (int)wave_left : BSX_WAVE;
-        float* __restrict__ tile = a.out.observation + wave_lane0 * (int64_t)numel;   // 256 * numel bytes into the array: 16-byte aligned
-        bsx_f4* __restrict__ t4 = reinterpret_cast<bsx_f4*>(tile);
-        const int total = lanes_w * numel, n_chunks = total >> 2;
-        const uint32_t numel_magic = a.numel_magic;                        // f / numel = __umulhi(f, magic), f < 2^16
-        for (int c = wl; c < n_chunks; c += BSX_WAVE) {
-          const uint32_t f = (uint32_t)c << 2;
-          const uint32_t dl = __umulhi(f, numel_magic);                    // the lane (of the wave) the chunk starts in
-          const uint32_t r = f - dl * (uint32_t)numel;
-          const uint32_t sh = ((uint32_t)c & 7u) << 2;
-          const uint32_t n0 = wplanes[c >> 3] >> sh;
-          const uint32_t n1 = R::PLANES > 1 ? wplanes[wstride + (c >> 3)] >> sh : 0u;
-          uint32_t nx, j0, j1 = 4u, h0 = 0u, h1 = 0u;
-          j0 = bsx_rows_head_slot(bsx_rows_fpos(R::KIND, 0), r, (uint32_t)numel, &nx);
-          if (j0 < 4u) h0 = __float_as_uint(whead[dl + nx]);
-          if (R::NF > 1) {
-            j1 = bsx_rows_head_slot(bsx_rows_fpos(R::KIND, 1), r, (uint32_t)numel, &nx);
-            if (j1 < 4u) h1 = __float_as_uint(whead[BSX_WAVE + dl + nx]);
-          }
-          uint32_t v0, v1, v2, v3;
-          bsx_rows_chunk(R::KIND, n0, n1, j0, h0, j1, h1, &v0, &v1, &v2, &v3);
-          bsx_f4 q4;
-          q4.x = __uint_as_float(v0); q4.y = __uint_as_float(v1); q4.z = __uint_as_float(v2); q4.w = __uint_as_float(v3);
-          t4[c] = q4;
-        }
-        // the < 4 floats behind the last whole chunk of a ragged wave
-        for (int f = (n_chunks << 2) + wl; f < total; f += BSX_WAVE) {
-          const uint32_t dl = __umulhi((uint32_t)f, numel_magic);
-          const uint32_t r = (uint32_t)f - dl * (uint32_t)numel;
-          const uint32_t b0 = (wplanes[f >> 5] >> (f & 31)) & 1u;
-          const uint32_t b1 = R::PLANES > 1 ? (wplanes[wstride + (f >> 5)] >> (f & 31)) & 1u : 0u;
-          uint32_t v = bsx_rows_decode(R::KIND, b0, b1);
-#pragma unroll
-          for (int q = 0; q < R::NF; ++q)
-            if (r == bsx_rows_fpos(R::KIND, q)) v = __float_as_uint(whead[q * BSX_WAVE + dl]);
-          tile[f] = __uint_as_float(v);
-        }
       }
     } else if constexpr (DIRECT) {
       // the waves of a block (and the steps of a fused rollout) never wait for each other
@@ -715,13 +627,6 @@ __global__ void __launch_bounds__(BSX_BLOCK) small_obs_kernel(const typename Env
   extern __shared__ __attribute__((aligned(16))) float s_obs[];
   __shared__ unsigned int s_cnt[2];
   small_obs_body<Env, ROLLOUT, LOG, NOISE, MT, DIRECT, false, -1, -1, ROWS>(a, n_steps, blockIdx.x, s_obs, s_cnt);
-}
-// ... a single step of wide rows with one tile per wave (small_obs_body, WTILE)
-template <class Env, int LOG, int NOISE, int MT>
-__global__ void __launch_bounds__(BSX_BLOCK) small_obs_wave_tile_kernel(const typename Env::args a) {
-  extern __shared__ __attribute__((aligned(16))) float s_obs[];
-  __shared__ unsigned int s_cnt[2];
-  small_obs_body<Env, false, LOG, NOISE, MT, false, false, -1, -1, false, true>(a, 1, blockIdx.x, s_obs, s_cnt);
 }
 
 // Eager step of a register-resident family, LPT = 2 or 4 lanes per thread (lean calls of 2^19+ lanes): thread t of
@@ -973,10 +878,6 @@ static void launch_eager2(const typename Env::args& a, int v, int lpt, hipStream
   launch_eager_lpt<Env, 2>(a, v, st);
 }
 
-// wide rows, single steps: one tile per wave (1) or one per workgroup (0: the PACKED path and its three barriers)
-#ifndef BSX_WAVE_TILE_DEFAULT
-#define BSX_WAVE_TILE_DEFAULT 0
-#endif
 template <class Env>
 static int launch_small_obs(const typename Env::args& a, int n_steps, void* hip_stream) {
   hipStream_t st = (hipStream_t)hip_stream;
@@ -1045,14 +946,6 @@ static int launch_small_obs(const typename Env::args& a, int n_steps, void* hip_
         else if (k == 4) bsx_row_stream_kernel<typename Env::rows_t, 4><<<gs, b, 0, st>>>(sg);
         else bsx_row_stream_kernel<typename Env::rows_t, 2><<<gs, b, 0, st>>>(sg);
         return bsx_launch_status();
-      }
-      if constexpr (Env::PACKED) {
-        static const int wave_tile = bsx_env_int("BSX_WAVE_TILE", BSX_WAVE_TILE_DEFAULT);
-        if (n_steps == 1 && wave_tile != 0) {
-          if (lean) small_obs_wave_tile_kernel<Env, 0, 0, 0><<<g, b, lds, st>>>(a);
-          else small_obs_wave_tile_kernel<Env, -1, -1, -1><<<g, b, lds, st>>>(a);
-          return bsx_launch_status();
-        }
       }
       SMALL_OBS_LAUNCH(false)
       return bsx_launch_status();
