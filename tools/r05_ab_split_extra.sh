@@ -1,3 +1,4 @@
+# RECORD of a measurement: BSX_SWEEP_SMALL_ORDER (a hook in sweep_batch.prepare_groups) was not kept; BSX_SPLIT_ROUND is the tuning knob of the adopted top-up.
 # split closed-loop sweep step: which small-observation workgroups top launch 1 up — the narrow-row families at the end of
 # the wide-first order (default), or the wide-row ones (narrow-first order) — and how many.  Tuning build, BSX_SPLIT_ROUND.
 out=$PWD/gpurun_out/r05f; mkdir -p $out

@@ -1,3 +1,4 @@
+# RECORD of a measurement, not a tool: BSX_WAVE_TILE exists in commit 81bebd8 only (the experiment was removed afterwards).
 # wide rows of memory_chain / umbrella_chain, single steps: one tile of 64 lanes per WAVE (small_obs_wave_tile_kernel: wave-private
 # flat bit planes, no workgroup barrier between step and stores) against one tile of 256 lanes per workgroup (the PACKED
 # path: three barriers per step).  Tuning build, BSX_WAVE_TILE.
