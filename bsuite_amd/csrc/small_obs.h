@@ -1026,6 +1026,10 @@ struct bandit_env : small_regs_defaults {
   }
 };
 
+// the chains' step(): the action loaded beside the state word (1) or where the episode needs it (0)
+#ifndef BSX_EARLY_ACTION
+#define BSX_EARLY_ACTION 1
+#endif
 // The time fraction 1 - t / L of the chains' rows (memory_chain.py:64, umbrella_chain.py:64): from the workgroup's LDS
 // table where the PACKED path staged one (bsx_bit_sink::tf), else the f64 division itself.  Evaluated ONCE per step(),
 // before the reset / step paths part ways.
@@ -1158,6 +1162,7 @@ struct memory_chain_env {
   __device__ static int step(const args& a, int64_t i, int64_t oi, uint64_t lane, uint64_t step, float* o, double& reward,
                              const Sink* sink = nullptr) {
     int32_t st = a.state[i];
+    const int act = BSX_EARLY_ACTION && !a.ctl.force_reset ? bsx_action(a.ctl, a.action, oi, step) : 0;   // (see umbrella_chain_env::step)
     int t = st & 0xFFFFF, query = (st >> 20) & 0xFF;
     uint64_t ctx = a.context[i];
     const bool resets = a.ctl.force_reset || (st & MC_RESET_BIT);
@@ -1189,7 +1194,7 @@ struct memory_chain_env {
     // (the episode's one bsuite_info update: a no-return atomic when episodes are long, i.e. when only a few lanes of a
     // wave end on a given call — bsx_info_add)
     const bool quiet = a.L >= 8 && bsx_info_quiet<LOG>(a.ctl);
-    if (bsx_action(a.ctl, a.action, oi, step) == (int)((ctx >> query) & 1ull)) { reward = 1.0; bsx_info_add(quiet, &a.info[i], 1.0); }   // :83-85
+    if ((BSX_EARLY_ACTION ? act : bsx_action(a.ctl, a.action, oi, step)) == (int)((ctx >> query) & 1ull)) { reward = 1.0; bsx_info_add(quiet, &a.info[i], 1.0); }   // :83-85
     else { reward = -1.0; bsx_info_add(quiet, &a.info[a.ctl.n_lanes + i], 2.0); }   // :86-88
     a.state[i] = t | (query << 20) | MC_RESET_BIT;
     return BSX_LAST;
@@ -1243,6 +1248,10 @@ struct umbrella_chain_env {
                              const Sink* sink = nullptr) {
     BSX_NO_CONTRACT
     int32_t st = a.state[i];
+    // (the action matters on the episode's first step only, but which lanes are there is known when the state word has
+    // arrived: loaded now, beside it, not in a second dependent round trip — in any real batch every wave holds such a
+    // lane, and the line is fetched for it anyway)
+    const int act = BSX_EARLY_ACTION && !a.ctl.force_reset ? bsx_action(a.ctl, a.action, oi, step) : 0;
     int t = st & 0xFFFFF, need = (st >> 20) & 1, has = (st >> 21) & 1;
     bsx_draws d;
     bsx_draws_begin<MT>(&d, a.ctl, i, lane, step);
@@ -1261,7 +1270,7 @@ struct umbrella_chain_env {
       return BSX_FIRST;
     }
     t += 1;                                                     // :69
-    if (t == 1) has = (bsx_action(a.ctl, a.action, oi, step) == 1);                       // :71-72 (action_spec: {0,1})
+    if (t == 1) has = ((BSX_EARLY_ACTION ? act : bsx_action(a.ctl, a.action, oi, step)) == 1);   // :71-72 (action_spec: {0,1})
     int type;
     if (t == a.L) {                                             // :74-81
       if (has == need) reward = 1.0;
