@@ -430,7 +430,9 @@ int bsx_group_step_phase(bsx_group_t* g, int32_t phase, void* hip_stream);
  * TimeSteps of the step complete when it returns to the stream — cut so that only what the store stream depends on
  * stands in front of it: launch 1 runs the phase-0 workgroups of the segments that have a share of the stream (lane
  * advance of deep_sea / mnist / large catch boards, packed rows of the chains), launch 2 the store stream BESIDE the
- * whole step of every other small-observation segment, whose last workgroup bumps the call counter.  Needs the
+ * whole step of every other small-observation segment, whose last workgroup bumps the call counter.  (When phase 0 is
+ * more than one dispatch round, launch 1 also takes the LAST small-observation workgroups of the group, up to one round
+ * in all: put the cheapest small-observation segments right before the ones with a stream share.)  Needs the
  * segments with a stream share to be the LAST segments of the group (set the others first): BSX_EMODE otherwise. */
 int bsx_group_step_split(bsx_group_t* g, void* hip_stream);
 /* Software-pipelined sweep step (ABI v9), for callers whose actions do not depend on the observations
