@@ -42,6 +42,8 @@ HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICR
 #              episode period in calls used to stagger the lanes' phases)
 WORKLOADS = {
     'deep_sea': ('deep_sea/10', 'deep_sea', dict(size=30, mapping_seed=42), 900, 8, 31),
+    # deep_sea/9: rows of 784 floats — the geometry control of the mnist bandit's store stream (VERDICT r05 next #1a)
+    'deep_sea_28': ('deep_sea/9', 'deep_sea', dict(size=28, mapping_seed=42), 784, 8, 29),
     'catch': ('catch/0', 'catch', dict(), 50, 8, 10),
     'catch_noise': ('catch_noise/0', 'catch', dict(), 50, 8, 10),     # RewardNoise(0.1): the non-lean kernel instantiations
     'cartpole': ('cartpole/0', 'cartpole', dict(), 6, 48, 128),

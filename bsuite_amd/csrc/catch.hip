@@ -61,7 +61,7 @@ extern "C" int bsx_group_set_catch(bsx_group_t* g, int32_t index, const bsx_catc
     if (fused) a.tile_cells_magic = sg.cells_magic;
     return bsx_mixed_put(g, BSX_FAM_CATCH, index, call, &a, sizeof(a), &sg, sizeof(sg),
                               (uint64_t)(a.ctl.n_lanes + BSX_BLOCK - 1) / BSX_BLOCK,
-                              fused ? 0 : bsx_flat_blocks((uint64_t)a.ctl.n_lanes * cells, 2), 0);
+                              fused ? 0 : bsx_flat_blocks((uint64_t)a.ctl.n_lanes * cells, PAIR_CATCH_K), 0);
   }
   rc = bsx_group_check_set(g, BSX_FAM_CATCH, index, call, sizeof(catch_fam::args),
                            sizeof(bsx_stream_seg<catch_hot>), 0);

@@ -206,7 +206,7 @@ extern "C" int bsx_group_set_deep_sea(bsx_group_t* g, int32_t index, const bsx_d
     sg.cells_magic = bsx_div_magic(cells); sg.dv = bsx_make_div64(cells); sg.fn = deep_sea_hot{cfg->size};
     return bsx_mixed_put(g, BSX_FAM_DEEP_SEA, index, call, &a, sizeof(a), &sg, sizeof(sg),
                               (uint64_t)(a.ctl.n_lanes + BSX_BLOCK - 1) / BSX_BLOCK,
-                              bsx_flat_blocks((uint64_t)a.ctl.n_lanes * cells, 4), 0);
+                              bsx_flat_blocks((uint64_t)a.ctl.n_lanes * cells, PAIR_DEEP_SEA_K), 0);
   }
   rc = bsx_group_check_set(g, BSX_FAM_DEEP_SEA, index, call, sizeof(deep_sea_fam::args),
                            sizeof(bsx_stream_seg<deep_sea_hot>), 0);

@@ -25,32 +25,22 @@ __global__ void __launch_bounds__(BSX_BLOCK) mnist_advance_group_kernel(const mn
   mnist_advance_body(table[w.seg], w.block, s_cnt);
 }
 
-template <int K, int VAR>
+template <int K>
 __global__ void __launch_bounds__(BSX_BLOCK) mnist_observe_kernel(const mnist_observe_args a) {
   __shared__ float s_lut[MNIST_LUT_FLOATS];
-  mnist_observe_body<K, VAR>(a, blockIdx.x, s_lut);
+  mnist_observe_body<K>(a, blockIdx.x, s_lut);
 }
 
-template <int K, int VAR>
+template <int K>
 __global__ void __launch_bounds__(BSX_BLOCK) mnist_observe_group_kernel(const mnist_observe_args* __restrict__ table,
                                                                         const bsx_group_index gi) {
   __shared__ float s_lut[MNIST_LUT_FLOATS];
   const bsx_group_slot w = bsx_group_find(gi, (int)blockIdx.x);
-  mnist_observe_body<K, VAR>(table[w.seg], w.block, s_lut);
+  mnist_observe_body<K>(table[w.seg], w.block, s_lut);
 }
 
-static int mnist_variant() {
-  static const int v = bsx_env_int("BSX_MNIST_VARIANT", 3) & 7;
-  return v;
-}
-static int mnist_group_k() {
-  // grouped workgroups pay two extra dependent loads (map entry, argument table) before their first
-  // store: 32 KiB runs amortise that better than the 16 KiB of the single-segment kernel
-  // (profiles/r01/ab_mnist_group_k.log: 100 -> 86 us per sweep step)
-  static const int v = bsx_env_int("BSX_MNIST_GROUP_K", 8);
-  return (v == 2 || v == 4) ? v : 8;
-}
-
+// 16 KiB per workgroup: a sharp optimum of the straight-line body (K = 3: 5.95, 4: 7.0, 5: 5.9, 8: 5.9 TB/s at 2^20 lanes,
+// profiles/r06/mnist_stream_microbench_2.log)
 #define MNIST_K 4
 
 static int mnist_make(const bsx_mnist_t* cfg, const bsx_call_t* call, const int32_t* action, int32_t* state,
@@ -69,10 +59,9 @@ static int mnist_make(const bsx_mnist_t* cfg, const bsx_call_t* call, const int3
   a->images = cfg->images; a->labels = cfg->labels; a->num_data = cfg->num_data; a->num_pixels = cfg->num_pixels;
   o->obs = out.observation; o->state = state; o->images = cfg->images; o->n_lanes = call->n_lanes;
   o->cells = (uint32_t)cfg->num_pixels; o->cells_magic = bsx_div_magic(o->cells); o->dv = bsx_make_div64(o->cells);
-  // A/B knob (tuning build): compute the reference's table (np.float32(int8) / 255, bsx_mnist_pixel_value) in the kernel
-  // instead of looking it up in LDS — exact, and measured slower (see pair_mixed.h): the product library always looks up
-  static const int arith_env = bsx_env_int("BSX_MNIST_ARITH", 0);
-  o->arith = arith_env != 0; o->_pad = 0;
+  // the reference's table (np.float32(int8) / 255) is recognised and then COMPUTED per wave (bsx_mnist_pixel_value, exact);
+  // any other table is read from the arguments
+  o->arith = 1; o->_pad = 0;
   for (int k = 0; k < 256; ++k) {
     o->lut[k] = cfg->pixel_lut[k];
     const float want = bsx_mnist_pixel_value((uint32_t)k, 0);
@@ -101,17 +90,7 @@ extern "C" int bsx_mnist_step(const bsx_mnist_t* cfg, const bsx_call_t* call, co
     a.out.reward = out.reward + off; a.out.discount = out.discount + off; a.out.step_type = out.step_type + off;
     mnist_advance_kernel<<<dim3((unsigned)blocks_a), dim3(BSX_BLOCK), 0, st>>>(a);
     o.obs = out.observation + off * (int64_t)o.cells;
-    const dim3 go((unsigned)blocks_o), bo(BSX_BLOCK);
-#if defined(BSX_TUNING)
-    if (o.arith) { mnist_observe_kernel<MNIST_K, 3 | 8><<<go, bo, 0, st>>>(o); continue; }
-#endif
-    switch (mnist_variant()) {
-      case 1: mnist_observe_kernel<MNIST_K, 1><<<go, bo, 0, st>>>(o); break;
-      case 2: mnist_observe_kernel<MNIST_K, 2><<<go, bo, 0, st>>>(o); break;
-      case 3: mnist_observe_kernel<MNIST_K, 3><<<go, bo, 0, st>>>(o); break;
-      case 7: mnist_observe_kernel<MNIST_K, 7><<<go, bo, 0, st>>>(o); break;
-      default: mnist_observe_kernel<MNIST_K, 0><<<go, bo, 0, st>>>(o); break;
-    }
+    mnist_observe_kernel<MNIST_K><<<dim3((unsigned)blocks_o), dim3(BSX_BLOCK), 0, st>>>(o);
   }
   return bsx_launch_status();
 }
@@ -121,14 +100,8 @@ static int mnist_group_launch(bsx_group* g, int phase, hipStream_t st) {
     mnist_advance_group_kernel<<<dim3((unsigned)g->total_blocks), dim3(BSX_BLOCK), 0, st>>>(
         (const mnist_args*)g->d_args, g->index1());
   if (phase == 0) return (int)hipGetLastError();
-  const dim3 go((unsigned)g->total_blocks2), bo(BSX_BLOCK);
-  const mnist_observe_args* tb = (const mnist_observe_args*)g->d_args2;
-  const int k = mnist_group_k(), var = mnist_variant();
-#define MN_GO(K, V) mnist_observe_group_kernel<K, V><<<go, bo, 0, st>>>(tb, g->index2())
-  if (k == 8) { if (var == 3) MN_GO(8, 3); else MN_GO(8, 0); }
-  else if (k == 2) { if (var == 3) MN_GO(2, 3); else MN_GO(2, 0); }
-  else { if (var == 3) MN_GO(4, 3); else MN_GO(4, 0); }
-#undef MN_GO
+  mnist_observe_group_kernel<PAIR_MNIST_K><<<dim3((unsigned)g->total_blocks2), dim3(BSX_BLOCK), 0, st>>>(
+      (const mnist_observe_args*)g->d_args2, g->index2());
   return (int)hipGetLastError();
 }
 
@@ -138,7 +111,7 @@ extern "C" int bsx_group_set_mnist(bsx_group_t* g, int32_t index, const bsx_mnis
   int rc;
   mnist_args a;
   mnist_observe_args o;
-  if (bsx_is_mixed_pair_group(g)) {            // one segment of the mixed two-kernel group (8 x 4 KiB runs)
+  if (bsx_is_mixed_pair_group(g)) {            // one segment of the mixed two-kernel group (PAIR_MNIST_K x 4 KiB runs)
     rc = mnist_make(cfg, call, action, state, out, info, &a, &o);
     if (rc != 0) return rc;
     a.ctl.state_in = call->state_alt;            // pipelined sweeps: the advance reads the other column
@@ -153,7 +126,7 @@ extern "C" int bsx_group_set_mnist(bsx_group_t* g, int32_t index, const bsx_mnis
   memcpy(&g->args[(size_t)index * sizeof(a)], &a, sizeof(a));
   memcpy(&g->args2[(size_t)index * sizeof(o)], &o, sizeof(o));
   const uint64_t b1 = (uint64_t)(call->n_lanes + BSX_BLOCK - 1) / BSX_BLOCK;
-  const uint64_t b2 = bsx_flat_blocks((uint64_t)call->n_lanes * o.cells, mnist_group_k());
+  const uint64_t b2 = bsx_flat_blocks((uint64_t)call->n_lanes * o.cells, PAIR_MNIST_K);
   if (b1 > 0x3FFFFFFFull || b2 > 0x3FFFFFFFull) return BSX_EINVAL;
   g->blocks[index] = (int32_t)b1; g->blocks2[index] = (int32_t)b2;
   g->is_set[index] = 1;

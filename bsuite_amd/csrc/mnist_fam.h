@@ -65,29 +65,34 @@ struct mnist_observe_args {
   uint32_t cells;
   uint32_t cells_magic;
   bsx_div64 dv;
-  int32_t arith;          // the LUT is exactly np.float32(int8) / 255 (mnist_make checks all 256 entries): compute it
+  int32_t arith;          // the table is exactly np.float32(int8) / 255 (mnist_make checks all 256 entries): computed, never read
   int32_t _pad;
-  float lut[256];
+  float lut[256];         // read only when !arith (a caller-defined pixel table)
 };
 
-// Block b writes floats [b*K*1024, (b+1)*K*1024) of the [B x num_pixels] observation array
-// (num_pixels % 4 == 0, so a 16-byte chunk never straddles two lanes).  VAR (A/B knob
-// BSX_MNIST_VARIANT): bit 0 = issue the state loads + image gathers BEFORE the LUT fill and its
-// barrier; bit 1 = each wave owns K consecutive KiB (the deep_sea stream order) instead of the
-// block-interleaved order; bit 2 = no workgroup barrier at all: every WAVE keeps its own copy of the LUT
-// (s_lut: MNIST_LUT_FLOATS floats) and fills it only when one of its chunks shows an image — on the calls after the
-// guess, when every lane's observation is zeros (mnist.py:73), a workgroup's stores wait for nothing but the state
-// loads (r03: the mnist half of the sweep's stream ran at 5.0-5.2 TB/s even then, WAIT_ANY 68 % of the wave cycles:
-// the LUT load + barrier in front of every workgroup's stores, profiles/r03/stream_mnist_pmc_sq.json).
+// Block b writes floats [b*K*1024, (b+1)*K*1024) of the [B x num_pixels] observation array (num_pixels % 4 == 0, so a
+// 16-byte chunk never straddles two lanes); each wave owns K consecutive KiB (the deep_sea stream order).
+//
+// Round 6 (profiles/r06/mnist_stream_microbench*.log, tools/micro/mnist_stream.hip — every element of the chain switched on and
+// off over the same [2^20 x 784] array in one process): the r05 body {guarded state load -> guarded image gather -> 256-entry
+// table copied from the kernel arguments + workgroup barrier -> LDS lookups -> guarded store} streamed 5.5-5.8 TB/s where
+// deep_sea's one-hot chain over the same rows streams 6.7-6.8; neither the row geometry (deep_sea size 28 through the
+// library: 6.56) nor the gather, the table or the barrier alone explains it (each removed alone: 5.0-5.9).  What does is
+// the CODE SHAPE: every `if (live) load` / `if (show) gather` / `if (!live) continue` is an exec-mask branch, and the
+// compiler's s_waitcnt insertion falls back to vmcnt(0) at every join — the four chunks of a thread run as four
+// serialised {load, wait, gather, wait, lookup, store} chains.  This body is STRAIGHT-LINE: every load is unconditional with a
+// selected address (a lane that shows nothing reads the first image's row — one L2-resident line — and discards it), every
+// lookup too, the values are selected (v_cndmask); the table is per WAVE (no workgroup barrier) and filled by arithmetic
+// (bsx_mnist_pixel_value: exact, tests/test_physics_math.py), so nothing but the state word and the pixels is waited for:
+// 7.0 TB/s in the bare pattern with half, all or none of the lanes showing.  Workgroups that contain the array's end take
+// the guarded form of the same body (uniform branch).  What did NOT help (same log): more or fewer KiB per wave (K = 3: 5.95,
+// K = 5: 5.89, K = 8: 5.9), several rounds per wave with the next round's loads issued ahead of this round's stores
+// (5.6-5.8), table-free pixel arithmetic (equal when every lane shows, 6.2-6.5 otherwise), a fixed XCD <-> address granule.
 #define MNIST_LUT_FLOATS (256 * (BSX_BLOCK / BSX_WAVE))
-// bit 3 = no LUT at all: the pixel values are computed (mnist_pixel_value) — no LDS, no barrier.
-template <int K, int VAR>
-__device__ __forceinline__ void mnist_observe_body(const mnist_observe_args& a, uint32_t block_id, float* s_lut) {
-  if (VAR & 4) s_lut += (threadIdx.x >> 6) * 256;          // this wave's copy
-  if (!(VAR & 1) && !(VAR & 4) && !(VAR & 8)) {
-    s_lut[threadIdx.x] = a.lut[threadIdx.x];
-    __syncthreads();
-  }
+template <int K, bool ARITH, bool FULL>
+__device__ __forceinline__ void mnist_observe_chunks(const mnist_observe_args& a, uint32_t block_id, float* s_lut) {
+  const uint32_t wave = threadIdx.x >> 6, wl = threadIdx.x & 63u;
+  s_lut += wave * 256;                                                   // this wave's copy
   const uint32_t cells = a.cells;
   const uint64_t total = (uint64_t)a.n_lanes * cells;
   const uint64_t F0 = (uint64_t)block_id * (uint64_t)(K * 4 * BSX_BLOCK);
@@ -95,52 +100,59 @@ __device__ __forceinline__ void mnist_observe_body(const mnist_observe_args& a, 
   const uint32_t r_b = (uint32_t)(F0 - lane_b * cells);
   bsx_f4* __restrict__ o4 = reinterpret_cast<bsx_f4*>(a.obs + F0);
   const int32_t* __restrict__ st = a.state + lane_b;
-  const uint32_t wave = threadIdx.x >> 6, wl = threadIdx.x & 63u;
-  uint32_t px[K];
-  bool live[K], show[K];
+  const int8_t* __restrict__ images = a.images;
+  int32_t s[K];
+  uint32_t r0[K], px[K];
+  bool live[K];
 #pragma unroll
   for (int u = 0; u < K; ++u) {
-    const uint32_t c = (VAR & 2) ? (wave * K + u) * 64u + wl : threadIdx.x + u * BSX_BLOCK;
+    const uint32_t c = (wave * K + u) * 64u + wl;
     const uint32_t f = r_b + (c << 2);
-    const uint32_t dl = __umulhi(f, a.cells_magic);
-    const uint32_t r0 = f - dl * cells;
-    live[u] = F0 + ((uint64_t)c << 2) + 3 < total;
-    show[u] = false;
-    px[u] = 0;
-    if (live[u]) {
-      const int32_t s = st[dl];
-      show[u] = (s & MN_SHOW_BIT) != 0;
-      if (show[u])    // four int8 pixels of image idx: one aligned dword of the table
-        px[u] = *reinterpret_cast<const uint32_t*>(a.images + (uint64_t)(s & 0x00FFFFFF) * cells + r0);
-    }
+    uint32_t dl = __umulhi(f, a.cells_magic);
+    r0[u] = f - dl * cells;
+    live[u] = FULL || F0 + ((uint64_t)c << 2) + 3 < total;
+    if (!FULL) { dl = live[u] ? dl : 0u; r0[u] = live[u] ? r0[u] : 0u; }  // past the end: the block's first lane (in range)
+    s[u] = st[dl];
   }
-  if (VAR & 8) {
-  } else if (VAR & 4) {
-    bool any_show = false;
-#pragma unroll
-    for (int u = 0; u < K; ++u) any_show |= show[u];
-    if (__ballot(any_show) != 0ull) {                          // wave-uniform
-#pragma unroll
-      for (int k = 0; k < 4; ++k) s_lut[wl + 64u * k] = a.lut[wl + 64u * k];
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-      __builtin_amdgcn_wave_barrier();
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  {                                                                      // mnist.py:64 astype(f32) / 255, all 256 bytes
+    bsx_f4 l;
+    if (ARITH) {
+      l.x = bsx_mnist_pixel_value(4u * wl, 0); l.y = bsx_mnist_pixel_value(4u * wl + 1u, 0);
+      l.z = bsx_mnist_pixel_value(4u * wl + 2u, 0); l.w = bsx_mnist_pixel_value(4u * wl + 3u, 0);
+    } else {
+      l.x = a.lut[4u * wl]; l.y = a.lut[4u * wl + 1u]; l.z = a.lut[4u * wl + 2u]; l.w = a.lut[4u * wl + 3u];
     }
-  } else if (VAR & 1) {
-    s_lut[threadIdx.x] = a.lut[threadIdx.x];
-    __syncthreads();
+    reinterpret_cast<bsx_f4*>(s_lut)[wl] = l;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  }
+#pragma unroll
+  for (int u = 0; u < K; ++u) {   // four int8 pixels of image idx: one aligned dword of the table (row 0 when nothing shows)
+    const uint64_t row = (s[u] & MN_SHOW_BIT) ? (uint64_t)(uint32_t)(s[u] & 0x00FFFFFF) * cells : 0ull;
+    px[u] = *reinterpret_cast<const uint32_t*>(images + (row + r0[u]));
   }
 #pragma unroll
   for (int u = 0; u < K; ++u) {
-    if (!live[u]) continue;
-    const uint32_t c = (VAR & 2) ? (wave * K + u) * 64u + wl : threadIdx.x + u * BSX_BLOCK;
-    bsx_f4 v = {0.f, 0.f, 0.f, 0.f};                            // mnist.py:73 zeros after the guess
-    if (show[u]) {                                              // mnist.py:64 astype(f32) / 255
-      const uint32_t p = px[u];
-      if (VAR & 8) { v.x = bsx_mnist_pixel_value(p, 0); v.y = bsx_mnist_pixel_value(p, 1); v.z = bsx_mnist_pixel_value(p, 2); v.w = bsx_mnist_pixel_value(p, 3); }
-      else { v.x = s_lut[p & 0xFF]; v.y = s_lut[(p >> 8) & 0xFF]; v.z = s_lut[(p >> 16) & 0xFF]; v.w = s_lut[p >> 24]; }
-    }
-    o4[c] = v;
+    const uint32_t p = px[u];
+    const bool show = (s[u] & MN_SHOW_BIT) != 0;                          // mnist.py:73 zeros after the guess
+    bsx_f4 v;
+    v.x = s_lut[p & 0xFF]; v.y = s_lut[(p >> 8) & 0xFF]; v.z = s_lut[(p >> 16) & 0xFF]; v.w = s_lut[p >> 24];
+    v.x = show ? v.x : 0.f; v.y = show ? v.y : 0.f; v.z = show ? v.z : 0.f; v.w = show ? v.w : 0.f;
+    if (FULL || live[u]) o4[(wave * K + u) * 64u + wl] = v;
+  }
+}
+
+template <int K>
+__device__ __forceinline__ void mnist_observe_body(const mnist_observe_args& a, uint32_t block_id, float* s_lut) {
+  const uint64_t total = (uint64_t)a.n_lanes * a.cells;
+  const bool full = ((uint64_t)block_id + 1ull) * (uint64_t)(K * 4 * BSX_BLOCK) <= total;      // uniform
+  if (a.arith) {
+    if (full) mnist_observe_chunks<K, true, true>(a, block_id, s_lut);
+    else mnist_observe_chunks<K, true, false>(a, block_id, s_lut);
+  } else {
+    if (full) mnist_observe_chunks<K, false, true>(a, block_id, s_lut);
+    else mnist_observe_chunks<K, false, false>(a, block_id, s_lut);
   }
 }
 

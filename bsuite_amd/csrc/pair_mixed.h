@@ -32,9 +32,19 @@ int bsx_sweep_launch_split(bsx_group* g, hipStream_t st);
 int bsx_sweep_launch_pipelined(bsx_group* streams_of, bsx_group* advances_of, hipStream_t st);
 
 // One workgroup of the mixed observation store stream: `block` of the phase-1 grid runs its segment's
-// family stream body (deep_sea 4 x 4 KiB, catch 2 x 4 KiB, mnist 8 x 4 KiB, wide chain rows 2 x 4 KiB runs per workgroup).
+// family stream body (deep_sea 4 x 4 KiB, catch 2 x 4 KiB, mnist 6 x 4 KiB, wide chain rows 2 x 4 KiB runs per workgroup).
+// mnist: 6 KiB-runs per wave — inside the mixed stream the straight-line mnist body is best at 24 KiB per workgroup (same
+// call, three repetitions each, closed-loop sweep step: 8: 162.0-165.3 us, 7: 160.9-163.9, 6: 158.8-159.6, 5: 164.8-165.9, 4:
+// 169-171; the r05 body at 8: 161.0-162.0; profiles/r06/ab_sweep_mnist_k.log) although alone over one large array it is best
+// at 16 KiB (mnist.hip)
 #ifndef PAIR_MNIST_K
-#define PAIR_MNIST_K 8
+#define PAIR_MNIST_K 6
+#endif
+#ifndef PAIR_DEEP_SEA_K
+#define PAIR_DEEP_SEA_K 4
+#endif
+#ifndef PAIR_CATCH_K
+#define PAIR_CATCH_K 2
 #endif
 __device__ __forceinline__ void pair_mixed_stream_body(const uint8_t* __restrict__ table, const int32_t* __restrict__ family,
                                                        const bsx_group_index& gi, uint32_t block, float* s_lut) {
@@ -43,32 +53,16 @@ __device__ __forceinline__ void pair_mixed_stream_body(const uint8_t* __restrict
   switch (w.tag >= 0 ? w.tag : (family[w.seg] & 0xFF)) {   // uniform per workgroup
     case BSX_FAM_DEEP_SEA: {
       const bsx_stream_seg<deep_sea_hot>& g = *reinterpret_cast<const bsx_stream_seg<deep_sea_hot>*>(slot);
-      bsx_hot_stream_body<deep_sea_hot, 4, BSX_BLOCK>(g.obs, g.state, g.n_lanes, g.cells, g.cells_magic, g.dv, g.fn, w.block);
+      bsx_hot_stream_body<deep_sea_hot, PAIR_DEEP_SEA_K, BSX_BLOCK>(g.obs, g.state, g.n_lanes, g.cells, g.cells_magic, g.dv, g.fn, w.block);
       break;
     }
     case BSX_FAM_CATCH: {
       const bsx_stream_seg<catch_hot>& g = *reinterpret_cast<const bsx_stream_seg<catch_hot>*>(slot);
-      bsx_hot_stream_body<catch_hot, 2, BSX_BLOCK>(g.obs, g.state, g.n_lanes, g.cells, g.cells_magic, g.dv, g.fn, w.block);
+      bsx_hot_stream_body<catch_hot, PAIR_CATCH_K, BSX_BLOCK>(g.obs, g.state, g.n_lanes, g.cells, g.cells_magic, g.dv, g.fn, w.block);
       break;
     }
     case BSX_FAM_MNIST:
-#ifdef BSX_MNIST_STREAM_VAR
-      mnist_observe_body<PAIR_MNIST_K, BSX_MNIST_STREAM_VAR>(*reinterpret_cast<const mnist_observe_args*>(slot), w.block, s_lut);
-#else
-      // (variant 7 — no workgroup barrier, a per-wave LUT copy filled only when the wave shows an image — measured the
-      // same as 3: sweep step 165.8-166.1 vs 164.2-166.2 us, profiles/r04/ab_sweep_mnist_stream_no_barrier.log; the
-      // barrier was not what holds the mnist half of the stream at 5.4 TB/s)
-#if defined(BSX_TUNING)
-      // (A/B, tuning build only: the table-free pixel values of bsx_mnist_pixel_value — measured SLOWER than the LDS table,
-      // stand-alone 654 vs 595 us at 2^20 lanes and 177.4 vs 173.5 us per sweep step, profiles/r05/ab_mnist_arith.log: the
-      // stream pays more for 20 extra vector instructions per chunk than for the table fill and its barrier)
-      if (reinterpret_cast<const mnist_observe_args*>(slot)->arith) {
-        mnist_observe_body<PAIR_MNIST_K, 3 | 8>(*reinterpret_cast<const mnist_observe_args*>(slot), w.block, s_lut);
-        break;
-      }
-#endif
-      mnist_observe_body<PAIR_MNIST_K, 3>(*reinterpret_cast<const mnist_observe_args*>(slot), w.block, s_lut);
-#endif
+      mnist_observe_body<PAIR_MNIST_K>(*reinterpret_cast<const mnist_observe_args*>(slot), w.block, s_lut);
       break;
     // wide rows of the chains, left packed by phase 0 (whole-sweep groups; row_stream.h)
     case BSX_FAM_MEMORY_CHAIN:

@@ -135,3 +135,30 @@ def test_invalid_actions_are_clamped_and_counted():
     env.step(torch.randint(3, (B,), device='cuda', generator=g, dtype=torch.int32))
   assert int(env.invalid_action_count()) == 0
   assert int(env.episode_counters()[0]) == 3 * B               # three finished episodes per lane
+
+
+@pytest.mark.parametrize('batch', [5, 6, 257, 4097])
+@pytest.mark.parametrize('custom_table', [False, True])
+def test_mnist_observation_stream_tables_and_ragged_ends(batch, custom_table):
+  """The mnist observation stream (csrc/mnist_fam.h): the reference's pixel table np.float32(int8) / 255 (mnist.py:64) is
+  recognised and computed per wave; any other table in bsx_mnist_t.pixel_lut is read from the arguments.  Both forms, on
+  batches whose last workgroup is partial (16 KiB = 5.22 rows), against the table applied on the host."""
+  from bsuite_amd.environments import mnist
+  from tests import golden_util as gu
+  images, labels = gu.mnist_dataset()
+  env = mnist.MNISTBandit(seed=5, batch=batch, images=images, labels=labels, num_buffers=1)
+  table = np.arange(256, dtype=np.uint8).view(np.int8).astype(np.float32) / 255
+  if custom_table:
+    table = (np.arange(256, dtype=np.float32) * 0.5 - 3.25).astype(np.float32)
+    for b in range(256):
+      env._cfg.pixel_lut[b] = float(table[b])
+  flat = images.reshape(len(labels), -1).view(np.uint8)
+  a = _acts(6, batch, na=10)
+  for t in range(6):
+    ts = env.step(a[t])
+    obs = ts.observation.cpu().numpy().reshape(batch, -1)
+    first = ts.step_type.cpu().numpy() == 0
+    idx = (env._state['state'].cpu().numpy() & 0x00FFFFFF)
+    want = np.where(first[:, None], table[flat[idx]], np.float32(0))
+    np.testing.assert_array_equal(obs.view(np.uint32), want.astype(np.float32).view(np.uint32))
+    assert first.all() if t % 2 == 0 else not first.any()

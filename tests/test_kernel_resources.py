@@ -51,7 +51,8 @@ BUDGET = {
     # config 5: the whole sweep as one launch group
     'sweep_phase0_kernel': 64,
     'sweep_pipelined_kernel': 64,
-    'pair_mixed_stream_kernel': 32,
+    'pair_mixed_stream_kernel': 64,         # 8 waves (the straight-line mnist body holds 6 chunks' state words, offsets and pixels)
+    'mnist_observe_kernel<4>': 64,
     # the chains' wide rows, opt-in pair path: lane advance (flat bit planes into the scratch) + the wide-row store stream
     'small_obs_kernel<umbrella_chain_env, false, 0, 0, 0, true, true>': 64,
     'small_obs_kernel<memory_chain_env, false, 0, 0, 0, true, true>': 64,

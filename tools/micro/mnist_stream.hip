@@ -1,0 +1,434 @@
+// What holds the mnist observation stream (mnist_fam.h) below deep_sea's store rate for the same 784-float row?
+// (VERDICT r05 next #1.)  The bare patterns, every one over the same [2^20 x 784] f32 array, same box, same process,
+// interleaved repetitions.  A kernel = K x 4 KiB runs per workgroup, 16-byte stores, wave-contiguous (the product shape):
+//   fill        no loads at all (the ceiling of this launch shape)
+//   hot         state load -> one-hot decode -> store              (deep_sea's chain)
+//   cur         state load -> image gather -> LUT from MEMORY + workgroup barrier -> LDS lookups -> store   (r05 product)
+//   nogather    cur without the gather (pixels synthesised from the state word)
+//   nolut       cur without LUT/barrier (the gathered dword stored as it is)
+//   lutA        LUT filled by ARITHMETIC (bsx_mnist_pixel_value), workgroup barrier
+//   lutW        per-WAVE LUT filled by arithmetic: no memory round trip and no workgroup barrier in front of a store
+//   arith       no LUT: four pixel values computed per chunk
+//   pipe<R>     lutW + every wave runs R rounds of K stores, the loads of round r+1 (gather) / r+2 (state) issued BEFORE
+//               the stores of round r: gfx9 counts loads and stores in ONE in-order vmcnt, so a load issued after a
+//               store waits for that store's acknowledgement; issued before it, the chain hides behind the stores
+// Lane patterns: half (each lane shows an image with probability 1/2: the bench's staggered phases), all, none.
+// Build: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off tools/micro/mnist_stream.hip -o tools/ab/mnist_stream
+#include <hip/hip_runtime.h>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+#define BS 256
+#define SHOW_BIT (1 << 29)
+
+struct div64 { uint64_t m; uint32_t s; };
+struct args {
+  float* obs; const int32_t* state; const int8_t* images; const float* lut;
+  int64_t n_lanes; uint32_t cells, cells_magic; div64 dv;
+};
+
+__device__ __forceinline__ float pixel_value(uint32_t four, int k) {
+  const float x = (float)((int32_t)(four << (24 - 8 * k)) >> 24);
+  const float r = 0x1.010102p-8f;
+  const float q = x * r;
+  const float e = __builtin_fmaf(-q, 255.0f, x);
+  return __builtin_fmaf(e, r, q);
+}
+
+enum { M_FILL, M_HOT, M_CUR, M_NOGATHER, M_NOLUT, M_LUTA, M_LUTW, M_ARITH };
+
+template <int K, int MODE>
+__global__ void __launch_bounds__(BS) k_obs(const args a) {
+  __shared__ float s_lut_all[1024];
+  float* s_lut = s_lut_all;
+  const uint32_t wave = threadIdx.x >> 6, wl = threadIdx.x & 63u;
+  if (MODE == M_LUTW) s_lut += wave * 256;
+  const uint32_t cells = a.cells;
+  const uint64_t total = (uint64_t)a.n_lanes * cells;
+  const uint64_t F0 = (uint64_t)blockIdx.x * (uint64_t)(K * 4 * BS);
+  const uint64_t lane_b = __umul64hi(F0, a.dv.m) >> a.dv.s;
+  const uint32_t r_b = (uint32_t)(F0 - lane_b * cells);
+  float4* __restrict__ o4 = reinterpret_cast<float4*>(a.obs + F0);
+  const int32_t* __restrict__ st = a.state + lane_b;
+  uint32_t px[K], r0[K];
+  int32_t s[K];
+  bool live[K], show[K];
+#pragma unroll
+  for (int u = 0; u < K; ++u) {
+    const uint32_t c = (wave * K + u) * 64u + wl;
+    const uint32_t f = r_b + (c << 2);
+    const uint32_t dl = __umulhi(f, a.cells_magic);
+    r0[u] = f - dl * cells;
+    live[u] = F0 + ((uint64_t)c << 2) + 3 < total;
+    show[u] = false; px[u] = 0; s[u] = 0;
+    if (MODE == M_FILL) continue;
+    if (live[u]) {
+      s[u] = st[dl];
+      show[u] = (s[u] & SHOW_BIT) != 0;
+      if (MODE == M_HOT) continue;
+      if (MODE == M_NOGATHER) px[u] = (uint32_t)s[u] * 0x9E3779B1u + r0[u];
+      else if (show[u]) px[u] = *reinterpret_cast<const uint32_t*>(a.images + (uint64_t)(s[u] & 0x00FFFFFF) * cells + r0[u]);
+    }
+  }
+  if (MODE == M_CUR || MODE == M_NOGATHER) { s_lut[threadIdx.x] = a.lut[threadIdx.x]; __syncthreads(); }
+  if (MODE == M_LUTA) { s_lut[threadIdx.x] = pixel_value(threadIdx.x, 0); __syncthreads(); }
+  if (MODE == M_LUTW) {
+    float4 l;
+    l.x = pixel_value(4 * wl, 0); l.y = pixel_value(4 * wl + 1, 0); l.z = pixel_value(4 * wl + 2, 0); l.w = pixel_value(4 * wl + 3, 0);
+    reinterpret_cast<float4*>(s_lut)[wl] = l;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  }
+#pragma unroll
+  for (int u = 0; u < K; ++u) {
+    if (!live[u]) continue;
+    const uint32_t c = (wave * K + u) * 64u + wl;
+    float4 v = {0.f, 0.f, 0.f, 0.f};
+    if (MODE == M_HOT) {
+      const int h = (s[u] & 0x3FF) - (int)r0[u];      // one hot cell per row
+      v.x = h == 0 ? 1.f : 0.f; v.y = h == 1 ? 1.f : 0.f; v.z = h == 2 ? 1.f : 0.f; v.w = h == 3 ? 1.f : 0.f;
+    } else if (MODE != M_FILL && show[u]) {
+      const uint32_t p = px[u];
+      if (MODE == M_NOLUT) { v.x = __uint_as_float(p & 0x3FFFFFFF); v.y = v.x; v.z = v.x; v.w = v.x; }
+      else if (MODE == M_ARITH) { v.x = pixel_value(p, 0); v.y = pixel_value(p, 1); v.z = pixel_value(p, 2); v.w = pixel_value(p, 3); }
+      else { v.x = s_lut[p & 0xFF]; v.y = s_lut[(p >> 8) & 0xFF]; v.z = s_lut[(p >> 16) & 0xFF]; v.w = s_lut[p >> 24]; }
+    }
+    o4[c] = v;
+  }
+}
+
+// R rounds of K stores per wave; a wave owns R*K consecutive KiB.  LUTMODE 0: per-wave arithmetic LUT; 1: per-pixel arithmetic.
+// BRANCH-FREE: a divergent `if (show) load` is an exec-mask branch, and the compiler's s_waitcnt insertion gives up at
+// every join (vmcnt(0): the wave then waits for its own stores).  Every load is unconditional with a selected address
+// (lanes that show nothing read the first image's row: always in L2), every LDS lookup too; the values are selected.
+// Workgroups that contain the array's end take the guarded slow path (uniform branch).
+template <int K, int R, int LUTMODE, int DEPTH, bool full>
+__device__ __forceinline__ void pipe_body(const args& a, float* s_lut_all) {
+  const uint32_t wave = threadIdx.x >> 6, wl = threadIdx.x & 63u;
+  float* s_lut = s_lut_all + wave * 256;
+  const uint32_t cells = a.cells;
+  const uint64_t total = (uint64_t)a.n_lanes * cells;
+  const uint64_t F0 = (uint64_t)blockIdx.x * (uint64_t)(R * K * 4 * BS);
+  const uint64_t lane_b = __umul64hi(F0, a.dv.m) >> a.dv.s;
+  const uint32_t r_b = (uint32_t)(F0 - lane_b * cells);
+  float4* __restrict__ o4 = reinterpret_cast<float4*>(a.obs + F0);
+  const int32_t* __restrict__ st = a.state + lane_b;
+  const int8_t* __restrict__ images = a.images;
+  uint32_t px[R][K], r0[R][K];
+  int32_t s[R][K];
+#define CH(r, u) ((wave * (R * K) + (r) * K + (u)) * 64u + wl)
+#define STAGE_A(r)                                                                 \
+  _Pragma("unroll") for (int u = 0; u < K; ++u) {                                  \
+    const uint32_t c = CH(r, u);                                                   \
+    const uint32_t f = r_b + (c << 2);                                             \
+    uint32_t dl = __umulhi(f, a.cells_magic);                                      \
+    r0[r][u] = f - dl * cells;                                                     \
+    if (!full) dl = (F0 + ((uint64_t)c << 2) + 3 < total) ? dl : 0u;               \
+    s[r][u] = st[dl];                                                              \
+  }
+#define STAGE_G(r)                                                                 \
+  if (LUTMODE != 2 && LUTMODE != 4 && LUTMODE != 5) _Pragma("unroll") for (int u = 0; u < K; ++u) { \
+    const uint32_t row = (s[r][u] & SHOW_BIT) ? (uint32_t)(s[r][u] & 0x00FFFFFF) * cells : 0u; \
+    px[r][u] = *reinterpret_cast<const uint32_t*>(images + (row + r0[r][u]));      \
+  }
+#define STAGE_S(r)                                                                 \
+  _Pragma("unroll") for (int u = 0; u < K; ++u) {                                  \
+    const uint32_t p = px[r][u];                                                   \
+    float4 v;                                                                      \
+    if (LUTMODE >= 2) {                                                            \
+      int sv = s[r][u];                                                            \
+      if (LUTMODE == 3) { uint32_t q = p; asm volatile("" : "+v"(q)); sv += (q == 0x9E3779B1u) ? 1 : 0; } \
+      if (LUTMODE == 4) sv = reinterpret_cast<int*>(s_lut)[(u * 64 + wl) & 255];   \
+      const int h = (sv & 0x3FF) - (int)r0[r][u];                                  \
+      v.x = h == 0 ? 1.f : 0.f; v.y = h == 1 ? 1.f : 0.f; v.z = h == 2 ? 1.f : 0.f; v.w = h == 3 ? 1.f : 0.f; \
+    } else if (LUTMODE == 1) { v.x = pixel_value(p, 0); v.y = pixel_value(p, 1); v.z = pixel_value(p, 2); v.w = pixel_value(p, 3); } \
+    else { v.x = s_lut[p & 0xFF]; v.y = s_lut[(p >> 8) & 0xFF]; v.z = s_lut[(p >> 16) & 0xFF]; v.w = s_lut[p >> 24]; } \
+    const bool sh = LUTMODE >= 2 || (s[r][u] & SHOW_BIT) != 0;                     \
+    v.x = sh ? v.x : 0.f; v.y = sh ? v.y : 0.f; v.z = sh ? v.z : 0.f; v.w = sh ? v.w : 0.f; \
+    if (full || F0 + ((uint64_t)CH(r, u) << 2) + 3 < total) o4[CH(r, u)] = v;     \
+  }
+  STAGE_A(0);
+  if (R > 1) { STAGE_A(1); }
+  if (DEPTH > 1 && R > 2) { STAGE_A(2); }
+  if (LUTMODE == 0) {
+    float4 l;
+    l.x = pixel_value(4 * wl, 0); l.y = pixel_value(4 * wl + 1, 0); l.z = pixel_value(4 * wl + 2, 0); l.w = pixel_value(4 * wl + 3, 0);
+    reinterpret_cast<float4*>(s_lut)[wl] = l;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  }
+  if (LUTMODE == 4) {
+    _Pragma("unroll") for (int u = 0; u < K; ++u) reinterpret_cast<int*>(s_lut)[(u * 64 + wl) & 255] = s[0][u];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  }
+  if (LUTMODE == 5) {
+    _Pragma("unroll") for (int u = 0; u < K; ++u) asm volatile("" : "+v"(s[0][u]));
+    for (int q = 0; q < DEPTH; ++q) __builtin_amdgcn_s_sleep(8);
+  }
+  if (LUTMODE == 2 || LUTMODE >= 4) { _Pragma("unroll") for (int rr = 0; rr < R; ++rr) _Pragma("unroll") for (int u = 0; u < K; ++u) px[rr][u] = 0; }
+  STAGE_G(0);
+  if (DEPTH > 1 && R > 1) { STAGE_G(1); }
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    if (r + DEPTH + 1 < R) { STAGE_A(r + DEPTH + 1); }
+    if (r + DEPTH < R) { STAGE_G(r + DEPTH); }
+    asm volatile("" ::: "memory");
+    STAGE_S(r);
+    asm volatile("" ::: "memory");
+    // nothing that consumes the next round's pixels may be scheduled above this round's stores (it would drag the
+    // wait for those loads — and with it, in-order, for older stores — in front of them)
+    if (r + 1 < R) {
+      _Pragma("unroll") for (int u = 0; u < K; ++u) {
+        if (LUTMODE == 2 || LUTMODE >= 4) asm volatile("" : "+v"(s[r + 1 < R ? r + 1 : r][u]));
+        else asm volatile("" : "+v"(px[r + 1 < R ? r + 1 : r][u]));
+      }
+    }
+  }
+#undef CH
+#undef STAGE_A
+#undef STAGE_G
+#undef STAGE_S
+}
+
+template <int K, int R, int LUTMODE, int DEPTH>
+__global__ void __launch_bounds__(BS) k_pipe(const args a) {
+  __shared__ float s_lut_all[1024];
+  const uint64_t total = (uint64_t)a.n_lanes * a.cells;
+  if ((uint64_t)(blockIdx.x + 1) * (uint64_t)(R * K * 4 * BS) <= total) pipe_body<K, R, LUTMODE, DEPTH, true>(a, s_lut_all);
+  else pipe_body<K, R, LUTMODE, DEPTH, false>(a, s_lut_all);
+}
+
+
+// Which XCD writes which addresses?  Workgroups are dealt to the 8 XCDs round-robin (block b -> XCD b % 8), so with the
+// natural order (block b writes bytes [b*P, (b+1)*P), P = K * 4 KiB) XCD x owns every 8th P-sized piece: the piece size IS the
+// granule of the XCD <-> address affinity.  This kernel separates the two: XCD x owns the granules q with q % 8 == x of
+// 2^lgG bytes each, and its j-th workgroup writes the j-th P bytes of that owned space (G = P: the natural order).
+// MODE 0: one-hot chain, guarded loads/stores (the product's code shape); 1: flat mnist chain with the per-wave LUT.
+template <int K, int MODE>
+__global__ void __launch_bounds__(BS) k_xcd(const args a, const uint32_t lgG) {
+  __shared__ float s_lut_all[1024];
+  const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), wl = threadIdx.x & 63u;
+  float* s_lut = s_lut_all + wave * 256;
+  const uint32_t cells = a.cells;
+  const uint64_t total = (uint64_t)a.n_lanes * cells;
+  const uint32_t x = blockIdx.x & 7u, j = blockIdx.x >> 3;
+  uint32_t r0[K], px[K];
+  int32_t s[K];
+  float4* dst[K];
+  bool live[K];
+#pragma unroll
+  for (int u = 0; u < K; ++u) {
+    const uint64_t o = (uint64_t)j * (uint64_t)(K * 4096) + (uint64_t)((wave * K + u) * 1024u);
+    const uint64_t q = o >> lgG;
+    const uint64_t addr = (((q << 3) + x) << lgG) + (o & ((1ull << lgG) - 1ull));       // bytes; uniform per wave
+    const uint64_t F = addr >> 2;
+    const uint64_t lane_run = __umul64hi(F, a.dv.m) >> a.dv.s;
+    const uint32_t r_run = (uint32_t)(F - lane_run * cells);
+    const uint32_t f = r_run + (wl << 2);
+    const uint32_t dl = __umulhi(f, a.cells_magic);
+    r0[u] = f - dl * cells;
+    dst[u] = reinterpret_cast<float4*>(a.obs + F) + wl;
+    live[u] = F + (wl << 2) + 3 < total;
+    if (MODE == 0) { s[u] = 0; if (live[u]) s[u] = a.state[lane_run + dl]; }
+    else s[u] = a.state[lane_run + dl];
+  }
+  if (MODE == 1) {
+    float4 l;
+    l.x = pixel_value(4 * wl, 0); l.y = pixel_value(4 * wl + 1, 0); l.z = pixel_value(4 * wl + 2, 0); l.w = pixel_value(4 * wl + 3, 0);
+    reinterpret_cast<float4*>(s_lut)[wl] = l;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+    for (int u = 0; u < K; ++u) {
+      const uint32_t row = (s[u] & SHOW_BIT) ? (uint32_t)(s[u] & 0x00FFFFFF) * cells : 0u;
+      px[u] = *reinterpret_cast<const uint32_t*>(a.images + (row + r0[u]));
+    }
+  }
+#pragma unroll
+  for (int u = 0; u < K; ++u) {
+    float4 v;
+    if (MODE == 0) {
+      if (!live[u]) continue;
+      const int h = (s[u] & 0x3FF) - (int)r0[u];
+      v.x = h == 0 ? 1.f : 0.f; v.y = h == 1 ? 1.f : 0.f; v.z = h == 2 ? 1.f : 0.f; v.w = h == 3 ? 1.f : 0.f;
+    } else {
+      const uint32_t p = px[u];
+      const bool sh = (s[u] & SHOW_BIT) != 0;
+      v.x = s_lut[p & 0xFF]; v.y = s_lut[(p >> 8) & 0xFF]; v.z = s_lut[(p >> 16) & 0xFF]; v.w = s_lut[p >> 24];
+      v.x = sh ? v.x : 0.f; v.y = sh ? v.y : 0.f; v.z = sh ? v.z : 0.f; v.w = sh ? v.w : 0.f;
+    }
+    *dst[u] = v;
+  }
+}
+
+static div64 make_div64(uint32_t d) {
+  div64 r; uint32_t lg = 0;
+  while ((2u << lg) <= d) ++lg;
+  r.s = lg - 1;
+  r.m = (uint64_t)((((unsigned __int128)1) << (64 + r.s)) / d) + 1;
+  return r;
+}
+
+typedef void (*launch_fn)(const args&, uint64_t total_floats);
+template <int K, int MODE> static void L(const args& a, uint64_t total) {
+  const uint64_t per = (uint64_t)K * 4 * BS;
+  k_obs<K, MODE><<<dim3((unsigned)((total + per - 1) / per)), dim3(BS)>>>(a);
+}
+template <int K, int R, int LM, int DEPTH = 1> static void P(const args& a, uint64_t total) {
+  const uint64_t per = (uint64_t)R * K * 4 * BS;
+  k_pipe<K, R, LM, DEPTH><<<dim3((unsigned)((total + per - 1) / per)), dim3(BS)>>>(a);
+}
+
+template <int K, int MODE, int LGG> static void X(const args& a, uint64_t total) {
+  const uint64_t per = (uint64_t)K * 4 * BS;
+  k_xcd<K, MODE><<<dim3((unsigned)(total / per)), dim3(BS)>>>(a, LGG);      // total % (8 granules) == 0 in this bench
+}
+
+struct variant { const char* name; launch_fn fn; bool exact; };
+
+int main(int argc, char** argv) {
+  const int64_t B = argc > 1 ? atoll(argv[1]) : (1 << 20);
+  const uint32_t cells = argc > 2 ? (uint32_t)atoi(argv[2]) : 784;
+  const int n_img = argc > 3 ? atoi(argv[3]) : 96;
+  const int reps = 12, rounds = 2;
+  const uint64_t total = (uint64_t)B * cells;
+  args a;
+  int32_t* d_state[3]; int8_t* d_img; float* d_lut; float* d_obs;
+  hipMalloc(&d_obs, total * 4 + 65536); hipMalloc(&d_img, (size_t)n_img * cells); hipMalloc(&d_lut, 1024);
+  std::vector<int8_t> img((size_t)n_img * cells);
+  uint64_t x = 88172645463325252ull;
+  auto rnd = [&]() { x ^= x << 13; x ^= x >> 7; x ^= x << 17; return x; };
+  for (auto& p : img) p = (int8_t)(rnd() >> 40);
+  hipMemcpy(d_img, img.data(), img.size(), hipMemcpyHostToDevice);
+  float lut[256];
+  for (int k = 0; k < 256; ++k) lut[k] = (float)(int8_t)k / 255.0f;
+  hipMemcpy(d_lut, lut, 1024, hipMemcpyHostToDevice);
+  std::vector<int32_t> st((size_t)B);
+  const char* pat_name[3] = {"half", "all", "none"};
+  for (int p = 0; p < 3; ++p) {
+    for (int64_t i = 0; i < B; ++i) {
+      const uint32_t idx = (uint32_t)(rnd() >> 33) % (uint32_t)n_img;
+      const bool show = p == 0 ? ((rnd() >> 50) & 1) : p == 1;
+      st[(size_t)i] = (int32_t)idx | (int32_t)((idx % 10) << 24) | (show ? SHOW_BIT : 0);
+    }
+    hipMalloc(&d_state[p], (size_t)B * 4);
+    hipMemcpy(d_state[p], st.data(), (size_t)B * 4, hipMemcpyHostToDevice);
+  }
+  a.obs = d_obs; a.images = d_img; a.lut = d_lut; a.n_lanes = B; a.cells = cells;
+  a.cells_magic = (uint32_t)((0x100000000ull / cells) + 1ull); a.dv = make_div64(cells);
+  const variant vs[] = {
+      {"fill K4", L<4, M_FILL>, false},
+      {"hot K4 (deep_sea chain)", L<4, M_HOT>, false},
+      {"cur K4 (r05 product)", L<4, M_CUR>, true},
+      {"flat lutW K4", P<4, 1, 0>, true},
+      {"xcd hot K1 G=4K", X<1, 0, 12>, false},
+      {"xcd hot K1 G=8K", X<1, 0, 13>, false},
+      {"xcd hot K1 G=16K", X<1, 0, 14>, false},
+      {"xcd hot K1 G=32K", X<1, 0, 15>, false},
+      {"xcd hot K1 G=64K", X<1, 0, 16>, false},
+      {"xcd hot K1 G=128K", X<1, 0, 17>, false},
+      {"xcd hot K2 G=4K", X<2, 0, 12>, false},
+      {"xcd hot K2 G=8K", X<2, 0, 13>, false},
+      {"xcd hot K2 G=16K", X<2, 0, 14>, false},
+      {"xcd hot K2 G=32K", X<2, 0, 15>, false},
+      {"xcd hot K2 G=64K", X<2, 0, 16>, false},
+      {"xcd hot K2 G=128K", X<2, 0, 17>, false},
+      {"xcd hot K4 G=4K", X<4, 0, 12>, false},
+      {"xcd hot K4 G=8K", X<4, 0, 13>, false},
+      {"xcd hot K4 G=16K", X<4, 0, 14>, false},
+      {"xcd hot K4 G=32K", X<4, 0, 15>, false},
+      {"xcd hot K4 G=64K", X<4, 0, 16>, false},
+      {"xcd hot K4 G=128K", X<4, 0, 17>, false},
+      {"xcd hot K8 G=4K", X<8, 0, 12>, false},
+      {"xcd hot K8 G=8K", X<8, 0, 13>, false},
+      {"xcd hot K8 G=16K", X<8, 0, 14>, false},
+      {"xcd hot K8 G=32K", X<8, 0, 15>, false},
+      {"xcd hot K8 G=64K", X<8, 0, 16>, false},
+      {"xcd hot K8 G=128K", X<8, 0, 17>, false},
+      {"xcd lutW K1 G=4K", X<1, 1, 12>, true},
+      {"xcd lutW K1 G=8K", X<1, 1, 13>, true},
+      {"xcd lutW K1 G=16K", X<1, 1, 14>, true},
+      {"xcd lutW K1 G=32K", X<1, 1, 15>, true},
+      {"xcd lutW K1 G=64K", X<1, 1, 16>, true},
+      {"xcd lutW K1 G=128K", X<1, 1, 17>, true},
+      {"xcd lutW K2 G=4K", X<2, 1, 12>, true},
+      {"xcd lutW K2 G=8K", X<2, 1, 13>, true},
+      {"xcd lutW K2 G=16K", X<2, 1, 14>, true},
+      {"xcd lutW K2 G=32K", X<2, 1, 15>, true},
+      {"xcd lutW K2 G=64K", X<2, 1, 16>, true},
+      {"xcd lutW K2 G=128K", X<2, 1, 17>, true},
+      {"xcd lutW K4 G=4K", X<4, 1, 12>, true},
+      {"xcd lutW K4 G=8K", X<4, 1, 13>, true},
+      {"xcd lutW K4 G=16K", X<4, 1, 14>, true},
+      {"xcd lutW K4 G=32K", X<4, 1, 15>, true},
+      {"xcd lutW K4 G=64K", X<4, 1, 16>, true},
+      {"xcd lutW K4 G=128K", X<4, 1, 17>, true},
+      {"xcd lutW K8 G=4K", X<8, 1, 12>, true},
+      {"xcd lutW K8 G=8K", X<8, 1, 13>, true},
+      {"xcd lutW K8 G=16K", X<8, 1, 14>, true},
+      {"xcd lutW K8 G=32K", X<8, 1, 15>, true},
+      {"xcd lutW K8 G=64K", X<8, 1, 16>, true},
+      {"xcd lutW K8 G=128K", X<8, 1, 17>, true},
+      {"flat lutW K4 (again)", P<4, 1, 0>, true}, {"hot K4 (again)", L<4, M_HOT>, false},
+  };
+  const int nv = sizeof(vs) / sizeof(vs[0]);
+  // correctness of the exact variants against the host (half pattern), first 4096 + last 4096 lanes
+  {
+    a.state = d_state[0];
+    hipMemcpy(st.data(), d_state[0], (size_t)B * 4, hipMemcpyDeviceToHost);
+    const int64_t chk = B < 4096 ? B : 4096;
+    std::vector<float> got((size_t)chk * cells);
+    for (int v = 0; v < nv; ++v) {
+      if (!vs[v].exact) continue;
+      hipMemset(d_obs, 0xFF, total * 4);
+      vs[v].fn(a, total);
+      hipDeviceSynchronize();
+      long bad = 0;
+      for (int part = 0; part < 2; ++part) {
+        const int64_t l0 = part == 0 ? 0 : B - chk;
+        hipMemcpy(got.data(), d_obs + (uint64_t)l0 * cells, got.size() * 4, hipMemcpyDeviceToHost);
+        for (int64_t i = 0; i < chk; ++i)
+          for (uint32_t c = 0; c < cells; ++c) {
+            const int32_t s = st[(size_t)(l0 + i)];
+            const float want = (s & SHOW_BIT) ? lut[(uint8_t)img[(size_t)(s & 0xFFFFFF) * cells + c]] : 0.f;
+            if (memcmp(&want, &got[(size_t)i * cells + c], 4) != 0) ++bad;
+          }
+      }
+      if (bad) printf("MISMATCH %-26s %ld floats differ\n", vs[v].name, bad);
+    }
+    printf("exact variants checked against the host\n");
+  }
+  hipEvent_t e0, e1;
+  hipEventCreate(&e0); hipEventCreate(&e1);
+  printf("lanes %lld x %u floats = %.3f GB per launch, %d images; us per launch (best of %d rounds of %d launches) and TB/s\n",
+         (long long)B, cells, total * 4 / 1e9, n_img, rounds, reps);
+  for (int p = 0; p < (getenv("ALL_PATTERNS") ? 3 : 1); ++p) {
+    a.state = d_state[p];
+    std::vector<float> best((size_t)nv, 1e30f), sum((size_t)nv, 0.f);
+    for (int r = 0; r < rounds; ++r)
+      for (int v = 0; v < nv; ++v) {
+        vs[v].fn(a, total); vs[v].fn(a, total);
+        hipDeviceSynchronize();
+        hipEventRecord(e0);
+        for (int i = 0; i < reps; ++i) vs[v].fn(a, total);
+        hipEventRecord(e1);
+        hipEventSynchronize(e1);
+        float ms = 0; hipEventElapsedTime(&ms, e0, e1);
+        const float us = ms * 1e3f / reps;
+        if (us < best[v]) best[v] = us;
+        sum[v] += us;
+      }
+    for (int v = 0; v < nv; ++v)
+      printf("%-5s %-26s best %8.1f us %6.3f TB/s | mean %8.1f us %6.3f TB/s\n", pat_name[p], vs[v].name, best[v],
+             total * 4 / best[v] / 1e6, sum[v] / rounds, total * 4 / (sum[v] / rounds) / 1e6);
+  }
+  return 0;
+}
