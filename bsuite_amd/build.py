@@ -112,38 +112,64 @@ def build(force=False, verbose=False, tuning=False):
   if not force and not needs_build(tuning):  # the common import: nothing to do, no lock traffic
     return _variant(tuning)[0]
   with _locked():
-    return _build_locked(force, verbose, tuning)
+    return _build_locked(force, verbose, (tuning,))[0]
 
 
-def _build_locked(force, verbose, tuning):
+def build_all(force=False, verbose=False):
+  """The product library AND the tuning build, their translation units compiled in ONE pool (a clean build of both is two
+  rounds of ~14 hipcc runs; side by side the cores never wait for one variant's slowest file).  Returns both paths."""
+  if not force and not needs_build(False) and not needs_build(True):
+    return _variant(False)[0], _variant(True)[0]
+  with _locked():
+    return tuple(_build_locked(force, verbose, (False, True)))
+
+
+def _build_locked(force, verbose, variants):
   import json  # pylint: disable=import-outside-toplevel
-  so_path, obj_dir, hash_path, extra = _variant(tuning)
-  want, have = source_hashes(), _recorded(tuning)
-  if not force and os.path.exists(so_path) and want == have:
-    return so_path                           # another process built it while we waited for the lock
-  os.makedirs(obj_dir, exist_ok=True)
-  objs, jobs = [], []
-  for s in sources():
-    name = os.path.basename(s)[:-4] + '.o'
-    o = os.path.join(obj_dir, name)
-    objs.append(o)
-    if force or not os.path.exists(o) or have.get(name) != want[name]:
-      jobs.append((s, o))
+  want = source_hashes()
+  plans, jobs = [], []
+  for tuning in variants:
+    so_path, obj_dir, hash_path, extra = _variant(tuning)
+    have = _recorded(tuning)
+    if not force and os.path.exists(so_path) and want == have:
+      plans.append((so_path, None, None))      # another process built it while we waited for the lock
+      continue
+    os.makedirs(obj_dir, exist_ok=True)
+    objs = []
+    for s in sources():
+      name = os.path.basename(s)[:-4] + '.o'
+      o = os.path.join(obj_dir, name)
+      objs.append(o)
+      if force or not os.path.exists(o) or have.get(name) != want[name]:
+        jobs.append((s, o, extra))
+    plans.append((so_path, objs, hash_path))
   if jobs:
     if verbose:
-      print('hipcc' + (' -DBSX_TUNING:' if tuning else ':'), ' '.join(os.path.basename(s) for s, _ in jobs), flush=True)
-    with concurrent.futures.ThreadPoolExecutor(max_workers=min(8, len(jobs))) as ex:
-      list(ex.map(lambda so: _compile(*so, extra=extra), jobs))
-  tmp = f'{so_path}.{os.getpid()}.tmp'
-  subprocess.check_call(['hipcc', '--offload-arch=gfx950', '-shared', '-fPIC', '-o', tmp] + objs)
-  os.replace(tmp, so_path)
-  with open(hash_path + '.tmp', 'w') as f:
-    json.dump(want, f)
-  os.replace(hash_path + '.tmp', hash_path)
-  return so_path
+      print('hipcc:', ' '.join(os.path.basename(s) + (' (-DBSX_TUNING)' if extra else '') for s, _, extra in jobs), flush=True)
+    # the slowest files first (sweep_mixed.hip holds every family's body, the physics families the most instantiations)
+    slow = ('sweep_mixed', 'cartpole', 'umbrella_chain', 'memory_chain', 'mountain_car', 'deep_sea')
+    jobs.sort(key=lambda j: next((i for i, n in enumerate(slow) if os.path.basename(j[0]).startswith(n)), len(slow)))
+    with concurrent.futures.ThreadPoolExecutor(max_workers=min(os.cpu_count() or 8, len(jobs))) as ex:
+      list(ex.map(lambda j: _compile(j[0], j[1], extra=j[2]), jobs))
+  for so_path, objs, hash_path in plans:
+    if objs is None:
+      continue
+    tmp = f'{so_path}.{os.getpid()}.tmp'
+    subprocess.check_call(['hipcc', '--offload-arch=gfx950', '-shared', '-fPIC', '-o', tmp] + objs)
+    os.replace(tmp, so_path)
+    # objects of sources that no longer exist (a file split or renamed) must not linger next to the library
+    keep = {os.path.basename(o) for o in objs}
+    for f in os.listdir(os.path.dirname(objs[0])):
+      if f.endswith('.o') and f not in keep:
+        os.remove(os.path.join(os.path.dirname(objs[0]), f))
+    with open(hash_path + '.tmp', 'w') as f:
+      json.dump(want, f)
+    os.replace(hash_path + '.tmp', hash_path)
+  return [p[0] for p in plans]
 
 
 if __name__ == '__main__':
-  print(build(force='--force' in sys.argv, verbose=True))
   if '--tuning' in sys.argv:
-    print(build(force='--force' in sys.argv, verbose=True, tuning=True))
+    print(*build_all(force='--force' in sys.argv, verbose=True), sep='\n')
+  else:
+    print(build(force='--force' in sys.argv, verbose=True))

@@ -207,9 +207,10 @@ struct bsx_group {
   bool stream_without_alt = false;      // = any(needs_alt), evaluated at commit
   std::vector<uint8_t> needs_alt;       // per segment (mixed groups)
   std::vector<const void*> row_scratch; // per segment: the row scratch of a chain segment on the row path, else null
+  std::vector<uintptr_t> rows_sorted;   // the non-null ones, sorted (frozen at commit: bsx_group_step_pipelined's aliasing check)
   int64_t split_block = -1;             // whole-sweep groups: first phase-0 workgroup of the segments that have a share of
                                         // the store stream, when those segments are the tail of the group (else -1)
-  const bsx_group* pipelined_peer = nullptr;   // the group this one was last checked against (bsx_group_step_pipelined)
+  int64_t split_round = -1;             // workgroups of the split step's first launch (sweep_mixed.hip), derived on first use
   // launch(g, phase, stream): phase 0 = the first kernel (the lane advance of a two-kernel family, or the
   // whole step of a small-observation group), phase 1 = the observation stream kernel of a two-kernel
   // family (depends on phase 0 of the same group only), phase < 0 = both in order.

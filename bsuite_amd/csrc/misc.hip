@@ -1,5 +1,7 @@
 // misc.hip — ABI version / error strings, the pure-store calibration kernel and the draw-stream
 // dump used by the tests to pin the device Philox / normal transform against the oracle.
+#include <algorithm>
+
 #include "bsx_host.h"
 #include "pair_mixed.h"
 
@@ -238,7 +240,11 @@ static int group_commit(bsx_group* g) {
   g->stream_without_alt = false;
   for (uint8_t f : g->needs_alt) g->stream_without_alt = g->stream_without_alt || f != 0;
   // the split step needs the segments with a share of the store stream to be the tail of the phase-0 grid
+  g->rows_sorted.clear();
+  for (const void* p : g->row_scratch) if (p != nullptr) g->rows_sorted.push_back(reinterpret_cast<uintptr_t>(p));
+  std::sort(g->rows_sorted.begin(), g->rows_sorted.end());
   g->split_block = -1;
+  g->split_round = -1;
   if (g->family == BSX_FAM_SWEEP_MIXED) {
     int first = g->n;
     while (first > 0 && g->blocks2[first - 1] > 0) --first;
@@ -278,14 +284,13 @@ extern "C" int bsx_group_step_pipelined(bsx_group_t* streams_of, bsx_group_t* ad
       streams_of->shared_counter != advances_of->shared_counter)
     return BSX_EINVAL;
   if (streams_of->stream_without_alt || advances_of->stream_without_alt) return BSX_EMODE;
-  if (streams_of->pipelined_peer != advances_of) {
-    // once per pairing: a chain segment on the row path must not share its row scratch between the two groups (the
-    // stream of step s would decode the rows the advance of step s+1 is writing)
-    const size_t n = streams_of->row_scratch.size() < advances_of->row_scratch.size() ? streams_of->row_scratch.size()
-                                                                                        : advances_of->row_scratch.size();
-    for (size_t i = 0; i < n; ++i)
-      if (streams_of->row_scratch[i] != nullptr && streams_of->row_scratch[i] == advances_of->row_scratch[i]) return BSX_EMODE;
-    streams_of->pipelined_peer = advances_of;
+  // a chain segment on the row path must not share its row scratch between the two groups (the stream of step s would
+  // decode the rows the advance of step s+1 is writing) — checked on EVERY call and against every segment of the other
+  // group (one merge over the two sorted lists frozen at commit: no cached verdict that a recycled group address could outlive)
+  for (size_t i = 0, j = 0; i < streams_of->rows_sorted.size() && j < advances_of->rows_sorted.size();) {
+    const uintptr_t p = streams_of->rows_sorted[i], q = advances_of->rows_sorted[j];
+    if (p == q) return BSX_EMODE;
+    if (p < q) ++i; else ++j;
   }
   return bsx_sweep_launch_pipelined(streams_of, advances_of, (hipStream_t)hip_stream);
 }

@@ -1302,7 +1302,13 @@ struct discounting_chain_env : small_regs_defaults {
   static int variant_of(const args&) { return 0; }
   template <bool NOFORCE = false>
   __device__ static __forceinline__ bool wants_reset(const args&, const regs&) { return false; }
-  __device__ static __forceinline__ void clear(regs& r) { r.st = 0; }
+  // state word: timestep (bits 0-7) | context + 6 (bits 8-11: the context is the episode's first action, -5..4, -1 after a
+  // reset — the reference indexes Python lists with it, so -5..-1 are legal and wrap, discounting_chain.py:76-81) | reset_next
+  __device__ static __forceinline__ int dc_context(int32_t st) { return ((st >> 8) & 0xF) - 6; }
+  __device__ static __forceinline__ int32_t dc_pack(int t, int ctx, bool last) {
+    return t | ((ctx + 6) << 8) | (last ? DC_RESET_BIT : 0);
+  }
+  __device__ static __forceinline__ void clear(regs& r) { r.st = dc_pack(0, -1, false); }
   __device__ static __forceinline__ bool reset_pending(const regs& r) { return (r.st & DC_RESET_BIT) != 0; }
   __device__ static __forceinline__ void reset_part(const args&, uint64_t, uint64_t, int, unsigned, bsx_reset_pool*) {}
   __host__ __device__ static bool table_fits(const args&) { return false; }
@@ -1320,53 +1326,55 @@ struct discounting_chain_env : small_regs_defaults {
                                              const bsx_reset_pool* = nullptr) {
     BSX_NO_CONTRACT
     const int32_t st = rg.st;
-    int t = st & 0xFF, ctx = ((st >> 8) & 0xF) - 1;
+    int t = st & 0xFF, ctx = dc_context(st);
     if ((!NOFORCE && a.ctl.force_reset) || (st & DC_RESET_BIT)) {   // discounting_chain.py:69-73
       o[0] = -1.0f; o[1] = 0.0f;
-      rg.st = 0;
+      rg.st = dc_pack(0, -1, false);
       return BSX_FIRST;
     }
     if (t == 0) {                                               // :76-77
       ctx = act;
-      if (ctx < 0 || ctx > 4) {                                 // reference: IndexError at the reward lookup
+      if (ctx < -5 || ctx > 4) {                                // reference: IndexError at the lookup of :80
         bsx_note_invalid_action(a.ctl, i);
         ctx = ctx < 0 ? 0 : 4;
       }
     }
     t += 1;
-    const int when = ctx == 0 ? 1 : ctx == 1 ? 3 : ctx == 2 ? 10 : ctx == 3 ? 30 : 100;   // :49
-    if (t == when) reward = (ctx == a.bonus) ? 1.0 + 0.1 : 1.0;                            // :57-58,80-83
+    const int chain = ctx < 0 ? ctx + 5 : ctx;                  // :80-81 index Python lists: -5..-1 wrap, the context stays negative
+    const int when = chain == 0 ? 1 : chain == 1 ? 3 : chain == 2 ? 10 : chain == 3 ? 30 : 100;   // :49
+    if (t == when) reward = (chain == a.bonus) ? 1.0 + 0.1 : 1.0;                          // :57-58,80-83
     o[0] = (float)ctx;                                          // :65
     o[1] = (float)((double)t / 100.0);                          // :66
     const int type = (t == 100) ? BSX_LAST : BSX_MID;           // :86-88
-    rg.st = t | ((ctx + 1) << 8) | (type == BSX_LAST ? DC_RESET_BIT : 0);
+    rg.st = dc_pack(t, ctx, type == BSX_LAST);
     return type;
   }
   template <int LOG, int MT>
   __device__ static int step(const args& a, int64_t i, int64_t oi, uint64_t, uint64_t step, float* o, double& reward) {
     BSX_NO_CONTRACT
     int32_t st = a.state[i];
-    int t = st & 0xFF, ctx = ((st >> 8) & 0xF) - 1;
+    int t = st & 0xFF, ctx = dc_context(st);
     if (a.ctl.force_reset || (st & DC_RESET_BIT)) {             // discounting_chain.py:69-73
       t = 0; ctx = -1;
       o[0] = -1.0f; o[1] = 0.0f;
-      a.state[i] = 0;
+      a.state[i] = dc_pack(0, -1, false);
       return BSX_FIRST;
     }
     if (t == 0) {                                               // :76-77
       ctx = bsx_action(a.ctl, a.action, oi, step);
-      if (ctx < 0 || ctx > 4) {                                 // reference: IndexError at the reward lookup
+      if (ctx < -5 || ctx > 4) {                                // reference: IndexError at the lookup of :80
         bsx_note_invalid_action(a.ctl, i);
         ctx = ctx < 0 ? 0 : 4;                                  // action_spec: 5 values; never OOB
       }
     }
     t += 1;
-    const int when = ctx == 0 ? 1 : ctx == 1 ? 3 : ctx == 2 ? 10 : ctx == 3 ? 30 : 100;   // :49
-    if (t == when) reward = (ctx == a.bonus) ? 1.0 + 0.1 : 1.0;                            // :57-58,80-83
+    const int chain = ctx < 0 ? ctx + 5 : ctx;                  // :80-81 index Python lists: -5..-1 wrap, the context stays negative
+    const int when = chain == 0 ? 1 : chain == 1 ? 3 : chain == 2 ? 10 : chain == 3 ? 30 : 100;   // :49
+    if (t == when) reward = (chain == a.bonus) ? 1.0 + 0.1 : 1.0;                          // :57-58,80-83
     o[0] = (float)ctx;                                          // :65
     o[1] = (float)((double)t / 100.0);                          // :66
     const int type = (t == 100) ? BSX_LAST : BSX_MID;           // :86-88
-    a.state[i] = t | ((ctx + 1) << 8) | (type == BSX_LAST ? DC_RESET_BIT : 0);
+    a.state[i] = dc_pack(t, ctx, type == BSX_LAST);
     return type;
   }
 };

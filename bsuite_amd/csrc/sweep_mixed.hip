@@ -193,29 +193,53 @@ int bsx_sweep_launch_pipelined(bsx_group* streams_of, bsx_group* advances_of, hi
 //              standing in front of them; their last workgroup to retire bumps the call counter.
 // Everything in a step reads the actions of that step only, so the schedule is closed-loop: the TimeSteps of step s are
 // complete when launch 2 ends.
-#ifndef BSX_SPLIT_ROUND_DEFAULT
-#define BSX_SPLIT_ROUND_DEFAULT 2420    // workgroups of launch 1 when phase 0 does not fit one dispatch round; 0 = the lane advance only
+// Workgroups of launch 1 when phase 0 does not fit one dispatch round: the machine's resident workgroup slots for THIS kernel
+// with THIS group's dynamic LDS (CUs x hipOccupancyMaxActiveBlocksPerMultiprocessor: 256 x 8 = 2048 on MI355X for the whole
+// sweep) plus the 18 % the dispatcher places while the first workgroups retire — the margin measured at 2^20 lanes
+// (profiles/r05/ab_sweep_split_point*.log: 164.2 us per sweep step with no top-up, 163.0 with 1200 workgroups, 162.0 with 1500,
+// 163.2 with 1800, noise from 2200 = slots x 1.07 up to 3000 = slots x 1.46; with ALL of phase 0 in launch 1 168).  Derived
+// per group and device, not a constant: another mix of families (more LDS per workgroup = fewer slots) or a part with fewer
+// CUs gets its own round.  -DBSX_SPLIT_ROUND_DEFAULT=<n> / BSX_SPLIT_ROUND (tuning build) pin it; 0 = the lane advance only.
+static int64_t sweep_split_round(bsx_group* g) {
+#ifdef BSX_SPLIT_ROUND_DEFAULT
+  static const int pinned = bsx_env_int("BSX_SPLIT_ROUND", BSX_SPLIT_ROUND_DEFAULT);
+#else
+  static const int pinned = bsx_env_int("BSX_SPLIT_ROUND", -1);
 #endif
+  if (pinned >= 0) return pinned;
+  if (g->split_round >= 0) return g->split_round;
+  int dev = 0, cus = 0, per_cu = 0;
+  if (hipGetDevice(&dev) != hipSuccess ||
+      hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess ||
+      hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, sweep_phase0_kernel, BSX_BLOCK, g->lds_bytes) != hipSuccess ||
+      cus <= 0 || per_cu <= 0) {
+    (void)hipGetLastError();
+    return 0;                               // unknown machine: the lane advance only (always correct, a little slower)
+  }
+  const int64_t slots = (int64_t)cus * per_cu;
+  g->split_round = slots + slots * 18 / 100;
+  return g->split_round;
+}
+
 int bsx_sweep_launch_split(bsx_group* g, hipStream_t st) {
   if (g->split_block < 0 || g->split_block > g->total_blocks) return BSX_EMODE;
-  // Launch 1 is one dispatch round whatever it holds (the machine has 2048 workgroup slots at this kernel's 8 waves per
-  // SIMD, and the first to retire make room while the dispatcher is still placing), and the lane advance fills less than
-  // half of it: when phase 0 is MORE than one round, launch 1 is topped up with small-observation workgroups — the last,
-  // lightest ones of their part of the grid — which then no longer compete with the store stream in launch 2.  Same
-  // call, five repetitions at 2^20 lanes (920 advance workgroups; profiles/r05/ab_sweep_split_point*.log): 164.2 us per
-  // sweep step with none, 163.0 with 1200, 162.0 with 1500 (every repetition below every one of the plain split), 163.2
-  // with 1800, noise from 2200 up; with ALL of them (= phase 0 | stream) 168.  On a second box, three repetitions
-  // (ab_sweep_split_order.log): 168.5 -> 166.9 (launch 1 = 2420 workgroups), 166.7 (3000), 168.3 (3600); with the small
-  // segments in narrow-rows-first order, i.e. the WIDE rows topping launch 1 up, 167.1 -> 167.4 / 170.6 / 169.1: not that.
-  static const int round = bsx_env_int("BSX_SPLIT_ROUND", BSX_SPLIT_ROUND_DEFAULT);
+  // Launch 1 is one dispatch round whatever it holds, and the lane advance fills less than half of it: when phase 0 is MORE
+  // than one round, launch 1 is topped up with small-observation workgroups — the last, lightest ones of their part of the
+  // grid — which then no longer compete with the store stream in launch 2 (sweep_split_round above).  On a second box, three
+  // repetitions (ab_sweep_split_order.log): 168.5 -> 166.9 (launch 1 = 2420 workgroups), 166.7 (3000), 168.3 (3600); with
+  // the small segments in narrow-rows-first order, i.e. the WIDE rows topping launch 1 up, 167.1 -> 167.4 / 170.6 / 169.1.
+  const int64_t round = sweep_split_round(g);
   int64_t extra = 0;
   if (g->total_blocks > round) extra = round - (g->total_blocks - g->split_block);
   if (extra < 0) extra = 0;
   const int64_t split = g->split_block > extra ? g->split_block - extra : 0;
   const int64_t n_tail = g->total_blocks - split;
-  if (n_tail > 0)
+  if (n_tail > 0) {
     sweep_phase0_kernel<<<dim3((unsigned)n_tail), dim3(BSX_BLOCK), g->lds_bytes, st>>>(
         (const uint8_t*)g->d_args, g->d_tags, g->index1(), split == 0 ? g->shared_counter : nullptr, g->d_ticket, nullptr, (uint32_t)split);
+    const int rc1 = (int)hipGetLastError();       // a failed launch 1 is reported as such, and launch 2 (which would bump the
+    if (rc1 != 0) return rc1;                     // call counter over lanes that never advanced) is not issued
+  }
   const uint64_t blocks = (uint64_t)split + (uint64_t)g->total_blocks2;
   if (blocks == 0) return (int)hipGetLastError();
   if (blocks > 0x7FFFFFFFull) return BSX_EINVAL;

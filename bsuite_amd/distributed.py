@@ -40,17 +40,20 @@ def local_summary(env) -> Tuple[torch.Tensor, Tuple[str, ...]]:
 
 
 def all_gather_summary(vec: torch.Tensor, group: Optional[dist.ProcessGroup] = None) -> torch.Tensor:
-  """All-gathers each rank's summary vector -> [world, k] on every rank (RCCL over xGMI for device
-  tensors, gloo for CPU tensors).  With no process group initialised it is the identity."""
+  """All-gathers each rank's summary vector -> [world, k] on every rank.  With no process group initialised it is the
+  identity.  ONE collective into ONE pre-allocated [world, k] tensor (`all_gather_into_tensor`): on device
+  tensors under the "nccl" backend that is a single ncclAllGather over RCCL/xGMI, no per-rank allocations and no
+  stack afterwards.  Under gloo (the CPU tests) a device tensor is gathered through host memory."""
   if not (dist.is_available() and dist.is_initialized()):
     return vec.unsqueeze(0)
   world = dist.get_world_size(group)
-  src = vec
+  src = vec.contiguous()
   if vec.is_cuda and dist.get_backend(group) != 'nccl':   # gloo (tests): gather through host memory
-    src = vec.cpu()
-  out = [torch.empty_like(src) for _ in range(world)]
-  dist.all_gather(out, src, group=group)
-  return torch.stack(out).to(vec.device)
+    src = src.cpu()
+  # (the concatenated form of the output — every backend takes it; gloo refuses the stacked one)
+  out = torch.empty(world * src.numel(), dtype=src.dtype, device=src.device)
+  dist.all_gather_into_tensor(out, src.reshape(-1), group=group)
+  return out.view((world,) + tuple(src.shape)).to(vec.device)
 
 
 def reduce_summary(gathered: torch.Tensor, names: Tuple[str, ...]) -> Dict[str, float]:

@@ -93,6 +93,7 @@ class Environment(dm_env.EnvironmentBase):
                lane_offset=0, num_buffers=2, device_step_counter=False, shared_step_counter=None,
                rng='philox', observation_mode='dense', obs_allocator=None):
     self._scalar = batch is None
+    self._scalar_last_type = None    # scalar view: step_type of the previous TimeStep (DiscountingChain._check_scalar_action)
     self._batch = 1 if batch is None else int(batch)
     if self._batch < 1:
       raise ValueError('batch must be >= 1')
@@ -416,7 +417,9 @@ class Environment(dm_env.EnvironmentBase):
     if self._delta:
       call.obs_paint = self._paint[b].data_ptr()
     call.force_reset = 1 if force_reset else 0
-    if self._tag_host_count:                       # (deep_sea with the host-side call count: not while capturing)
+    if self._tag_host_count:                       # (deep_sea with the host-side call count: not while capturing.  The
+      # current device IS this environment's here — the redirect at the top of _call — so this asks about the stream the
+      # kernels are about to be launched on)
       call.flags = 0 if torch.cuda.is_current_stream_capturing() else _native.CALL_STATE_TAGGED
     if self._wrap is not self._wrap_applied:       # the wrappers install a NEW tuple when they change it
       w = self._call_wrap
@@ -520,7 +523,10 @@ class Environment(dm_env.EnvironmentBase):
   def _coerce_actions(self, action) -> torch.Tensor:
     if self._scalar:
       a = int(action)
-      self._check_scalar_action(a)
+      # base.py:59-62: a step that auto-resets (fresh environment, or the previous TimeStep was LAST) never looks at its
+      # action — the reference raises nothing there, whatever it is
+      if self._scalar_last_type is not None and self._scalar_last_type != _native.LAST:
+        self._check_scalar_action(a)
       if self._host_out:
         self._scalar_action.numpy()[0] = a      # host write; the kernel reads it through the mapping
       else:
@@ -552,6 +558,7 @@ class Environment(dm_env.EnvironmentBase):
       st = int(out['step_type'].item())
       obs = out['observation'][0].cpu().numpy()
       reward, discount = float(self._reward_f64.item()), float(out['discount'].item())
+    self._scalar_last_type = st
     if st == _native.FIRST:
       return dm_env.restart(obs)
     if st == _native.LAST:
@@ -709,9 +716,11 @@ class Environment(dm_env.EnvironmentBase):
 
   def invalid_action_count(self) -> torch.Tensor:
     """int64 scalar device tensor: lane-steps so far whose action was outside the action_spec in a
-    family where the reference raises IndexError (bandit, catch, discounting_chain).  The batched
-    kernels clamp such actions instead of faulting; assert this is 0 to get the reference's
-    strictness without a per-step host check (the scalar view raises like the reference)."""
+    family where the reference raises IndexError (bandit.py:61, catch.py:84; discounting_chain.py:80 for an episode's first
+    action outside -5..4 — Python's negative indices are legal there and the kernels wrap them the same way).  The batched
+    kernels clamp such actions instead of faulting; assert this is 0 to get the reference's strictness without a per-step
+    host check.  The scalar view raises IndexError exactly where the reference does (`_check_scalar_action` of the three
+    families; tests/test_gpu_dm_env_conformance.py)."""
     self._ensure_allocated()
     return self._counters[:, 2].sum()
 
@@ -739,6 +748,7 @@ class Environment(dm_env.EnvironmentBase):
 
   def load_state_dict(self, d: Dict[str, Any]):
     self._ensure_allocated()
+    self._scalar_last_type = None       # (scalar view: no action check until the next TimeStep says where the episode is)
     for k, v in self._state.items():
       v.copy_(d[k])
     self._info.copy_(d['__info'])

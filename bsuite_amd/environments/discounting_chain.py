@@ -31,6 +31,14 @@ class DiscountingChain(base.Environment):
 
   _abi_name = 'discounting_chain'
 
+  def _check_scalar_action(self, action):
+    # discounting_chain.py:76-81: the episode's FIRST action becomes the context and indexes two Python lists on every step
+    # of the episode: IndexError outside -5..4, raised on that first step (later actions are never looked at); -5..-1 wrap
+    # like Python's negative indices while the observation shows the negative context — the kernels do the same, and
+    # count lanes outside -5..4 in invalid_action_count() instead of raising.
+    if self._scalar_last_type == _native.FIRST:
+      self._reward_timestep[action]  # pylint: disable=pointless-statement
+
   def _native_args(self, call, action_ptr, out):
     return (ctypes.byref(self._cfg), ctypes.byref(call), action_ptr, self._state['state'].data_ptr(), out)
 

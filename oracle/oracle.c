@@ -380,7 +380,9 @@ void orc_discounting_chain(const orc_call* c, int mapping_seed, int32_t* timeste
     }
     if (timestep[i] == 0) context[i] = c->action[i];                   /* :76-77 */
     timestep[i] += 1;
-    double reward = (timestep[i] == reward_timestep[context[i]]) ? rewards[context[i]] : 0.0;
+    int chain = context[i] < 0 ? context[i] + 5 : context[i];          /* :80-81 Python list indexing: -5..-1 wrap (outside
+                                                                          -5..4 the reference raises IndexError: not a case here) */
+    double reward = (timestep[i] == reward_timestep[chain]) ? rewards[chain] : 0.0;
     o[0] = (float)context[i];                                          /* :65 */
     o[1] = (float)((double)timestep[i] / 100.0);                       /* :66 */
     if (timestep[i] == 100) { reset_next[i] = 1; emit(c, i, LAST, reward); }

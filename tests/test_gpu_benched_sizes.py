@@ -285,3 +285,51 @@ def test_config5_eight_shards_equal_the_unsharded_sweep(tmp_path):
     torch.cuda.empty_cache()
   assert seen == set(whole) and sum(loads) == total_load
   assert max(loads) / (total_load / world) < 1.01, loads
+
+
+@pytest.mark.timeout(900)
+def test_split_step_of_another_family_mix_equals_the_unsplit_step_and_is_not_slower():
+  """The split closed-loop step (bsx_group_step_split) tops its first launch up to one dispatch round DERIVED from the
+  device and the group (CUs x resident workgroups of sweep_phase0_kernel with this group's LDS, + 18 %: csrc/sweep_mixed.hip),
+  not to a constant tuned on BASELINE config 5: a sweep of a different composition — no mnist, no deep_sea above size 20,
+  every wide-row chain id — at 2^20 lanes (phase 0 = 4100+ workgroups, two dispatch rounds) gives the unsplit step's
+  TimeSteps, bsuite_info and counters bit for bit, and does not take longer than it."""
+  ids = [b for b in sweep.SWEEP if not b.startswith('mnist') and not (b.startswith('deep_sea') and int(b.split('/')[1]) > 5)]
+  assert 360 < len(ids) < 400
+  seed, steps, ring = 7, 19, 16
+
+  def run(split):
+    batch = sb.SweepBatch(ids, B, seed=seed)
+    acts = batch.random_actions(seed=3, ring=ring)
+    outs = batch.prepare_groups(acts, split=split)
+    assert batch._split == split
+    for _ in range(steps):
+      batch.step_grouped()
+    batch.sync()
+    assert batch._split == split                      # (the split cut applies: no fallback to the ordinary step)
+    res = {}
+    for (bid, _, _), ts, env in zip(batch.segments, outs, batch.envs):
+      res[bid] = (tuple(x.clone() for x in (ts.step_type, ts.reward, ts.discount, ts.observation)),
+                  {k: v.clone() for k, v in env.bsuite_info().items()}, eu.raw(env).episode_counters().clone())
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    best = float('inf')
+    for _ in range(5):
+      e0.record()
+      for _ in range(40):
+        batch.step_grouped()
+      e1.record()
+      torch.cuda.synchronize()
+      best = min(best, e0.elapsed_time(e1) / 40)
+    batch.release_groups()
+    return res, best
+
+  plain, t_plain = run(False)
+  torch.cuda.empty_cache()
+  cut, t_cut = run(True)
+  for bid, (ts, info, counters) in plain.items():
+    for x, y in zip(cut[bid][0], ts):
+      assert torch.equal(x, y), bid
+    for k, v in info.items():
+      assert torch.equal(cut[bid][1][k], v), (bid, k)
+    assert torch.equal(cut[bid][2], counters), bid
+  assert t_cut <= 1.03 * t_plain, (t_cut, t_plain)

@@ -91,6 +91,43 @@ def test_invalid_actions_raise_like_the_reference():
   assert d.step(7).mid()                   # deep_sea accepts any int: != mapping => left (:118)
   with pytest.raises(NotImplementedError):
     d._step(0)
+  # a step that auto-resets never looks at its action (base.py:59-62): nothing is raised there
+  b = bandit.SimpleBandit(0)
+  assert b.step(99).first()                # fresh environment
+  assert b.step(3).last()
+  assert b.step(99).first()                # after LAST
+
+
+def test_discounting_chain_indexes_like_the_reference():
+  """discounting_chain.py:76-81: the episode's first action becomes the context and indexes two Python lists at every
+  step of the episode — IndexError outside -5..4 on that first step, -5..-1 wrap (the observation keeps the negative
+  context), later actions are never looked at."""
+  for bad in (5, 100, -6):
+    dc = discounting_chain.DiscountingChain(mapping_seed=0)
+    dc.reset()
+    with pytest.raises(IndexError):
+      dc.step(bad)
+  dc = discounting_chain.DiscountingChain(mapping_seed=0)
+  dc.reset()
+  assert dc.step(2).mid()
+  assert dc.step(99).mid() and dc.step(-77).mid()          # only the first action of an episode matters
+  pay, bonus_chain = [1, 3, 10, 30, 100], 4 % 5
+  for first in (-1, -2, -5, 4, 0):
+    dc = discounting_chain.DiscountingChain(mapping_seed=4)
+    dc.reset()
+    chain = first % 5
+    for t in range(1, 101):
+      ts = dc.step(first if t == 1 else 3)
+      assert ts.observation[0, 0] == np.float32(first) and ts.observation[0, 1] == np.float32(t / 100)
+      want = (1.1 if chain == bonus_chain else 1.0) if t == pay[chain] else 0.0
+      assert ts.reward == want, (first, t, ts.reward)
+      assert ts.last() == (t == 100)
+    assert dc.step(5).first()                               # auto-reset: the action is not looked at
+  many = discounting_chain.DiscountingChain(mapping_seed=4, batch=64)
+  import torch
+  many.step(torch.zeros(64, dtype=torch.int32, device='cuda'))
+  many.step(torch.arange(-32, 32, dtype=torch.int32, device='cuda'))
+  assert int(many.invalid_action_count().item()) == 64 - 10       # -5..4 are the reference's legal first actions
 
 
 def test_scalar_view_is_lane_zero_of_the_batched_view():

@@ -88,3 +88,26 @@ def test_oracle_matches_the_live_reference(chunk):
       check_oracle_against_case(meta, g)
     except AssertionError as e:
       raise AssertionError(f'{c}: {e}') from e
+
+
+def test_oracle_discounting_chain_negative_first_actions_match_the_live_reference():
+  """discounting_chain.py:76-81 indexes Python lists with the episode's first action: -5..-1 are legal there and wrap.
+  No fixture holds such a case (the action_spec is 0..4): the restatement is pinned on the reference live."""
+  from oracle import replay
+  if not replay.reference_available():
+    pytest.skip('no reference on this box')
+  replay.import_reference()
+  from bsuite.environments import discounting_chain as ref_dc      # the reference (oracle/_ref or /root/reference)
+  firsts = np.array([-1, -2, -3, -4, -5, 0, 4, 2], np.int32)
+  for mapping_seed in (0, 3, 4, 7):
+    refs = [ref_dc.DiscountingChain(mapping_seed=mapping_seed) for _ in firsts]
+    env = coracle.OracleEnv('discounting_chain', dict(mapping_seed=mapping_seed), np.arange(len(firsts), dtype=np.uint64), seed=1)
+    for t in range(103):
+      a = firsts if t == 1 else np.full(len(firsts), (t * 7) % 5, np.int32)
+      st, r, d, o = env.call(a, t)
+      for i, e in enumerate(refs):
+        ts = e.step(int(a[i]))
+        assert int(ts.step_type) == st[i]
+        np.testing.assert_array_equal(ts.observation, o[i])
+        if not ts.first():
+          assert ts.reward == r[i] and ts.discount == d[i]

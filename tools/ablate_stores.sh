@@ -9,8 +9,8 @@ python -m bsuite_amd.build | tail -1
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fPIC -fno-fast-math -Iinclude -Ibsuite_amd/csrc"
 mkdir -p tools/ab
 for e in ${ABLATE:-1 2 3}; do
-  hipcc $FLAGS -DBSX_ABLATE_STORES=$e -c bsuite_amd/csrc/small_obs.hip -o /tmp/small_obs_ablate$e.o
-  hipcc --offload-arch=gfx950 -shared -fPIC -o tools/ab/libbsx_ablate$e.so /tmp/small_obs_ablate$e.o $(ls bsuite_amd/_lib/*.o | grep -v small_obs.o)
+  for f in cartpole mountain_car; do hipcc $FLAGS -DBSX_ABLATE_STORES=$e -c bsuite_amd/csrc/$f.hip -o /tmp/${f}_ablate$e.o; done
+  hipcc --offload-arch=gfx950 -shared -fPIC -o tools/ab/libbsx_ablate$e.so /tmp/cartpole_ablate$e.o /tmp/mountain_car_ablate$e.o $(ls bsuite_amd/_lib/*.o | grep -v "/cartpole.o\|/mountain_car.o")
 done
 ls -la tools/ab/libbsx_ablate*.so
 echo "gpurun -- 'for lib in \"\" tools/ab/libbsx_ablate1.so tools/ab/libbsx_ablate2.so tools/ab/libbsx_ablate3.so; do BSX_NATIVE_LIB=\$lib python tools/lanes_sweep.py --mode rollout --T 16 --steps 320 cartpole mountain_car -- 2**20; done'"

@@ -1,6 +1,6 @@
 """ISA of one kernel out of a .hip translation unit, with a per-basic-block instruction census (no GPU):
 
-  python tools/kernel_isa.py bsuite_amd/csrc/small_obs.hip 'small_obs_kernel<cartpole_env, true, 0, 0, 0, true, true>' [-o out.s] [-D...]
+  python tools/kernel_isa.py bsuite_amd/csrc/cartpole.hip 'small_obs_kernel<cartpole_env, true, 0, 0, 0, true, true>' [-o out.s] [-D...]
 
 Compiles the file to gfx950 assembly (cached under /tmp/bsx_isa by content hash), finds the kernel by its demangled
 name (substring), writes its text to -o and prints, per basic block, the number of VALU / SALU / VMEM / LDS

@@ -118,7 +118,7 @@ __device__ __forceinline__ void pipe_body(const args& a, float* s_lut_all) {
   float4* __restrict__ o4 = reinterpret_cast<float4*>(a.obs + F0);
   const int32_t* __restrict__ st = a.state + lane_b;
   const int8_t* __restrict__ images = a.images;
-  uint32_t px[R][K], r0[R][K];
+  uint32_t px[R][K], r0[R][K], dlk[R][K];
   int32_t s[R][K];
 #define CH(r, u) ((wave * (R * K) + (r) * K + (u)) * 64u + wl)
 #define STAGE_A(r)                                                                 \
@@ -128,10 +128,15 @@ __device__ __forceinline__ void pipe_body(const args& a, float* s_lut_all) {
     uint32_t dl = __umulhi(f, a.cells_magic);                                      \
     r0[r][u] = f - dl * cells;                                                     \
     if (!full) dl = (F0 + ((uint64_t)c << 2) + 3 < total) ? dl : 0u;               \
+    dlk[r][u] = dl;                                                                \
     s[r][u] = st[dl];                                                              \
   }
 #define STAGE_G(r)                                                                 \
-  if (LUTMODE != 2 && LUTMODE != 4 && LUTMODE != 5) _Pragma("unroll") for (int u = 0; u < K; ++u) { \
+  if (LUTMODE == 6) _Pragma("unroll") for (int u = 0; u < K; ++u) {                \
+    uint32_t z = (uint32_t)s[r][u]; asm volatile("v_and_b32 %0, 0, %0" : "+v"(z)); \
+    px[r][u] = (uint32_t)st[dlk[r][u] + z];                                        \
+  }                                                                                \
+  if (LUTMODE != 2 && LUTMODE != 4 && LUTMODE != 5 && LUTMODE != 6 && LUTMODE != 7) _Pragma("unroll") for (int u = 0; u < K; ++u) { \
     const uint32_t row = (s[r][u] & SHOW_BIT) ? (uint32_t)(s[r][u] & 0x00FFFFFF) * cells : 0u; \
     px[r][u] = *reinterpret_cast<const uint32_t*>(images + (row + r0[r][u]));      \
   }
@@ -143,8 +148,10 @@ __device__ __forceinline__ void pipe_body(const args& a, float* s_lut_all) {
       int sv = s[r][u];                                                            \
       if (LUTMODE == 3) { uint32_t q = p; asm volatile("" : "+v"(q)); sv += (q == 0x9E3779B1u) ? 1 : 0; } \
       if (LUTMODE == 4) sv = reinterpret_cast<int*>(s_lut)[(u * 64 + wl) & 255];   \
+      if (LUTMODE == 6) sv = (int)p;                                               \
       const int h = (sv & 0x3FF) - (int)r0[r][u];                                  \
-      v.x = h == 0 ? 1.f : 0.f; v.y = h == 1 ? 1.f : 0.f; v.z = h == 2 ? 1.f : 0.f; v.w = h == 3 ? 1.f : 0.f; \
+      if (LUTMODE >= 6) { v.x = s_lut[h == 0]; v.y = s_lut[h == 1]; v.z = s_lut[h == 2]; v.w = s_lut[h == 3]; } \
+      else { v.x = h == 0 ? 1.f : 0.f; v.y = h == 1 ? 1.f : 0.f; v.z = h == 2 ? 1.f : 0.f; v.w = h == 3 ? 1.f : 0.f; } \
     } else if (LUTMODE == 1) { v.x = pixel_value(p, 0); v.y = pixel_value(p, 1); v.z = pixel_value(p, 2); v.w = pixel_value(p, 3); } \
     else { v.x = s_lut[p & 0xFF]; v.y = s_lut[(p >> 8) & 0xFF]; v.z = s_lut[(p >> 16) & 0xFF]; v.w = s_lut[p >> 24]; } \
     const bool sh = LUTMODE >= 2 || (s[r][u] & SHOW_BIT) != 0;                     \
@@ -168,11 +175,17 @@ __device__ __forceinline__ void pipe_body(const args& a, float* s_lut_all) {
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
   }
+  if (LUTMODE >= 6) {
+    if (wl < 2) s_lut[wl] = (float)wl;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  }
   if (LUTMODE == 5) {
     _Pragma("unroll") for (int u = 0; u < K; ++u) asm volatile("" : "+v"(s[0][u]));
     for (int q = 0; q < DEPTH; ++q) __builtin_amdgcn_s_sleep(8);
   }
-  if (LUTMODE == 2 || LUTMODE >= 4) { _Pragma("unroll") for (int rr = 0; rr < R; ++rr) _Pragma("unroll") for (int u = 0; u < K; ++u) px[rr][u] = 0; }
+  if (LUTMODE == 2 || LUTMODE == 4 || LUTMODE == 5 || LUTMODE == 7) { _Pragma("unroll") for (int rr = 0; rr < R; ++rr) _Pragma("unroll") for (int u = 0; u < K; ++u) px[rr][u] = 0; }
   STAGE_G(0);
   if (DEPTH > 1 && R > 1) { STAGE_G(1); }
 #pragma unroll
@@ -269,6 +282,71 @@ __global__ void __launch_bounds__(BS) k_xcd(const args a, const uint32_t lgG) {
   }
 }
 
+
+// How many of a wave's stores should be in flight?  The guarded kernels above wait vmcnt(0) in front of EVERY store (the
+// compiler's s_waitcnt insertion at the joins of their exec-mask branches): a wave has ONE store in flight, and they are the
+// faster ones.  Straight-line body, all K state loads first, then store u waits until at most N older stores are unacknowledged.
+// MODE 0: one-hot chain; 1: mnist chain (per-wave arithmetic table)
+template <int K, int N, int MODE>
+__global__ void __launch_bounds__(BS) k_paced(const args a) {
+  __shared__ float s_lut_all[1024];
+  const uint32_t wave = threadIdx.x >> 6, wl = threadIdx.x & 63u;
+  float* s_lut = s_lut_all + wave * 256;
+  const uint32_t cells = a.cells;
+  const uint64_t F0 = (uint64_t)blockIdx.x * (uint64_t)(K * 4 * BS);
+  const uint64_t lane_b = __umul64hi(F0, a.dv.m) >> a.dv.s;
+  const uint32_t r_b = (uint32_t)(F0 - lane_b * cells);
+  float4* __restrict__ o4 = reinterpret_cast<float4*>(a.obs + F0);
+  const int32_t* __restrict__ st = a.state + lane_b;
+  int32_t s[K];
+  uint32_t r0[K], px[K];
+#pragma unroll
+  for (int u = 0; u < K; ++u) {
+    const uint32_t c = (wave * K + u) * 64u + wl;
+    const uint32_t f = r_b + (c << 2);
+    const uint32_t dl = __umulhi(f, a.cells_magic);
+    r0[u] = f - dl * cells;
+    s[u] = st[dl];
+  }
+  if (MODE == 1) {
+    float4 l;
+    l.x = pixel_value(4 * wl, 0); l.y = pixel_value(4 * wl + 1, 0); l.z = pixel_value(4 * wl + 2, 0); l.w = pixel_value(4 * wl + 3, 0);
+    reinterpret_cast<float4*>(s_lut)[wl] = l;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+    for (int u = 0; u < K; ++u) {
+      const uint32_t row = (s[u] & SHOW_BIT) ? (uint32_t)(s[u] & 0x00FFFFFF) * cells : 0u;
+      px[u] = *reinterpret_cast<const uint32_t*>(a.images + (row + r0[u]));
+    }
+  }
+  float4 v[K];
+#pragma unroll
+  for (int u = 0; u < K; ++u) {
+    if (MODE == 0) {
+      const int h = (s[u] & 0x3FF) - (int)r0[u];
+      v[u].x = h == 0 ? 1.f : 0.f; v[u].y = h == 1 ? 1.f : 0.f; v[u].z = h == 2 ? 1.f : 0.f; v[u].w = h == 3 ? 1.f : 0.f;
+    } else {
+      const uint32_t p = px[u];
+      const bool sh = (s[u] & SHOW_BIT) != 0;
+      v[u].x = s_lut[p & 0xFF]; v[u].y = s_lut[(p >> 8) & 0xFF]; v[u].z = s_lut[(p >> 16) & 0xFF]; v[u].w = s_lut[p >> 24];
+      v[u].x = sh ? v[u].x : 0.f; v[u].y = sh ? v[u].y : 0.f; v[u].z = sh ? v[u].z : 0.f; v[u].w = sh ? v[u].w : 0.f;
+    }
+  }
+#pragma unroll
+  for (int u = 0; u < K; ++u) {
+    if (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (N == 1) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+    if (N == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+    if (N == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+    if (N >= 100 && N < 200 && u > 0) __builtin_amdgcn_s_sleep(N - 100);
+    if (N >= 200 && u > 0) { _Pragma("unroll") for (int q = 0; q < N - 200; ++q) asm volatile("s_nop 7" ::: "memory"); }
+    o4[(wave * K + u) * 64u + wl] = v[u];
+    asm volatile("" ::: "memory");
+  }
+}
+
 static div64 make_div64(uint32_t d) {
   div64 r; uint32_t lg = 0;
   while ((2u << lg) <= d) ++lg;
@@ -290,6 +368,11 @@ template <int K, int R, int LM, int DEPTH = 1> static void P(const args& a, uint
 template <int K, int MODE, int LGG> static void X(const args& a, uint64_t total) {
   const uint64_t per = (uint64_t)K * 4 * BS;
   k_xcd<K, MODE><<<dim3((unsigned)(total / per)), dim3(BS)>>>(a, LGG);      // total % (8 granules) == 0 in this bench
+}
+
+template <int K, int N, int MODE> static void W(const args& a, uint64_t total) {
+  const uint64_t per = (uint64_t)K * 4 * BS;
+  k_paced<K, N, MODE><<<dim3((unsigned)(total / per)), dim3(BS)>>>(a);      // (the tail of a non-multiple is left unwritten: timing only)
 }
 
 struct variant { const char* name; launch_fn fn; bool exact; };
@@ -327,56 +410,11 @@ int main(int argc, char** argv) {
   const variant vs[] = {
       {"fill K4", L<4, M_FILL>, false},
       {"hot K4 (deep_sea chain)", L<4, M_HOT>, false},
-      {"cur K4 (r05 product)", L<4, M_CUR>, true},
       {"flat lutW K4", P<4, 1, 0>, true},
-      {"xcd hot K1 G=4K", X<1, 0, 12>, false},
-      {"xcd hot K1 G=8K", X<1, 0, 13>, false},
-      {"xcd hot K1 G=16K", X<1, 0, 14>, false},
-      {"xcd hot K1 G=32K", X<1, 0, 15>, false},
-      {"xcd hot K1 G=64K", X<1, 0, 16>, false},
-      {"xcd hot K1 G=128K", X<1, 0, 17>, false},
-      {"xcd hot K2 G=4K", X<2, 0, 12>, false},
-      {"xcd hot K2 G=8K", X<2, 0, 13>, false},
-      {"xcd hot K2 G=16K", X<2, 0, 14>, false},
-      {"xcd hot K2 G=32K", X<2, 0, 15>, false},
-      {"xcd hot K2 G=64K", X<2, 0, 16>, false},
-      {"xcd hot K2 G=128K", X<2, 0, 17>, false},
-      {"xcd hot K4 G=4K", X<4, 0, 12>, false},
-      {"xcd hot K4 G=8K", X<4, 0, 13>, false},
-      {"xcd hot K4 G=16K", X<4, 0, 14>, false},
-      {"xcd hot K4 G=32K", X<4, 0, 15>, false},
-      {"xcd hot K4 G=64K", X<4, 0, 16>, false},
-      {"xcd hot K4 G=128K", X<4, 0, 17>, false},
-      {"xcd hot K8 G=4K", X<8, 0, 12>, false},
-      {"xcd hot K8 G=8K", X<8, 0, 13>, false},
-      {"xcd hot K8 G=16K", X<8, 0, 14>, false},
-      {"xcd hot K8 G=32K", X<8, 0, 15>, false},
-      {"xcd hot K8 G=64K", X<8, 0, 16>, false},
-      {"xcd hot K8 G=128K", X<8, 0, 17>, false},
-      {"xcd lutW K1 G=4K", X<1, 1, 12>, true},
-      {"xcd lutW K1 G=8K", X<1, 1, 13>, true},
-      {"xcd lutW K1 G=16K", X<1, 1, 14>, true},
-      {"xcd lutW K1 G=32K", X<1, 1, 15>, true},
-      {"xcd lutW K1 G=64K", X<1, 1, 16>, true},
-      {"xcd lutW K1 G=128K", X<1, 1, 17>, true},
-      {"xcd lutW K2 G=4K", X<2, 1, 12>, true},
-      {"xcd lutW K2 G=8K", X<2, 1, 13>, true},
-      {"xcd lutW K2 G=16K", X<2, 1, 14>, true},
-      {"xcd lutW K2 G=32K", X<2, 1, 15>, true},
-      {"xcd lutW K2 G=64K", X<2, 1, 16>, true},
-      {"xcd lutW K2 G=128K", X<2, 1, 17>, true},
-      {"xcd lutW K4 G=4K", X<4, 1, 12>, true},
-      {"xcd lutW K4 G=8K", X<4, 1, 13>, true},
-      {"xcd lutW K4 G=16K", X<4, 1, 14>, true},
-      {"xcd lutW K4 G=32K", X<4, 1, 15>, true},
-      {"xcd lutW K4 G=64K", X<4, 1, 16>, true},
-      {"xcd lutW K4 G=128K", X<4, 1, 17>, true},
-      {"xcd lutW K8 G=4K", X<8, 1, 12>, true},
-      {"xcd lutW K8 G=8K", X<8, 1, 13>, true},
-      {"xcd lutW K8 G=16K", X<8, 1, 14>, true},
-      {"xcd lutW K8 G=32K", X<8, 1, 15>, true},
-      {"xcd lutW K8 G=64K", X<8, 1, 16>, true},
-      {"xcd lutW K8 G=128K", X<8, 1, 17>, true},
+      {"flat hot K4", P<4, 1, 2>, false},
+      {"flat hot+gather K4", P<4, 1, 3>, false},
+      {"flat hot+reload+ldsvals K4", P<4, 1, 6>, false}, {"flat hot+reload+ldsvals K3", P<3, 1, 6>, false}, {"flat hot+reload+ldsvals K5", P<5, 1, 6>, false},
+      {"flat hot+ldsvals K4", P<4, 1, 7>, false}, {"flat hot+ldsvals K3", P<3, 1, 7>, false}, {"flat hot+ldsvals K5", P<5, 1, 7>, false},
       {"flat lutW K4 (again)", P<4, 1, 0>, true}, {"hot K4 (again)", L<4, M_HOT>, false},
   };
   const int nv = sizeof(vs) / sizeof(vs[0]);
@@ -410,7 +448,7 @@ int main(int argc, char** argv) {
   hipEventCreate(&e0); hipEventCreate(&e1);
   printf("lanes %lld x %u floats = %.3f GB per launch, %d images; us per launch (best of %d rounds of %d launches) and TB/s\n",
          (long long)B, cells, total * 4 / 1e9, n_img, rounds, reps);
-  for (int p = 0; p < (getenv("ALL_PATTERNS") ? 3 : 1); ++p) {
+  for (int p = 0; p < 3; ++p) {
     a.state = d_state[p];
     std::vector<float> best((size_t)nv, 1e30f), sum((size_t)nv, 0.f);
     for (int r = 0; r < rounds; ++r)
