@@ -62,6 +62,10 @@ WORKLOADS = {
 
 def _synthetic_mnist():
   import numpy as np
+  if os.environ.get('BSX_BENCH_MNIST_DIR'):     # (information only: idx files of another size, e.g. the real 47 MB table)
+    from bsuite_amd.utils import datasets
+    (x, y), _ = datasets.load_mnist(os.environ['BSX_BENCH_MNIST_DIR'])
+    return x, y
   d = np.load(os.path.join(ROOT, 'tests', 'golden', 'mnist_synthetic_dataset.npz'))
   return d['images_u8'].view(np.int8), d['labels']
 
@@ -80,11 +84,13 @@ def _latest_profile(name):
     return json.load(f), os.path.relpath(hits[-1], ROOT)
 
 
-def pmc_traffic(workload, lanes):
-  """HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/rNN/<w>_pmc_traffic.json:
-  WRITE_SIZE and FETCH_SIZE collected in separate runs over the timed launches, gfx950 corrections applied
-  there: tools/pmc.py)."""
-  d, src = _latest_profile(f'{workload}_pmc_traffic.json')
+def pmc_traffic(workload, lanes, mode='eager', chunk=0, logging=False):
+  """HBM bytes per env step of the whole batch from the committed rocprofv3 PMC passes (profiles/rNN/<w>[_logging][_<mode>]
+  _pmc_traffic.json: WRITE_SIZE and FETCH_SIZE collected in separate runs over the timed launches, gfx950 corrections
+  applied there; a fused rollout launch's bytes / T, a multi-launch rollout's summed over its launches: tools/pmc.py).
+  A HIP-graph replay issues the eager launches: it cites their pass."""
+  key = workload + ('_logging' if logging else '') + ('' if mode in ('eager', 'graph') else f'_{mode}{chunk}')
+  d, src = _latest_profile(f'{key}_pmc_traffic.json')
   if d is None or lanes != d.get('lanes', 1 << 20) or not d['per_launch'].get('fetch_bytes_x2'):
     return None, None                      # (a pass that recorded no FETCH bytes is not evidence)
   return d['per_launch']['hbm_bytes'], src
@@ -482,7 +488,7 @@ class Rank:
       # (deep_sea: clear 1 + set 1; catch: up to 2 + 2).
       bytes_per_step = 13 + state_bytes + 8 + 4 * (2 if family == 'deep_sea' else 4)
     achieved = bytes_per_step * B / (kernel_ms * 1e-3) / 1e9
-    traffic, traffic_src = pmc_traffic(workload + ('_delta' if delta else ''), B) if mode == 'eager' else (None, None)
+    traffic, traffic_src = pmc_traffic(workload + ('_delta' if delta else ''), B, mode, chunk, logging)
     del env, actions
     torch.cuda.empty_cache()
     calls = steps * B * self.world
@@ -645,6 +651,13 @@ class Rank:
       out['steps'] = r['steps']
     if common is None or r['lanes'] != common['lanes_per_gpu']:
       out['lanes_per_gpu'] = r['lanes']
+    if r['family'] == 'bandit' and r['mode'] == 'eager':
+      # SURVEY §8(d) leaves the info accumulators out ("touched only on LAST steps: amortised < 1 B") — not so for a ONE-step
+      # episode: every second call of every lane is LAST, and the order-dependent f64 total_regret column (bandit.py:62) is a
+      # whole cache line read and written per 16 lanes whichever half of them updates: + 8 B in + 8 B out per env step.  The
+      # line's `frac` stays on the survey's 25 B; this is what the kernel really has to move (PMC: profiles/*/bandit_pmc_traffic.json)
+      out['bytes_actual'] = r['bytes_per_step'] + 16
+      roof['frac_actual_bytes'] = roof['frac'] * (r['bytes_per_step'] + 16) / r['bytes_per_step']
     if r['mode'] == 'eager' and r['family'] not in ('deep_sea', 'catch', 'mnist') and self.world == 1:
       # the small-observation families read a third of what they write: their line is this box's COPY rate
       roof['frac_of_box_copy'] = r['achieved'] / self.copy_ceiling()

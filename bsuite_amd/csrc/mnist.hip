@@ -3,12 +3,14 @@
 //
 // Episode = reset (show image idx = randint(num_data), obs = int8 pixels / 255 in f32) + one step
 // (reward +-1 by action == label, LAST, obs = zeros).  Per call and lane: 3136 B of observation
-// stores, on FIRST calls plus a 784 B gather from the L2/Infinity-cache resident image table.
+// stores, on FIRST calls plus a 784 B gather from the image table (L2-resident when small; the real
+// 47 MB dataset sits in the Infinity Cache).
 //   advance  mnist_advance_kernel: one lane per thread, packed state = idx | label | flags
 //   observe  mnist_observe_kernel: pure 16-byte store stream over [B x 784] f32; a chunk is four
-//            table bytes mapped through the 256-entry LUT (LDS) or zero.
-// The LUT holds np.float32(int8(b)) / 255 evaluated by numpy on the host, so the int8 parsing quirk
-// of the reference (datasets.py:55-56) and its f32 division are reproduced bit for bit.
+//            table bytes mapped through a per-wave 256-entry table in LDS, or zero (mnist_fam.h).
+// The table is np.float32(int8(b)) / 255 — the int8 parsing quirk of the reference (datasets.py:55-56)
+// and its f32 division, bit for bit: numpy's values from the host are recognised and then computed on
+// the device (bsx_mnist_pixel_value, exact for all 256 bytes); any other table is read as given.
 #include "bsx_host.h"
 #include "mnist_fam.h"
 #include "pair_mixed.h"
@@ -39,9 +41,18 @@ __global__ void __launch_bounds__(BSX_BLOCK) mnist_observe_group_kernel(const mn
   mnist_observe_body<K>(table[w.seg], w.block, s_lut);
 }
 
-// 16 KiB per workgroup: a sharp optimum of the straight-line body (K = 3: 5.95, 4: 7.0, 5: 5.9, 8: 5.9 TB/s at 2^20 lanes,
-// profiles/r06/mnist_stream_microbench_2.log)
+// KiB-runs per wave.  16 KiB per workgroup is a sharp optimum of the straight-line body while the image table stays in L2 (K = 3:
+// 5.95, 4: 7.0, 5: 5.9, 8: 5.9 TB/s at 2^20 lanes with 96 images, and 4 stays best up to 20 000 images = 15.7 MB: 6.66 against
+// 5.6 for K = 5 / 6; profiles/r06/mnist_stream_microbench_2.log, _8_table_sizes.log).  The REAL dataset (60 000 images, 47 MB)
+// is larger than the 32 MiB of L2 the chip has: every gather then comes from the Infinity Cache, the chain {state word -> four
+// pixels -> store} is longer, and more of it in flight per wave pays: K = 4: 5.03, 5: 5.37, 6: 5.37, 8: 4.46 TB/s — where the r05
+// body reached 3.9 (_7_table47MB.log; through the library: 761 us per step at K = 4 on such a table, 515 on the small one).
 #define MNIST_K 4
+#define MNIST_K_BIG_TABLE 6
+#define MNIST_BIG_TABLE_BYTES (32ll << 20)
+static bool mnist_big_table(const mnist_observe_args& o, const bsx_mnist_t* cfg) {
+  return (int64_t)cfg->num_data * (int64_t)o.cells > MNIST_BIG_TABLE_BYTES;
+}
 
 static int mnist_make(const bsx_mnist_t* cfg, const bsx_call_t* call, const int32_t* action, int32_t* state,
                       bsx_timestep_t out, double* info, mnist_args* a, mnist_observe_args* o) {
@@ -79,7 +90,8 @@ extern "C" int bsx_mnist_step(const bsx_mnist_t* cfg, const bsx_call_t* call, co
   if (call->n_lanes == 0) return 0;
   hipStream_t st = (hipStream_t)call->hip_stream;
   const int64_t blocks_a = (call->n_lanes + BSX_BLOCK - 1) / BSX_BLOCK;
-  const uint64_t blocks_o = bsx_flat_blocks((uint64_t)call->n_lanes * o.cells, MNIST_K);
+  const bool big = mnist_big_table(o, cfg);
+  const uint64_t blocks_o = bsx_flat_blocks((uint64_t)call->n_lanes * o.cells, big ? MNIST_K_BIG_TABLE : MNIST_K);
   if (blocks_a > 0x7FFFFFFF || blocks_o > 0x7FFFFFFFull) return BSX_EINVAL;
   const int n_steps = bsx_n_steps(call);
   for (int t = 0; t < n_steps; ++t) {       // rollout: the kernel pair once per step
@@ -90,7 +102,8 @@ extern "C" int bsx_mnist_step(const bsx_mnist_t* cfg, const bsx_call_t* call, co
     a.out.reward = out.reward + off; a.out.discount = out.discount + off; a.out.step_type = out.step_type + off;
     mnist_advance_kernel<<<dim3((unsigned)blocks_a), dim3(BSX_BLOCK), 0, st>>>(a);
     o.obs = out.observation + off * (int64_t)o.cells;
-    mnist_observe_kernel<MNIST_K><<<dim3((unsigned)blocks_o), dim3(BSX_BLOCK), 0, st>>>(o);
+    if (big) mnist_observe_kernel<MNIST_K_BIG_TABLE><<<dim3((unsigned)blocks_o), dim3(BSX_BLOCK), 0, st>>>(o);
+    else mnist_observe_kernel<MNIST_K><<<dim3((unsigned)blocks_o), dim3(BSX_BLOCK), 0, st>>>(o);
   }
   return bsx_launch_status();
 }

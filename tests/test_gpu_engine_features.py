@@ -138,14 +138,19 @@ def test_invalid_actions_are_clamped_and_counted():
 
 
 @pytest.mark.parametrize('batch', [5, 6, 257, 4097])
-@pytest.mark.parametrize('custom_table', [False, True])
-def test_mnist_observation_stream_tables_and_ragged_ends(batch, custom_table):
+@pytest.mark.parametrize('custom_table,big_dataset', [(False, False), (True, False), (False, True), (True, True)])
+def test_mnist_observation_stream_tables_and_ragged_ends(batch, custom_table, big_dataset):
   """The mnist observation stream (csrc/mnist_fam.h): the reference's pixel table np.float32(int8) / 255 (mnist.py:64) is
   recognised and computed per wave; any other table in bsx_mnist_t.pixel_lut is read from the arguments.  Both forms, on
-  batches whose last workgroup is partial (16 KiB = 5.22 rows), against the table applied on the host."""
+  batches whose last workgroup is partial (16 KiB = 5.22 rows), against the table applied on the host — on the small
+  dataset and on one beyond 32 MiB (the real MNIST's class: six KiB-runs per wave, csrc/mnist.hip)."""
   from bsuite_amd.environments import mnist
   from tests import golden_util as gu
   images, labels = gu.mnist_dataset()
+  if big_dataset:
+    rng = np.random.default_rng(1)
+    images = rng.integers(-128, 128, size=(43000, 28, 28), dtype=np.int8)
+    labels = rng.integers(0, 10, size=43000).astype(np.uint8)
   env = mnist.MNISTBandit(seed=5, batch=batch, images=images, labels=labels, num_buffers=1)
   table = np.arange(256, dtype=np.uint8).view(np.int8).astype(np.float32) / 255
   if custom_table:

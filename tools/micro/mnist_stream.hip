@@ -410,12 +410,14 @@ int main(int argc, char** argv) {
   const variant vs[] = {
       {"fill K4", L<4, M_FILL>, false},
       {"hot K4 (deep_sea chain)", L<4, M_HOT>, false},
-      {"flat lutW K4", P<4, 1, 0>, true},
-      {"flat hot K4", P<4, 1, 2>, false},
-      {"flat hot+gather K4", P<4, 1, 3>, false},
-      {"flat hot+reload+ldsvals K4", P<4, 1, 6>, false}, {"flat hot+reload+ldsvals K3", P<3, 1, 6>, false}, {"flat hot+reload+ldsvals K5", P<5, 1, 6>, false},
-      {"flat hot+ldsvals K4", P<4, 1, 7>, false}, {"flat hot+ldsvals K3", P<3, 1, 7>, false}, {"flat hot+ldsvals K5", P<5, 1, 7>, false},
-      {"flat lutW K4 (again)", P<4, 1, 0>, true}, {"hot K4 (again)", L<4, M_HOT>, false},
+      {"cur K4 (r05 product)", L<4, M_CUR>, true}, {"cur K8", L<8, M_CUR>, true},
+      {"lutW K8 (branchy)", L<8, M_LUTW>, true},
+      {"flat lutW K2", P<2, 1, 0>, true}, {"flat lutW K3", P<3, 1, 0>, true}, {"flat lutW K4", P<4, 1, 0>, true},
+      {"flat lutW K5", P<5, 1, 0>, true}, {"flat lutW K6", P<6, 1, 0>, true}, {"flat lutW K8", P<8, 1, 0>, true},
+      {"flat arith K4", P<4, 1, 1>, true},
+      {"pipe K4 R2", P<4, 2, 0>, true}, {"pipe K4 R4", P<4, 4, 0>, true}, {"pipe K2 R4", P<2, 4, 0>, true}, {"pipe K2 R8", P<2, 8, 0>, true},
+      {"pipe K1 R8", P<1, 8, 0>, true}, {"pipe K4 R4 depth2", P<4, 4, 0, 2>, true}, {"pipe K2 R8 depth2", P<2, 8, 0, 2>, true},
+      {"flat lutW K4 (again)", P<4, 1, 0>, true},
   };
   const int nv = sizeof(vs) / sizeof(vs[0]);
   // correctness of the exact variants against the host (half pattern), first 4096 + last 4096 lanes
@@ -448,7 +450,7 @@ int main(int argc, char** argv) {
   hipEventCreate(&e0); hipEventCreate(&e1);
   printf("lanes %lld x %u floats = %.3f GB per launch, %d images; us per launch (best of %d rounds of %d launches) and TB/s\n",
          (long long)B, cells, total * 4 / 1e9, n_img, rounds, reps);
-  for (int p = 0; p < 3; ++p) {
+  for (int p = 0; p < (getenv("ALL_PATTERNS") ? 3 : 1); ++p) {
     a.state = d_state[p];
     std::vector<float> best((size_t)nv, 1e30f), sum((size_t)nv, 0.f);
     for (int r = 0; r < rounds; ++r)

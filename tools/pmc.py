@@ -70,6 +70,35 @@ def one_pass(counters, bench_args, wanted, last):
   return res
 
 
+def last_total(counter, bench_args, wanted, n):
+  """SUM of `counter` (KiB) over the LAST n dispatches of the kernels whose names contain one of `wanted`, in dispatch
+  order — the timed region of a multi-launch rollout (1 advance + T-1 pipelined launches + 1 stream per call) — and
+  how many dispatches of each kernel that was."""
+  rows = raw_pass([counter], bench_args, wanted)
+  flat = sorted((i, k, v.get(counter, 0.0)) for k, per in rows.items() for i, v in per.items())
+  if len(flat) < n:
+    raise SystemExit(f'{len(flat)} dispatches of {wanted}, {n} expected')
+  by_kernel = collections.Counter(short(k) for _, k, _ in flat[-n:])
+  return sum(v for _, _, v in flat[-n:]), dict(by_kernel)
+
+
+def raw_pass(counters, bench_args, wanted):
+  out = tempfile.mkdtemp(prefix='pmc_', dir='/tmp')
+  cmd = ['timeout', '600', 'rocprofv3', '--pmc'] + list(counters) + ['--kernel-trace', '--output-format', 'csv', '-d', out, '--',
+         sys.executable] + SCRIPT + bench_args
+  p = subprocess.run(cmd, cwd='/tmp', env=dict(os.environ, TMPDIR='/tmp'), stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                     text=True, check=False)
+  rows = collections.defaultdict(lambda: collections.defaultdict(dict))
+  for f in glob.glob(os.path.join(out, '**', '*counter_collection.csv'), recursive=True):
+    for r in csv.DictReader(open(f)):
+      k = r['Kernel_Name']
+      if any(w in k for w in wanted):
+        rows[k][int(r['Dispatch_Id'])][r['Counter_Name']] = float(r['Counter_Value'])
+  if not rows:
+    raise SystemExit(f'rocprofv3 pass {counters} produced no rows for {wanted}: rc={p.returncode}\n{p.stderr[-2000:]}')
+  return rows
+
+
 def short(k):
   return k.split('(')[0].replace('void ', '')[:90]
 
@@ -83,6 +112,11 @@ def main():
   ap.add_argument('--alg-bytes', type=float, default=0.0)
   ap.add_argument('--lanes', type=int, default=1 << 20)
   ap.add_argument('--last', type=int, default=0)
+  ap.add_argument('--last-total', type=int, default=0,
+                  help='the LAST N dispatches of all --kernels together are the timed region (a pipelined rollout is 1 advance + '
+                       'T-1 pipelined launches + 1 stream per call); the per-launch figures become per STEP: their sum / --steps-total')
+  ap.add_argument('--steps-total', type=int, default=0, help='env steps the counted dispatches cover (see --last-total)')
+  ap.add_argument('--steps-per-launch', type=int, default=1, help='a fused rollout launch runs T steps: per-launch bytes / T')
   ap.add_argument('--script', default=None, help='profile this python script instead of bench.py (needs --last)')
   sep = sys.argv.index('--', 2)
   args = ap.parse_args(sys.argv[1:sep])
@@ -104,14 +138,23 @@ def main():
     missing = [k for k in kernels if k not in passes['FETCH_SIZE']]
     if missing or not kernels:
       raise SystemExit(f'kernels missing from the FETCH_SIZE pass: {missing or args.kernels}')
-    write = sum(passes['WRITE_SIZE'][k]['WRITE_SIZE'] * 1024 for k in kernels)
-    fetch = sum(2 * passes['FETCH_SIZE'][k]['FETCH_SIZE'] * 1024 for k in kernels)
+    if args.last_total:
+      # per STEP of a multi-launch rollout: everything the timed region's dispatches moved / the steps they cover
+      w_kib, by_kernel = last_total('WRITE_SIZE', bench_args, args.kernels, args.last_total)
+      f_kib, _ = last_total('FETCH_SIZE', bench_args, args.kernels, args.last_total)
+      write, fetch = w_kib * 1024 / args.steps_total, 2 * f_kib * 1024 / args.steps_total
+      doc['timed_region'] = dict(dispatches=args.last_total, steps=args.steps_total, dispatches_by_kernel=by_kernel,
+                                 write_KiB_total=w_kib, fetch_KiB_total=f_kib)
+    else:
+      write = sum(passes['WRITE_SIZE'][k]['WRITE_SIZE'] * 1024 for k in kernels) / args.steps_per_launch
+      fetch = sum(2 * passes['FETCH_SIZE'][k]['FETCH_SIZE'] * 1024 for k in kernels) / args.steps_per_launch
     doc.update(kernels={short(k): dict(write_KiB=passes['WRITE_SIZE'][k]['WRITE_SIZE'], fetch_KiB=passes['FETCH_SIZE'][k]['FETCH_SIZE'],
                                        dispatches=passes['WRITE_SIZE'][k]['_n'], dur_us=(passes['WRITE_SIZE'][k]['_dur_ns'] or 0) / 1e3)
                         for k in kernels},
                write_size_calibration=calib,
                fetch_note='FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 reports 1/2 of coalesced reads)',
-               per_launch=dict(note='sum over the kernels of one step', write_bytes=write, fetch_bytes_x2=fetch,
+               per_launch=dict(note='sum over the kernels of one step' + (f' (a launch runs {args.steps_per_launch} steps: per-launch bytes / {args.steps_per_launch})' if args.steps_per_launch > 1 else '')
+                                    + (' (multi-launch rollout: the timed dispatches summed / their steps)' if args.last_total else ''), write_bytes=write, fetch_bytes_x2=fetch,
                                hbm_bytes=write + fetch, algorithmic_bytes=args.alg_bytes,
                                ratio=(write + fetch) / args.alg_bytes if args.alg_bytes else None))
   else:

@@ -39,6 +39,17 @@ pm traffic discounting_chain $out/discounting_chain_pmc_traffic.json --kernels "
 pm traffic memory_len $out/memory_len_pmc_traffic.json --kernels "small_obs_kernel<memory_chain_env" "small_obs_eager2_kernel<memory_chain_env" --alg-bytes $((49*B)) -- --steps 20 --warmup 4 $A --workload memory_len
 pm traffic umbrella_length $out/umbrella_length_pmc_traffic.json --kernels "small_obs_kernel<umbrella_chain_env" --alg-bytes $((113*B)) -- --steps 20 --warmup 4 $A --workload umbrella_length
 pm traffic mnist $out/mnist_pmc_traffic.json --kernels mnist_advance_kernel mnist_observe_kernel --alg-bytes $((3157*B)) -- --steps 20 --warmup 4 $A --workload mnist
+# ... and behind every rollout / wrapped record of the default line: a fused rollout launch runs 16 steps
+# (per-launch bytes / 16); a pipelined rollout of deep_sea / catch is T+1 launches per call (the timed dispatches summed / their steps)
+pm traffic catch_noise $out/catch_noise_pmc_traffic.json --kernels "catch_fam" "catch_hot" --alg-bytes $((221*B)) -- --steps 20 --warmup 4 $A --workload catch_noise
+pm traffic deep_sea_logging $out/deep_sea_logging_pmc_traffic.json --kernels "deep_sea_fam" "deep_sea_hot" --alg-bytes $((3621*B)) -- --steps 20 --warmup 4 $A --workload deep_sea --logging
+pm traffic catch_rollout32 $out/catch_rollout32_pmc_traffic.json --kernels "catch_fam" "catch_hot" --alg-bytes $((221*B)) --last 7 --last-total $((7*33)) --steps-total 224 -- --workload catch --rollout 32 --steps 224 --warmup 32 $A
+pm traffic deep_sea_rollout16 $out/deep_sea_rollout16_pmc_traffic.json --kernels "deep_sea_fam" "deep_sea_hot" --alg-bytes $((3621*B)) --last 3 --last-total $((3*17)) --steps-total 48 -- --workload deep_sea --rollout 16 --steps 48 --warmup 16 $A
+for wk in "cartpole cartpole_env 40" "mountain_car mountain_car_env 26.5" "bandit bandit_env 17.5" "discounting_chain discounting_chain_env 21.5" "memory_len memory_chain_env 26.5" "umbrella_length umbrella_chain_env 105.5"; do
+  set -- $wk; ns=""; [ $1 = mountain_car ] && ns="--no-stagger"
+  alg=$(python -c "print(int($3*$B))")
+  pm traffic ${1}_rollout16 $out/${1}_rollout16_pmc_traffic.json --kernels "small_obs_lean_rollout_kernel<$2" "small_obs_kernel<$2" --alg-bytes $alg --last 4 --steps-per-launch 16 -- --workload $1 --rollout 16 --steps 64 --warmup 16 $A $ns
+done
 for w in bandit discounting_chain memory_len umbrella_length mnist; do
   timeout 300 python tools/kernel_stats.py $out/${w}_kernel_stats.csv -- --workload $w --steps 200 --warmup 20 $A > /dev/null 2>>$out/kernel_stats.err
 done
