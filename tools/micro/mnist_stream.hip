@@ -1,19 +1,23 @@
 // What holds the mnist observation stream (mnist_fam.h) below deep_sea's store rate for the same 784-float row?
-// (VERDICT r05 next #1.)  The bare patterns, every one over the same [2^20 x 784] f32 array, same box, same process,
+// (VERDICT r05 next #1.)  The bare patterns, every one over the same [lanes x cells] f32 array, same box, same process,
 // interleaved repetitions.  A kernel = K x 4 KiB runs per workgroup, 16-byte stores, wave-contiguous (the product shape):
-//   fill        no loads at all (the ceiling of this launch shape)
-//   hot         state load -> one-hot decode -> store              (deep_sea's chain)
-//   cur         state load -> image gather -> LUT from MEMORY + workgroup barrier -> LDS lookups -> store   (r05 product)
-//   nogather    cur without the gather (pixels synthesised from the state word)
-//   nolut       cur without LUT/barrier (the gathered dword stored as it is)
-//   lutA        LUT filled by ARITHMETIC (bsx_mnist_pixel_value), workgroup barrier
-//   lutW        per-WAVE LUT filled by arithmetic: no memory round trip and no workgroup barrier in front of a store
-//   arith       no LUT: four pixel values computed per chunk
-//   pipe<R>     lutW + every wave runs R rounds of K stores, the loads of round r+1 (gather) / r+2 (state) issued BEFORE
-//               the stores of round r: gfx9 counts loads and stores in ONE in-order vmcnt, so a load issued after a
-//               store waits for that store's acknowledgement; issued before it, the chain hides behind the stores
-// Lane patterns: half (each lane shows an image with probability 1/2: the bench's staggered phases), all, none.
+//   k_obs    guarded code (`if (live) load`, `if (show) gather`, `if (!live) continue`: exec-mask branches, the compiler's
+//            s_waitcnt insertion waits vmcnt(0) at every join — in the one-hot kernel that is ONE store in flight per wave):
+//            fill (no loads), hot (deep_sea's chain), cur (the r05 mnist body), nogather / nolut (cur minus one element),
+//            lutA (table by arithmetic + workgroup barrier), lutW (per-wave table), arith (no table)
+//   k_pipe   STRAIGHT-LINE code: unconditional loads with selected addresses, selected values; R rounds of K stores per wave
+//            with the loads of later rounds issued ahead of this round's stores (R = 1: "flat"); LUTMODE: 0 mnist with the
+//            per-wave arithmetic table (the r06 product body), 1 per-pixel arithmetic, 2.. one-hot chains with extras
+//   k_xcd    which XCD writes which addresses (granule 2^lgG bytes, independent of K)
+//   k_paced  all loads first, then the stores with at most N older ones unacknowledged (s_waitcnt vmcnt(N)) or spaced by
+//            s_sleep / s_nop
+// Findings (profiles/r06/mnist_stream_microbench*.log): the mnist loss was the guarded CODE SHAPE (cur 5.5 -> flat 7.0 TB/s);
+// K = 4 is a sharp optimum for an L2-resident image table, 5-6 for a 47 MB one; the one-hot chain is best exactly as the
+// product has it (guarded = ack-serialised stores: 6.7; flat 6.1; any pacing by sleeps 5.8-6.1); rounds per wave, XCD granules
+// and table-free arithmetic do not help.
+// Lane patterns: half (each lane shows an image with probability 1/2: the bench's staggered phases), all, none (ALL_PATTERNS=1).
 // Build: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off tools/micro/mnist_stream.hip -o tools/ab/mnist_stream
+// Run:   tools/ab/mnist_stream [lanes=2^20] [cells=784] [images=96]
 #include <hip/hip_runtime.h>
 #include <cstdint>
 #include <cstdio>
