@@ -457,7 +457,11 @@ struct bsx_stream_seg {            // one segment's arguments of the observation
   HotFn fn;
 };
 
-template <class HotFn, int K, int BS>
+// NT: non-temporal stores.  Stand-alone they cost the stream 8-10 % (deep_sea 586 -> 636-652 us per step, catch 41.0 -> 42.5:
+// r01, and again profiles/r06/ab_nontemporal_stores.log); inside the sweep's mixed stream they are what keeps everything ELSE —
+// the state columns the stream itself reads, the small families' columns, actions and tables — in cache while 842 MB of
+// observations pass: closed-loop sweep step 161-162.5 -> 157-161.5 us, open-loop 157-158 -> 150-151.6 (pair_mixed.h).
+template <class HotFn, int K, int BS, bool NT = false>
 __device__ __forceinline__ void bsx_hot_stream_body(float* __restrict__ obs,
                                                     const int32_t* __restrict__ state,
                                                     int64_t n_lanes, uint32_t cells,
@@ -528,7 +532,11 @@ __device__ __forceinline__ void bsx_hot_stream_body(float* __restrict__ obs,
       if (over <= 2) v.z = (a1 == 2 || b1 == 2) ? 1.0f : 0.0f;
       v.w = (a1 == 3 || b1 == 3) ? 1.0f : 0.0f;
     }
-    o4[wave_contig ? ((threadIdx.x >> 6) * (K * 64) + u * 64 + (threadIdx.x & 63)) : (threadIdx.x + u * BS)] = v;
+    {
+      bsx_f4* dst = &o4[wave_contig ? ((threadIdx.x >> 6) * (K * 64) + u * 64 + (threadIdx.x & 63)) : (threadIdx.x + u * BS)];
+      if (NT) __builtin_nontemporal_store(v, dst);
+      else *dst = v;
+    }
   }
   // ragged tail (< 4 floats) of an odd-sized array: the block that contains the array's end
   const uint64_t tail0 = total & ~3ull;

@@ -41,18 +41,14 @@ __global__ void __launch_bounds__(BSX_BLOCK) mnist_observe_group_kernel(const mn
   mnist_observe_body<K>(table[w.seg], w.block, s_lut);
 }
 
-// KiB-runs per wave.  16 KiB per workgroup is a sharp optimum of the straight-line body while the image table stays in L2 (K = 3:
-// 5.95, 4: 7.0, 5: 5.9, 8: 5.9 TB/s at 2^20 lanes with 96 images, and 4 stays best up to 20 000 images = 15.7 MB: 6.66 against
-// 5.6 for K = 5 / 6; profiles/r06/mnist_stream_microbench_2.log, _8_table_sizes.log).  The REAL dataset (60 000 images, 47 MB)
-// is larger than the 32 MiB of L2 the chip has: every gather then comes from the Infinity Cache, the chain {state word -> four
-// pixels -> store} is longer, and more of it in flight per wave pays: K = 4: 5.03, 5: 5.37, 6: 5.37, 8: 4.46 TB/s — where the r05
-// body reached 3.9 (_7_table47MB.log; through the library: 761 us per step at K = 4 on such a table, 515 on the small one).
+// 4 KiB-runs per wave: 16 KiB per workgroup is a sharp optimum of the straight-line body (K = 3: 5.95, 4: 7.0, 5: 5.9, 8: 5.9 TB/s
+// at 2^20 lanes with 96 images; 4 stays best up to 20 000 images = 15.7 MB; profiles/r06/mnist_stream_microbench_2.log,
+// _8_table_sizes.log).  The REAL dataset (60 000 images, 47 MB) is larger than the 32 MiB of L2 the chip has: the stream's own
+// stores then evict the table rows between their uses, and NON-TEMPORAL stores are what helps — bare pattern on a 47 MB
+// table: r05 body 3.9 TB/s, this body 5.0-5.2, six KiB-runs 5.3-5.4, **four + nt stores 5.8**; prefetching the rows a later
+// workgroup of the same XCD will gather: 4.0-4.2, worse (_7_table47MB.log, _9_table47MB_nt_prefetch.log, _10_nt_by_table.log).
 #define MNIST_K 4
-#define MNIST_K_BIG_TABLE 6
 #define MNIST_BIG_TABLE_BYTES (32ll << 20)
-static bool mnist_big_table(const mnist_observe_args& o, const bsx_mnist_t* cfg) {
-  return (int64_t)cfg->num_data * (int64_t)o.cells > MNIST_BIG_TABLE_BYTES;
-}
 
 static int mnist_make(const bsx_mnist_t* cfg, const bsx_call_t* call, const int32_t* action, int32_t* state,
                       bsx_timestep_t out, double* info, mnist_args* a, mnist_observe_args* o) {
@@ -72,7 +68,8 @@ static int mnist_make(const bsx_mnist_t* cfg, const bsx_call_t* call, const int3
   o->cells = (uint32_t)cfg->num_pixels; o->cells_magic = bsx_div_magic(o->cells); o->dv = bsx_make_div64(o->cells);
   // the reference's table (np.float32(int8) / 255) is recognised and then COMPUTED per wave (bsx_mnist_pixel_value, exact);
   // any other table is read from the arguments
-  o->arith = 1; o->_pad = 0;
+  o->arith = 1;
+  o->nt = (int64_t)cfg->num_data * (int64_t)cfg->num_pixels > MNIST_BIG_TABLE_BYTES;
   for (int k = 0; k < 256; ++k) {
     o->lut[k] = cfg->pixel_lut[k];
     const float want = bsx_mnist_pixel_value((uint32_t)k, 0);
@@ -90,8 +87,7 @@ extern "C" int bsx_mnist_step(const bsx_mnist_t* cfg, const bsx_call_t* call, co
   if (call->n_lanes == 0) return 0;
   hipStream_t st = (hipStream_t)call->hip_stream;
   const int64_t blocks_a = (call->n_lanes + BSX_BLOCK - 1) / BSX_BLOCK;
-  const bool big = mnist_big_table(o, cfg);
-  const uint64_t blocks_o = bsx_flat_blocks((uint64_t)call->n_lanes * o.cells, big ? MNIST_K_BIG_TABLE : MNIST_K);
+  const uint64_t blocks_o = bsx_flat_blocks((uint64_t)call->n_lanes * o.cells, MNIST_K);
   if (blocks_a > 0x7FFFFFFF || blocks_o > 0x7FFFFFFFull) return BSX_EINVAL;
   const int n_steps = bsx_n_steps(call);
   for (int t = 0; t < n_steps; ++t) {       // rollout: the kernel pair once per step
@@ -102,8 +98,7 @@ extern "C" int bsx_mnist_step(const bsx_mnist_t* cfg, const bsx_call_t* call, co
     a.out.reward = out.reward + off; a.out.discount = out.discount + off; a.out.step_type = out.step_type + off;
     mnist_advance_kernel<<<dim3((unsigned)blocks_a), dim3(BSX_BLOCK), 0, st>>>(a);
     o.obs = out.observation + off * (int64_t)o.cells;
-    if (big) mnist_observe_kernel<MNIST_K_BIG_TABLE><<<dim3((unsigned)blocks_o), dim3(BSX_BLOCK), 0, st>>>(o);
-    else mnist_observe_kernel<MNIST_K><<<dim3((unsigned)blocks_o), dim3(BSX_BLOCK), 0, st>>>(o);
+    mnist_observe_kernel<MNIST_K><<<dim3((unsigned)blocks_o), dim3(BSX_BLOCK), 0, st>>>(o);
   }
   return bsx_launch_status();
 }

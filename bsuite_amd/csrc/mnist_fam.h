@@ -66,7 +66,7 @@ struct mnist_observe_args {
   uint32_t cells_magic;
   bsx_div64 dv;
   int32_t arith;          // the table is exactly np.float32(int8) / 255 (mnist_make checks all 256 entries): computed, never read
-  int32_t _pad;
+  int32_t nt;             // the image table is larger than the chip's L2: non-temporal observation stores (mnist.hip)
   float lut[256];         // read only when !arith (a caller-defined pixel table)
 };
 
@@ -89,7 +89,10 @@ struct mnist_observe_args {
 // K = 5: 5.89, K = 8: 5.9), several rounds per wave with the next round's loads issued ahead of this round's stores
 // (5.6-5.8), table-free pixel arithmetic (equal when every lane shows, 6.2-6.5 otherwise), a fixed XCD <-> address granule.
 #define MNIST_LUT_FLOATS (256 * (BSX_BLOCK / BSX_WAVE))
-template <int K, bool ARITH, bool FULL>
+// NT: non-temporal stores — for an image table beyond the chip's L2 (the real dataset): 3.3 GB of ordinary stores per call
+// evict the table between two gathers of the same row; with nt stores it stays cached (47 MB table: 5.0-5.3 -> 5.8 TB/s,
+// 34 MB: 5.6-5.8 -> 6.1); on a table that fits L2 they cost 10 % (6.95 -> 6.2: profiles/r06/mnist_stream_microbench_9*, _10*.log)
+template <int K, bool ARITH, bool FULL, bool NT = false>
 __device__ __forceinline__ void mnist_observe_chunks(const mnist_observe_args& a, uint32_t block_id, float* s_lut) {
   const uint32_t wave = threadIdx.x >> 6, wl = threadIdx.x & 63u;
   s_lut += wave * 256;                                                   // this wave's copy
@@ -139,21 +142,34 @@ __device__ __forceinline__ void mnist_observe_chunks(const mnist_observe_args& a
     bsx_f4 v;
     v.x = s_lut[p & 0xFF]; v.y = s_lut[(p >> 8) & 0xFF]; v.z = s_lut[(p >> 16) & 0xFF]; v.w = s_lut[p >> 24];
     v.x = show ? v.x : 0.f; v.y = show ? v.y : 0.f; v.z = show ? v.z : 0.f; v.w = show ? v.w : 0.f;
-    if (FULL || live[u]) o4[(wave * K + u) * 64u + wl] = v;
+    if (FULL || live[u]) {
+      if (NT) __builtin_nontemporal_store(v, &o4[(wave * K + u) * 64u + wl]);
+      else o4[(wave * K + u) * 64u + wl] = v;
+    }
+  }
+}
+
+template <int K, bool NT>
+__device__ __forceinline__ void mnist_observe_body_nt(const mnist_observe_args& a, uint32_t block_id, float* s_lut) {
+  const uint64_t total = (uint64_t)a.n_lanes * a.cells;
+  const bool full = ((uint64_t)block_id + 1ull) * (uint64_t)(K * 4 * BSX_BLOCK) <= total;      // uniform
+  if (a.arith) {
+    if (full) mnist_observe_chunks<K, true, true, NT>(a, block_id, s_lut);
+    else mnist_observe_chunks<K, true, false, NT>(a, block_id, s_lut);
+  } else {
+    if (full) mnist_observe_chunks<K, false, true, NT>(a, block_id, s_lut);
+    else mnist_observe_chunks<K, false, false, NT>(a, block_id, s_lut);
   }
 }
 
 template <int K>
 __device__ __forceinline__ void mnist_observe_body(const mnist_observe_args& a, uint32_t block_id, float* s_lut) {
-  const uint64_t total = (uint64_t)a.n_lanes * a.cells;
-  const bool full = ((uint64_t)block_id + 1ull) * (uint64_t)(K * 4 * BSX_BLOCK) <= total;      // uniform
-  if (a.arith) {
-    if (full) mnist_observe_chunks<K, true, true>(a, block_id, s_lut);
-    else mnist_observe_chunks<K, true, false>(a, block_id, s_lut);
-  } else {
-    if (full) mnist_observe_chunks<K, false, true>(a, block_id, s_lut);
-    else mnist_observe_chunks<K, false, false>(a, block_id, s_lut);
-  }
+#if defined(BSX_AB_MNIST_NT)        // measurement builds only
+  mnist_observe_body_nt<K, true>(a, block_id, s_lut);
+  return;
+#endif
+  if (a.nt) mnist_observe_body_nt<K, true>(a, block_id, s_lut);                                // uniform
+  else mnist_observe_body_nt<K, false>(a, block_id, s_lut);
 }
 
 #endif  // BSX_MNIST_FAM_H_

@@ -32,19 +32,27 @@ int bsx_sweep_launch_split(bsx_group* g, hipStream_t st);
 int bsx_sweep_launch_pipelined(bsx_group* streams_of, bsx_group* advances_of, hipStream_t st);
 
 // One workgroup of the mixed observation store stream: `block` of the phase-1 grid runs its segment's
-// family stream body (deep_sea 4 x 4 KiB, catch 2 x 4 KiB, mnist 6 x 4 KiB, wide chain rows 2 x 4 KiB runs per workgroup).
-// mnist: 6 KiB-runs per wave — inside the mixed stream the straight-line mnist body is best at 24 KiB per workgroup (same
-// call, three repetitions each, closed-loop sweep step: 8: 162.0-165.3 us, 7: 160.9-163.9, 6: 158.8-159.6, 5: 164.8-165.9, 4:
-// 169-171; the r05 body at 8: 161.0-162.0; profiles/r06/ab_sweep_mnist_k.log) although alone over one large array it is best
-// at 16 KiB (mnist.hip)
+// family stream body (deep_sea 4 x 4 KiB, catch 2 x 4 KiB, mnist 4 x 4 KiB, wide chain rows 2 x 4 KiB runs per workgroup).
+// mnist: 4 KiB-runs per wave, its stand-alone optimum (mnist.hip) — but only TOGETHER with the non-temporal one-hot stores
+// below.  Same call, three / four repetitions each, closed-loop sweep step (profiles/r06/ab_sweep_mnist_k.log,
+// ab_nontemporal_stores*.log): with ordinary one-hot stores 4: 169-171 us, 5: 165-166, 6: 158.8-159.6, 7: 161-164, 8: 162-165
+// (r05 body at 8: 161-162); with non-temporal one-hot stores 3: 165-168, **4: 153.8-157.5**, 5: 154-162, 6: 159.6-163.5 on one
+// box and 157.8-161.9 (4) against 163.0-165.5 (6) and 162.9-164.4 (ordinary stores, 6) on a slower one.
 #ifndef PAIR_MNIST_K
-#define PAIR_MNIST_K 6
+#define PAIR_MNIST_K 4
 #endif
 #ifndef PAIR_DEEP_SEA_K
 #define PAIR_DEEP_SEA_K 4
 #endif
 #ifndef PAIR_CATCH_K
 #define PAIR_CATCH_K 2
+#endif
+// non-temporal stores for the one-hot bodies of the MIXED stream (bsx_hot_stream_body<..., NT>): what the other workgroups of the
+// launch and the next launch want to find in cache — state columns, action ring, tables, the small families' columns — is no
+// longer evicted by 420 MB of deep_sea / catch observations per sweep step.  Not for the mnist body (its image gathers like
+// ordinary neighbours: 165-171 us with nt on mnist alone, 157-169 with both; profiles/r06/ab_nontemporal_stores*.log)
+#ifndef PAIR_HOT_NT
+#define PAIR_HOT_NT true
 #endif
 __device__ __forceinline__ void pair_mixed_stream_body(const uint8_t* __restrict__ table, const int32_t* __restrict__ family,
                                                        const bsx_group_index& gi, uint32_t block, float* s_lut) {
@@ -53,12 +61,12 @@ __device__ __forceinline__ void pair_mixed_stream_body(const uint8_t* __restrict
   switch (w.tag >= 0 ? w.tag : (family[w.seg] & 0xFF)) {   // uniform per workgroup
     case BSX_FAM_DEEP_SEA: {
       const bsx_stream_seg<deep_sea_hot>& g = *reinterpret_cast<const bsx_stream_seg<deep_sea_hot>*>(slot);
-      bsx_hot_stream_body<deep_sea_hot, PAIR_DEEP_SEA_K, BSX_BLOCK>(g.obs, g.state, g.n_lanes, g.cells, g.cells_magic, g.dv, g.fn, w.block);
+      bsx_hot_stream_body<deep_sea_hot, PAIR_DEEP_SEA_K, BSX_BLOCK, PAIR_HOT_NT>(g.obs, g.state, g.n_lanes, g.cells, g.cells_magic, g.dv, g.fn, w.block);
       break;
     }
     case BSX_FAM_CATCH: {
       const bsx_stream_seg<catch_hot>& g = *reinterpret_cast<const bsx_stream_seg<catch_hot>*>(slot);
-      bsx_hot_stream_body<catch_hot, PAIR_CATCH_K, BSX_BLOCK>(g.obs, g.state, g.n_lanes, g.cells, g.cells_magic, g.dv, g.fn, w.block);
+      bsx_hot_stream_body<catch_hot, PAIR_CATCH_K, BSX_BLOCK, PAIR_HOT_NT>(g.obs, g.state, g.n_lanes, g.cells, g.cells_magic, g.dv, g.fn, w.block);
       break;
     }
     case BSX_FAM_MNIST:

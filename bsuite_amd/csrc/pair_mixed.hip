@@ -10,7 +10,7 @@
 //   phase 0  pair_mixed_advance_kernel   every lane of every segment advances in one ~8 us launch;
 //   phase 1  pair_mixed_stream_kernel    ONE store stream over all observation arrays (~850 of the
 //                                        sweep's 886 MB), each workgroup running its family's stream
-//                                        body (deep_sea 4 x 4 KiB, catch 2 x 4 KiB, mnist 6 x 4 KiB runs).
+//                                        body (deep_sea 4 x 4 KiB, catch 2 x 4 KiB, mnist 4 x 4 KiB runs).
 #include "catch_fam.h"
 #include "deep_sea_fam.h"
 #include "mnist_fam.h"

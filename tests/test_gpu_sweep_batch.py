@@ -311,3 +311,39 @@ def test_eager_and_grouped_steps_alternate_on_one_counter():
     for x, y in zip(eu.to_np(out), eu.to_np(ts)):
       np.testing.assert_array_equal(x, y, err_msg=bid)
   batch.release_groups()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('mix_all', [True, False])
+def test_grouped_mnist_on_a_dataset_beyond_l2_equals_standalone_envs(tmp_path, mix_all):
+  """An image table larger than the chip's 32 MiB of L2 (the real MNIST's class) switches the mnist observation stream to
+  non-temporal stores (csrc/mnist.hip: `mnist_observe_args.nt`, per segment) — stand-alone, inside the whole-sweep group
+  (6 KiB-runs per wave) and inside a per-family pair group: same TimeSteps and bsuite_info as the stand-alone environments."""
+  from bsuite_amd.utils import datasets
+  rng = np.random.default_rng(4)
+  imgs = rng.integers(0, 256, size=(43000, 28, 28), dtype=np.uint8)
+  labels = rng.integers(0, 10, size=43000).astype(np.uint8)
+  datasets.write_idx_files(str(tmp_path), imgs, labels, imgs[:16], labels[:16])
+  mn = dict(data_dir=str(tmp_path))
+  kw = dict(mnist=mn, mnist_noise=mn, mnist_scale=mn)
+  ids = ['mnist/0', 'deep_sea/3', 'mnist_noise/7', 'bandit/2', 'mnist_scale/12', 'catch/1']
+  total, seed, reps = len(ids) * 700 + 5, 31, 6
+  batch = sb.SweepBatch(ids, total, seed=seed, env_kwargs=kw)
+  acts = batch.random_actions(seed=9)
+  outs = batch.prepare_groups(acts, mix_all=mix_all)
+  for _ in range(reps):
+    batch.step_grouped()
+  batch.sync()
+  for (bid, begin, lanes), a, out, env in zip(batch.segments, acts, outs, batch.envs):
+    name = bid.split('/')[0]
+    ekw = dict(kw.get(name, {}))
+    if sweep.SETTINGS[bid].get('seed', 0) is None or 'seed' not in sweep.SETTINGS[bid]:
+      ekw['seed'] = seed
+    ref = bsuite_amd.load_from_id(bid, batch=lanes, lane_offset=begin, num_buffers=1, **ekw)
+    for _ in range(reps):
+      ts = ref.step(a)
+    for x, y in zip(eu.to_np(out), eu.to_np(ts)):
+      np.testing.assert_array_equal(x, y, err_msg=bid)
+    for k, v in ref.bsuite_info().items():
+      torch.testing.assert_close(env.bsuite_info()[k], v, rtol=0, atol=0)
+  batch.release_groups()

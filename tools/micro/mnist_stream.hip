@@ -351,6 +351,83 @@ __global__ void __launch_bounds__(BS) k_paced(const args a) {
   }
 }
 
+
+// The real dataset's class (image table beyond L2): (NT) the same straight-line body with NON-TEMPORAL stores — do the 3.3 GB
+// of stores per launch evict the table from L2 / the Infinity Cache? — and (DELTA > 0) with every workgroup also touching the
+// image rows that workgroup b + DELTA (a multiple of 8: the same XCD, hence the same L2) will gather, issued AFTER its own
+// gathers (one in-order vmcnt: its own pixels return first and nothing ever waits for the prefetch).
+typedef float f4v __attribute__((ext_vector_type(4)));
+template <int K, bool NT, int DELTA>
+__global__ void __launch_bounds__(BS) k_pref(const args a) {
+  __shared__ float s_lut_all[1024];
+  const uint32_t wave = threadIdx.x >> 6, wl = threadIdx.x & 63u;
+  float* s_lut = s_lut_all + wave * 256;
+  const uint32_t cells = a.cells;
+  const uint64_t total = (uint64_t)a.n_lanes * cells;
+  const uint64_t F0 = (uint64_t)blockIdx.x * (uint64_t)(K * 4 * BS);
+  const uint64_t lane_b = __umul64hi(F0, a.dv.m) >> a.dv.s;
+  const uint32_t r_b = (uint32_t)(F0 - lane_b * cells);
+  f4v* __restrict__ o4 = reinterpret_cast<f4v*>(a.obs + F0);
+  const int32_t* __restrict__ st = a.state + lane_b;
+  // the block DELTA ahead (clamped to the array)
+  uint64_t G0 = F0 + (uint64_t)DELTA * (uint64_t)(K * 4 * BS);
+  if (G0 + (uint64_t)(K * 4 * BS) > total) G0 = F0;
+  const uint64_t lane_g = __umul64hi(G0, a.dv.m) >> a.dv.s;
+  const uint32_t r_g = (uint32_t)(G0 - lane_g * cells);
+  const int32_t* __restrict__ stg = a.state + lane_g;
+  int32_t s[K], sg[K];
+  uint32_t r0[K], rg[K], px[K];
+#pragma unroll
+  for (int u = 0; u < K; ++u) {
+    const uint32_t c = (wave * K + u) * 64u + wl;
+    const uint32_t f = r_b + (c << 2);
+    const uint32_t dl = __umulhi(f, a.cells_magic);
+    r0[u] = f - dl * cells;
+    s[u] = st[dl];
+    if (DELTA > 0) {
+      const uint32_t g = r_g + (c << 2);
+      const uint32_t dg = __umulhi(g, a.cells_magic);
+      rg[u] = g - dg * cells;
+      sg[u] = stg[dg];
+    }
+  }
+  {
+    float4 l;
+    l.x = pixel_value(4 * wl, 0); l.y = pixel_value(4 * wl + 1, 0); l.z = pixel_value(4 * wl + 2, 0); l.w = pixel_value(4 * wl + 3, 0);
+    reinterpret_cast<float4*>(s_lut)[wl] = l;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  }
+#pragma unroll
+  for (int u = 0; u < K; ++u) {
+    const uint32_t row = (s[u] & SHOW_BIT) ? (uint32_t)(s[u] & 0x00FFFFFF) * cells : 0u;
+    px[u] = *reinterpret_cast<const uint32_t*>(a.images + (row + r0[u]));
+  }
+  uint32_t dummy[K];      // destinations of the prefetch loads: written whenever the data arrives, so they stay reserved
+  if (DELTA > 0) {        // (an asm sink after the stores) — the compiler does not know the asm is a load and would reuse them
+#pragma unroll
+    for (int u = 0; u < K; ++u) {
+      const uint32_t row = (sg[u] & SHOW_BIT) ? (uint32_t)(sg[u] & 0x00FFFFFF) * cells : 0u;
+      asm volatile("global_load_dword %0, %1, off" : "=&v"(dummy[u]) : "v"(a.images + (row + rg[u])) : "memory");   // never waited for
+    }
+  }
+#pragma unroll
+  for (int u = 0; u < K; ++u) {
+    const uint32_t p = px[u];
+    const bool sh = (s[u] & SHOW_BIT) != 0;
+    f4v v;
+    v.x = s_lut[p & 0xFF]; v.y = s_lut[(p >> 8) & 0xFF]; v.z = s_lut[(p >> 16) & 0xFF]; v.w = s_lut[p >> 24];
+    v.x = sh ? v.x : 0.f; v.y = sh ? v.y : 0.f; v.z = sh ? v.z : 0.f; v.w = sh ? v.w : 0.f;
+    if (NT) __builtin_nontemporal_store(v, &o4[(wave * K + u) * 64u + wl]);
+    else o4[(wave * K + u) * 64u + wl] = v;
+  }
+  if (DELTA > 0) {
+#pragma unroll
+    for (int u = 0; u < K; ++u) asm volatile("" :: "v"(dummy[u]));
+  }
+}
+
 static div64 make_div64(uint32_t d) {
   div64 r; uint32_t lg = 0;
   while ((2u << lg) <= d) ++lg;
@@ -377,6 +454,11 @@ template <int K, int MODE, int LGG> static void X(const args& a, uint64_t total)
 template <int K, int N, int MODE> static void W(const args& a, uint64_t total) {
   const uint64_t per = (uint64_t)K * 4 * BS;
   k_paced<K, N, MODE><<<dim3((unsigned)(total / per)), dim3(BS)>>>(a);      // (the tail of a non-multiple is left unwritten: timing only)
+}
+
+template <int K, bool NT, int DELTA> static void F(const args& a, uint64_t total) {
+  const uint64_t per = (uint64_t)K * 4 * BS;
+  k_pref<K, NT, DELTA><<<dim3((unsigned)(total / per)), dim3(BS)>>>(a);     // (total % per == 0 at the bench sizes)
 }
 
 struct variant { const char* name; launch_fn fn; bool exact; };
@@ -412,15 +494,15 @@ int main(int argc, char** argv) {
   a.obs = d_obs; a.images = d_img; a.lut = d_lut; a.n_lanes = B; a.cells = cells;
   a.cells_magic = (uint32_t)((0x100000000ull / cells) + 1ull); a.dv = make_div64(cells);
   const variant vs[] = {
-      {"fill K4", L<4, M_FILL>, false},
       {"hot K4 (deep_sea chain)", L<4, M_HOT>, false},
-      {"cur K4 (r05 product)", L<4, M_CUR>, true}, {"cur K8", L<8, M_CUR>, true},
-      {"lutW K8 (branchy)", L<8, M_LUTW>, true},
-      {"flat lutW K2", P<2, 1, 0>, true}, {"flat lutW K3", P<3, 1, 0>, true}, {"flat lutW K4", P<4, 1, 0>, true},
-      {"flat lutW K5", P<5, 1, 0>, true}, {"flat lutW K6", P<6, 1, 0>, true}, {"flat lutW K8", P<8, 1, 0>, true},
-      {"flat arith K4", P<4, 1, 1>, true},
-      {"pipe K4 R2", P<4, 2, 0>, true}, {"pipe K4 R4", P<4, 4, 0>, true}, {"pipe K2 R4", P<2, 4, 0>, true}, {"pipe K2 R8", P<2, 8, 0>, true},
-      {"pipe K1 R8", P<1, 8, 0>, true}, {"pipe K4 R4 depth2", P<4, 4, 0, 2>, true}, {"pipe K2 R8 depth2", P<2, 8, 0, 2>, true},
+      {"cur K4 (r05 product)", L<4, M_CUR>, true},
+      {"flat lutW K4", P<4, 1, 0>, true}, {"flat lutW K6", P<6, 1, 0>, true},
+      {"pref K4 plain", F<4, false, 0>, false}, {"pref K6 plain", F<6, false, 0>, false},
+      {"pref K4 nt-stores", F<4, true, 0>, false}, {"pref K6 nt-stores", F<6, true, 0>, false},
+      {"pref K4 ahead 64", F<4, false, 64>, false}, {"pref K4 ahead 256", F<4, false, 256>, false},
+      {"pref K4 ahead 1024", F<4, false, 1024>, false}, {"pref K4 ahead 2048", F<4, false, 2048>, false}, {"pref K4 ahead 4096", F<4, false, 4096>, false},
+      {"pref K6 ahead 256", F<6, false, 256>, false}, {"pref K6 ahead 1024", F<6, false, 1024>, false}, {"pref K6 ahead 2048", F<6, false, 2048>, false},
+      {"pref K4 nt ahead 1024", F<4, true, 1024>, false}, {"pref K4 nt ahead 2048", F<4, true, 2048>, false},
       {"flat lutW K4 (again)", P<4, 1, 0>, true},
   };
   const int nv = sizeof(vs) / sizeof(vs[0]);
