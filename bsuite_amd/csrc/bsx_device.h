@@ -725,7 +725,11 @@ __global__ void __launch_bounds__(BSX_BLOCK) bsx_pipelined_kernel(const typename
   __shared__ unsigned int s_cnt[2];
   const bsx_pipe_role r = bsx_pipe_role_of(blockIdx.x, gridDim.x, adv_blocks, place);   // uniform per workgroup
   if (r.adv) bsx_advance_body<Fam, LEAN>(a, r.index, s_fam, s_cnt);
+#if defined(BSX_AB_PIPELINED_NT)     // measurement builds only: non-temporal stores in the pipelined rollout's stream half
+  else bsx_hot_stream_body<HotFn, K, BSX_BLOCK, true>(obs, hot_state, a.ctl.n_lanes, cells, cells_magic, dv, fn, r.index);
+#else
   else bsx_hot_stream_body<HotFn, K, BSX_BLOCK>(obs, hot_state, a.ctl.n_lanes, cells, cells_magic, dv, fn, r.index);
+#endif
 }
 
 template <class HotFn, int K>

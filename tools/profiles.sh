@@ -4,10 +4,11 @@
 # (tools/pmc.py); kernel averages over the TIMED launches only (tools/kernel_stats.py).
 #   bash tools/profiles.sh [quick]     quick: skip the test suite and the secondary workloads
 set -u
+mode=${1:-}
 out=$PWD/gpurun_out/final; mkdir -p $out
 B=1048576
 A="--no-cpu-baseline --no-also"
-if [ "${1:-}" != quick ] && [ -z "${SKIP_PYTEST:-}" ]; then
+if [ "$mode" != quick ] && [ -z "${SKIP_PYTEST:-}" ]; then
   ( time timeout 1700 python -m pytest tests -m gpu -q --durations=8 ) > $out/pytest_gpu.log 2>&1; tail -3 $out/pytest_gpu.log
 fi
 timeout 400 python bench.py > $out/bench_default.json 2> $out/bench_default.err; wc -c $out/bench_default.json
@@ -60,7 +61,7 @@ for w in cartpole mountain_car; do
   pm sq ${w}_rollout16 $out/${w}_rollout16_pmc_sq.json --kernels "small_obs_lean_rollout_kernel<${w}_env" --last 4 -- --workload $w --rollout 16 --steps 64 --warmup 16 $A $ns
   pm sq ${w}_eager $out/${w}_eager_pmc_sq.json --kernels "small_obs_kernel<${w}_env, false" "small_obs_eager2_kernel<${w}_env" -- --workload $w --steps 20 --warmup 4 $A $ns
 done
-if [ "${1:-}" != quick ]; then
+if [ "$mode" != quick ]; then
   for w in bandit discounting_chain memory_len umbrella_length umbrella_distract memory_size cartpole mountain_car catch deep_sea mnist; do
     timeout 100 python bench.py --workload $w --steps 200 --warmup 40 $A 2>/dev/null | tail -1 | python -c "
 import sys,json; d=json.loads(sys.stdin.read()); r=d['roofline']; print('%-18s eager  %.3e env-steps/s  %.2f us/step  %.0f GB/s  frac %.3f' % ('$w', d['value'], r['kernel_ms']*1e3, r['achieved'], r['frac']))"
