@@ -409,6 +409,9 @@ __global__ void __launch_bounds__(BSX_BLOCK) bsx_advance_kernel(const typename F
   __shared__ unsigned int s_cnt[2];
   bsx_advance_body<Fam, LEAN>(a, blockIdx.x, s_fam, s_cnt);
 }
+// (the WRAPPED call with two lanes per thread — Logging / RewardNoise instantiation — measured in round 6 and not kept:
+// catch_noise/0 49.4-50.0 -> 51.4-51.7 us per step, its normal draws then run twice in series; deep_sea under Logging equal;
+// profiles/r06/ab_wrapped_advance_two_lanes.log, catch_noise_kernel_stats.csv: the wrapped advance is 18.0 us, the lean one 9.1)
 template <class Fam>
 __global__ void __launch_bounds__(BSX_BLOCK) bsx_advance2_kernel(const typename Fam::args a) {     // two lanes per thread, lean
   __shared__ typename Fam::shared s_fam;
