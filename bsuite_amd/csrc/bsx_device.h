@@ -17,6 +17,22 @@
 #define BSX_WAVE 64
 
 typedef float bsx_f4 __attribute__((ext_vector_type(4)));
+typedef float bsx_f2 __attribute__((ext_vector_type(2)));
+
+// Which per-lane OUTPUT stores are non-temporal (bits; -DBSX_SMALL_NT=<n> in measurement builds, tools/ab_flag_lib.py):
+//   1  reward / discount / step_type columns (a wave's store is one contiguous 256- / 64-byte range)
+//   2  observation rows of one or two floats stored by their own thread (contiguous per wave as well)
+//   4  rows staged through a wave's LDS and stored as 16-byte chunks (full lines)
+//   8  rows of 4 / 6 / 8 floats stored by their own thread as 8-byte pieces at the row stride (partial lines)
+//  16  rows of three floats (one 12-byte store per lane, contiguous per wave)
+#ifndef BSX_SMALL_NT
+#define BSX_SMALL_NT 23        // 1 + 2 + 4 + 16: everything but the partial-line rows (small_obs.h has the measurements)
+#endif
+template <bool NT, class P, class V>
+__device__ __forceinline__ void bsx_st(P* p, V v) {
+  if (NT) __builtin_nontemporal_store((P)v, p);
+  else *p = (P)v;
+}
 
 // Per-call values every kernel needs, flattened out of bsx_call_t on the host.
 struct bsx_ctl {
@@ -212,9 +228,9 @@ __device__ __forceinline__ void bsx_emit_at(const bsx_ctl& c, const bsx_timestep
                                             uint64_t lane, uint64_t step, int type, double reward) {
   float r, d;
   bsx_emit_values<LOG, NOISE, F64, MT>(c, i, oi, lane, step, type, reward, r, d);
-  out.reward[oi] = r;
-  out.discount[oi] = d;
-  out.step_type[oi] = (int8_t)type;
+  bsx_st<(BSX_SMALL_NT & 1) != 0>(&out.reward[oi], r);
+  bsx_st<(BSX_SMALL_NT & 1) != 0>(&out.discount[oi], d);
+  bsx_st<(BSX_SMALL_NT & 1) != 0>(&out.step_type[oi], (int8_t)type);
 }
 __device__ __forceinline__ void bsx_emit(const bsx_ctl& c, const bsx_timestep_t& out, int64_t i,
                                          uint64_t lane, uint64_t step, int type, double reward) {

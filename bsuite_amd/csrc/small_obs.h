@@ -82,23 +82,47 @@ struct bsx_reset_pool {
   unsigned int n[2];                 // how many; [step parity]
 };
 
+// Non-temporal OUTPUT stores (BSX_SMALL_NT, bsx_device.h; round 6).  What a step or a rollout writes — TimeStep columns and
+// observation rows — is never read again on the device, while what it READS (actions a run ahead, state and info columns,
+// tables) is what the stores evict: the fused rollouts were bound by exactly those reads (r04: 6.5 us with, 4.8 without the
+// action loads).  With the outputs non-temporal wherever a wave's store instruction covers one contiguous range:
+// mountain_car r16 6.45 -> 4.45-4.7 us per step, memory_len r16 7.0 -> 5.2, discounting_chain r16 5.2 -> 3.8, bandit r16
+// 5.0 -> 4.0, cartpole r16 9.8 -> 7.7 (its rows leave as 16-byte chunks through the wave's LDS), eager steps -3 ... -7 %,
+// umbrella_chain equal; deep_sea / catch / mnist / the sweep equal (profiles/r06/ab_small_families_nt*.log,
+// ab_small_nt_other_paths.log).  NOT for rows written as 8-byte pieces at the row stride (cartpole's eager step: 18 -> 25 us —
+// partial lines want the L2 to merge them).  Per family: does the fused rollout store reward / discount / step_type non-temporal?
+template <class Env> struct small_rollout_nt_scalars { static constexpr bool value = true; };
+
 // A lane's own thread stores its short row (<= 8 floats).  A wave's 64 rows are one contiguous range, written by
 // back-to-back instructions that the L2 merges line by line.
 __device__ __forceinline__ void small_obs_store_row(float* __restrict__ dst, const float* o, int numel) {
   if ((numel & 1) == 0) {
-    float2* __restrict__ d2 = reinterpret_cast<float2*>(dst);
+    bsx_f2* __restrict__ d2 = reinterpret_cast<bsx_f2*>(dst);
 #pragma unroll
     for (int k = 0; k < 4; ++k)
-      if (2 * k < numel) d2[k] = make_float2(o[2 * k], o[2 * k + 1]);
+      if (2 * k < numel) {
+        bsx_f2 v; v.x = o[2 * k]; v.y = o[2 * k + 1];
+        if (numel == 2) bsx_st<(BSX_SMALL_NT & 2) != 0>(&d2[k], v);
+        else bsx_st<(BSX_SMALL_NT & 8) != 0>(&d2[k], v);
+      }
   } else if (numel == 3) {
     // one 12-byte store per lane (global_store_dwordx3): a wave's 64 rows are 768 contiguous bytes
-    struct __attribute__((packed, aligned(4))) row3 { float a, b, c; };
-    row3 v; v.a = o[0]; v.b = o[1]; v.c = o[2];
-    *reinterpret_cast<row3*>(dst) = v;
+    if (BSX_SMALL_NT & 16) {
+      typedef float row3v __attribute__((ext_vector_type(3), aligned(4)));
+      row3v v; v.x = o[0]; v.y = o[1]; v.z = o[2];
+      __builtin_nontemporal_store(v, reinterpret_cast<row3v*>(dst));
+    } else {
+      struct __attribute__((packed, aligned(4))) row3 { float a, b, c; };
+      row3 v; v.a = o[0]; v.b = o[1]; v.c = o[2];
+      *reinterpret_cast<row3*>(dst) = v;
+    }
   } else {
 #pragma unroll
     for (int k = 0; k < 7; ++k)                                   // numel == 1, 5, 7: 4-byte stores
-      if (k < numel) dst[k] = o[k];
+      if (k < numel) {
+        if (numel == 1) bsx_st<(BSX_SMALL_NT & 2) != 0>(&dst[k], o[k]);
+        else dst[k] = o[k];
+      }
   }
 }
 
@@ -143,7 +167,7 @@ __device__ __forceinline__ void small_obs_store_rows_wave(float* __restrict__ ds
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
   const int chunks = 16 * numel;                                 // 64 rows x numel floats / 4
   for (int c = wl; c < chunks; c += 64)
-    reinterpret_cast<float4*>(dst)[c] = reinterpret_cast<const float4*>(s_wave)[c];
+    bsx_st<(BSX_SMALL_NT & 4) != 0>(&reinterpret_cast<bsx_f4*>(dst)[c], reinterpret_cast<const bsx_f4*>(s_wave)[c]);
   __builtin_amdgcn_wave_barrier();                               // (the next step's rows are written after these reads)
 }
 // ... the same with the destination as {uniform slab pointer, byte offset of the wave's first row}
@@ -163,7 +187,7 @@ __device__ __forceinline__ void small_obs_store_rows_wave_off(float* slab, uint3
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
   const int chunks = 16 * numel;
   for (int c = wl; c < chunks; c += 64)
-    *bsx_at_off(reinterpret_cast<float4*>(slab), wave_off + 16u * (uint32_t)c) = reinterpret_cast<const float4*>(s_wave)[c];
+    bsx_st<(BSX_SMALL_NT & 4) != 0>(bsx_at_off(reinterpret_cast<bsx_f4*>(slab), wave_off + 16u * (uint32_t)c), reinterpret_cast<const bsx_f4*>(s_wave)[c]);
   __builtin_amdgcn_wave_barrier();
 }
 
@@ -364,9 +388,10 @@ __device__ __forceinline__ void small_obs_regs_rollout(const typename Env::args&
           if constexpr (OFF32) {
             float r, d;
             bsx_emit_values<LOG, NOISE, F64, MT>(a.ctl, i, oi, lane, step0 + (uint64_t)t, type, reward, r, d);
-            *bsx_at_off(rp, iu * 4u) = r;
-            *bsx_at_off(dp, iu * 4u) = d;
-            *bsx_at_off(sp, iu) = (int8_t)type;
+            constexpr bool NTS = (BSX_SMALL_NT & 1) != 0 && small_rollout_nt_scalars<Env>::value;
+            bsx_st<NTS>(bsx_at_off(rp, iu * 4u), r);
+            bsx_st<NTS>(bsx_at_off(dp, iu * 4u), d);
+            bsx_st<NTS>(bsx_at_off(sp, iu), (int8_t)type);
           } else {
             bsx_emit_at<LOG, NOISE, F64, MT>(a.ctl, a.out, i, oi, lane, step0 + (uint64_t)t, type, reward);
           }
@@ -1692,5 +1717,7 @@ struct mountain_car_env {
     return type;
   }
 };
+// (with its 12-byte rows non-temporal, mountain_car's rollout is faster with ORDINARY scalar stores: 4.45 against 4.7 us per step)
+template <> struct small_rollout_nt_scalars<mountain_car_env> { static constexpr bool value = false; };
 
 #endif  // BSX_SMALL_OBS_H_
