@@ -541,7 +541,23 @@ __device__ __forceinline__ void small_obs_body(const typename Env::args& a, cons
         // profiles/r03/ab_eager_rows_via_lds.log: one memory round trip per launch bounds it, not the write requests;
         // pooled resets in the eager step: 17.6 -> 19.1-19.6 us, the barriers wait for the slowest wave's loads,
         // profiles/r03/ab_eager_pooled_resets.log)
-        small_obs_store_row(a.out.observation + oi * (int64_t)numel, o, numel);
+        // Rows of 4-8 floats (cartpole, swing-up): a full wave stages its 64 rows in LDS and stores them as NON-TEMPORAL 16-byte
+        // chunks (small_obs_store_rows_wave) — row-per-lane they are 8-byte pieces at the row stride, partial lines that must
+        // not be non-temporal (18 -> 25 us), and ordinary stores evict the columns the next call reads.  Round 3 had measured the
+        // staging alone as equal (ab_eager_rows_via_lds.log); with non-temporal chunks: cartpole/0 17.4-18.7 -> 15.4-16.0 us per
+        // step at 2^20 lanes, 7.8 -> 7.2 at 2^18 (profiles/r06/ab_cartpole_eager_rows_lds_nt.log).
+        bool staged = false;
+        if constexpr (Env::HAS_REGS) {
+          if constexpr (Env::ROWS_VIA_LDS && !ROLLOUT) {
+            float* s_rows_e = s_obs;                                // dynamic LDS: small_obs_lds() reserves 256 rows x 8 floats
+            const int wl_e = (int)(threadIdx.x & 63u);
+            if (i - wl_e + 64 <= B) {                              // (uniform per wave: all 64 lanes are in range)
+              small_obs_store_rows_wave(a.out.observation + (oi - wl_e) * (int64_t)numel, o, numel, s_rows_e + (threadIdx.x - wl_e) * 8, wl_e);
+              staged = true;
+            }
+          }
+        }
+        if (!staged) small_obs_store_row(a.out.observation + oi * (int64_t)numel, o, numel);
       }
       bsx_count_types(a.ctl, type, s_cnt);
     } else {
@@ -725,6 +741,7 @@ static size_t small_obs_lds(const typename Env::args& a) {
   if constexpr (Env::PACKED)     // PLANES data planes + the HEAD-position plane + the lanes' HEAD floats (padded) + the time fractions
     return bsx_small_direct_shape(a.obs_numel) ? 0 : (size_t)(Env::PLANES + 1) * a.obs_numel * (BSX_BLOCK / 32) * 4 + (size_t)(BSX_BLOCK * Env::HEAD + 8) * 4 +
                                                      (Env::tf_table_fits(a) ? ((size_t)a.L + 1) * 4 : 0);
+  else if constexpr (Env::HAS_REGS) return Env::ROWS_VIA_LDS ? (size_t)BSX_BLOCK * 8 * 4 : 0;     // the eager step's row staging (small_obs_body, DIRECT)
   else return 0;
 }
 // does a single-step call of this segment take the row path (flat bit planes into a.rows + the wide-row store stream)?
