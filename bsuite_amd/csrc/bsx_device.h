@@ -25,8 +25,9 @@ typedef float bsx_f2 __attribute__((ext_vector_type(2)));
 //   4  rows staged through a wave's LDS and stored as 16-byte chunks (full lines)
 //   8  rows of 4 / 6 / 8 floats stored by their own thread as 8-byte pieces at the row stride (partial lines)
 //  16  rows of three floats (one 12-byte store per lane, contiguous per wave)
+//  32  the 16-byte chunks of the wide rows' LDS bit-plane tiles (memory_chain, umbrella_chain)
 #ifndef BSX_SMALL_NT
-#define BSX_SMALL_NT 23        // 1 + 2 + 4 + 16: everything but the partial-line rows (small_obs.h has the measurements)
+#define BSX_SMALL_NT 55        // 1 + 2 + 4 + 16 + 32: everything but the partial-line rows (small_obs.h has the measurements)
 #endif
 template <bool NT, class P, class V>
 __device__ __forceinline__ void bsx_st(P* p, V v) {
@@ -223,14 +224,18 @@ __device__ __forceinline__ void bsx_emit_values(const bsx_ctl& c, int64_t i, int
 
 // Writes the scalar TimeStep fields of one lane (coalesced: lane i -> element oi of each column;
 // oi == i for step(), oi == t*B + i inside a fused T-step rollout).
-template <int LOG = -1, int NOISE = -1, bool F64 = true, int MT = -1>
+// NTS: non-temporal stores (BSX_SMALL_NT bit 1) — ONLY where every lane of a wave emits, lane by lane (the small-observation
+// kernels): a wave's store is then one contiguous range.  A lone emitting thread (the writer threads of deep_sea's
+// single-launch step: one lane per 225 threads) must not — 4-byte non-temporal stores scattered over the grid took that
+// kernel from 81 to 125 us at 2^17 lanes.
+template <int LOG = -1, int NOISE = -1, bool F64 = true, int MT = -1, bool NTS = false>
 __device__ __forceinline__ void bsx_emit_at(const bsx_ctl& c, const bsx_timestep_t& out, int64_t i, int64_t oi,
                                             uint64_t lane, uint64_t step, int type, double reward) {
   float r, d;
   bsx_emit_values<LOG, NOISE, F64, MT>(c, i, oi, lane, step, type, reward, r, d);
-  bsx_st<(BSX_SMALL_NT & 1) != 0>(&out.reward[oi], r);
-  bsx_st<(BSX_SMALL_NT & 1) != 0>(&out.discount[oi], d);
-  bsx_st<(BSX_SMALL_NT & 1) != 0>(&out.step_type[oi], (int8_t)type);
+  bsx_st<NTS && (BSX_SMALL_NT & 1) != 0>(&out.reward[oi], r);
+  bsx_st<NTS && (BSX_SMALL_NT & 1) != 0>(&out.discount[oi], d);
+  bsx_st<NTS && (BSX_SMALL_NT & 1) != 0>(&out.step_type[oi], (int8_t)type);
 }
 __device__ __forceinline__ void bsx_emit(const bsx_ctl& c, const bsx_timestep_t& out, int64_t i,
                                          uint64_t lane, uint64_t step, int type, double reward) {
@@ -588,7 +593,11 @@ __global__ void __launch_bounds__(BS) bsx_hot_stream_kernel(float* __restrict__ 
 // hot cells decoded from LDS.  At 2^20 lanes the decoupled pair wins (no store waits behind a barrier: the
 // barrier'd single-kernel designs lost 15-35 % there); when the whole step is a few microseconds
 // the second launch and the state column's round trip through L2 are what is left to remove.
-template <class HotFn>
+// NT: non-temporal chunk stores — for the 64-lane tiles of small batches and for the fused rollout (catch at 2^17 lanes, a
+// rank's share of an 8-GPU run: 8.0 -> 6.8 us per step, rollout 7.2 -> 5.5; rollouts at 2^18 / 2^19 lanes equal / -4 %); the
+// 256-lane tiles of a single step at 2^18-2^19 lanes are SLOWER with them (12.3 -> 13.0, 19.3 -> 23.3) and keep ordinary
+// stores, as do the catch tiles inside the sweep's phase 0 (profiles/r06/ab_nt_wide_rows_and_small_batches.log).
+template <class HotFn, bool NT = false>
 __device__ __forceinline__ void bsx_tile_stream(float* __restrict__ tile, const int32_t* s_state, int lanes_here,
                                                 uint32_t cells, uint32_t cells_magic, const HotFn& fn) {
   const uint32_t total = (uint32_t)lanes_here * cells;                  // <= 256 * 4096 floats
@@ -616,7 +625,7 @@ __device__ __forceinline__ void bsx_tile_stream(float* __restrict__ tile, const 
       if (over <= 2) v.z = (a1 == 2 || b1 == 2) ? 1.0f : 0.0f;
       v.w = (a1 == 3 || b1 == 3) ? 1.0f : 0.0f;
     }
-    t4[c] = v;
+    bsx_st<NT>(&t4[c], v);
   }
   // ragged tail (< 4 floats): only the last, partial workgroup of an odd-sized array can have one
   const uint32_t f = (n_chunks << 2) + threadIdx.x;
@@ -679,7 +688,7 @@ __global__ void __launch_bounds__(BSX_BLOCK) bsx_fused_tile64_kernel(const typen
   }
   __syncthreads();
   const int64_t left = a.ctl.n_lanes - lane0;
-  bsx_tile_stream(obs + lane0 * (int64_t)cells, s_state, left < BSX_WAVE ? (int)left : BSX_WAVE, cells, cells_magic, fn);
+  bsx_tile_stream<HotFn, true>(obs + lane0 * (int64_t)cells, s_state, left < BSX_WAVE ? (int)left : BSX_WAVE, cells, cells_magic, fn);
 }
 
 // The same for a rollout of T steps: ONE launch.  Lanes never interact, so a workgroup can take its 256 lanes
@@ -722,7 +731,7 @@ __global__ void __launch_bounds__(BSX_BLOCK) bsx_fused_rollout_kernel(const type
     // one barrier per step: tile t is read from s_state[t & 1] after it; step t+1 writes the other buffer, and no
     // thread reaches step t+2 (which rewrites this one) before every thread has passed the barrier of step t+1
     __syncthreads();
-    bsx_tile_stream(obs + ((int64_t)t * B + lane0) * (int64_t)cells, s_state[t & 1], lanes_here, cells, cells_magic, fn);
+    bsx_tile_stream<HotFn, true>(obs + ((int64_t)t * B + lane0) * (int64_t)cells, s_state[t & 1], lanes_here, cells, cells_magic, fn);
   }
   if (mine) a.state[i] = st;
   bsx_final_barrier();

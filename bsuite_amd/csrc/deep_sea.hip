@@ -127,6 +127,7 @@ __global__ void __launch_bounds__(BSX_BLOCK) deep_sea_step1_kernel(const deep_se
     v.y = p0 == 1 ? 1.0f : 0.0f;
     v.z = p0 == 2 ? 1.0f : 0.0f;
     v.w = p0 == 3 ? 1.0f : 0.0f;
+    // (non-temporal here: 79 -> 83.5 us per step at 2^17 lanes, 157 -> 166 at 2^18: profiles/r06/ab_deep_sea_step1_nt.log)
     o4[(threadIdx.x >> 6) * (K * 64) + u * 64 + (threadIdx.x & 63)] = v;
   }
   const unsigned int n_last = (unsigned int)__popcll(__ballot(tA == BSX_LAST)) + (unsigned int)__popcll(__ballot(tB == BSX_LAST));

@@ -87,8 +87,9 @@ struct bsx_reset_pool {
 // tables) is what the stores evict: the fused rollouts were bound by exactly those reads (r04: 6.5 us with, 4.8 without the
 // action loads).  With the outputs non-temporal wherever a wave's store instruction covers one contiguous range:
 // mountain_car r16 6.45 -> 4.45-4.7 us per step, memory_len r16 7.0 -> 5.2, discounting_chain r16 5.2 -> 3.8, bandit r16
-// 5.0 -> 4.0, cartpole r16 9.8 -> 7.7 (its rows leave as 16-byte chunks through the wave's LDS), eager steps -3 ... -7 %,
-// umbrella_chain equal; deep_sea / catch / mnist / the sweep equal (profiles/r06/ab_small_families_nt*.log,
+// 5.0 -> 4.0, cartpole r16 9.8 -> 7.7 (its rows leave as 16-byte chunks through the wave's LDS), eager steps -3 ... -7 %;
+// the wide rows' tile chunks: umbrella_length eager 25.8 -> 21.7 us, r16 23.8 -> 21.4, memory_size 42.7 -> 37.4, umbrella_distract
+// 94.9 -> 91.0 (ab_nt_wide_rows_and_small_batches.log); deep_sea / catch / mnist / the sweep equal (profiles/r06/ab_small_families_nt*.log,
 // ab_small_nt_other_paths.log).  NOT for rows written as 8-byte pieces at the row stride (cartpole's eager step: 18 -> 25 us —
 // partial lines want the L2 to merge them).  Per family: does the fused rollout store reward / discount / step_type non-temporal?
 template <class Env> struct small_rollout_nt_scalars { static constexpr bool value = true; };
@@ -393,7 +394,7 @@ __device__ __forceinline__ void small_obs_regs_rollout(const typename Env::args&
             bsx_st<NTS>(bsx_at_off(dp, iu * 4u), d);
             bsx_st<NTS>(bsx_at_off(sp, iu), (int8_t)type);
           } else {
-            bsx_emit_at<LOG, NOISE, F64, MT>(a.ctl, a.out, i, oi, lane, step0 + (uint64_t)t, type, reward);
+            bsx_emit_at<LOG, NOISE, F64, MT, true>(a.ctl, a.out, i, oi, lane, step0 + (uint64_t)t, type, reward);
           }
         }
         if (rows) {
@@ -500,7 +501,7 @@ __device__ __forceinline__ void small_obs_body(const typename Env::args& a, cons
         float o[Env::HEAD];
         const bsx_bit_sink sink{wplanes, (int)wstride, (uint32_t)(wl * numel + Env::HEAD)};
         type = Env::template step<LOG, MT, true>(a, i, oi, lane, step0 + (uint64_t)t, o, reward, &sink);
-        bsx_emit_at<LOG, NOISE, F64, MT>(a.ctl, a.out, i, oi, lane, step0 + (uint64_t)t, type, reward);
+        bsx_emit_at<LOG, NOISE, F64, MT, true>(a.ctl, a.out, i, oi, lane, step0 + (uint64_t)t, type, reward);
         float* __restrict__ heads = reinterpret_cast<float*>(a.rows + (uint64_t)R::PLANES * (uint64_t)a.row_plane_words);
         uint32_t head_bits = 0u;
 #pragma unroll
@@ -535,7 +536,7 @@ __device__ __forceinline__ void small_obs_body(const typename Env::args& a, cons
         BSX_LIFE_AFTER_S(2, (uint32_t)step0);                   // the argument slot and the call counter have arrived
         type = Env::template step<LOG, MT>(a, i, oi, lane, step0 + (uint64_t)t, o, reward);
         BSX_LIFE_AFTER_V(4, type);                              // loads + arithmetic (+ the state stores issued)
-        bsx_emit_at<LOG, NOISE, F64, MT>(a.ctl, a.out, i, oi, lane, step0 + (uint64_t)t, type, reward);
+        bsx_emit_at<LOG, NOISE, F64, MT, true>(a.ctl, a.out, i, oi, lane, step0 + (uint64_t)t, type, reward);
         // (row-per-lane stores also in a big launch: staging the rows like the fused rollout does left the eager step
         // where it was — 17.5 / 17.5 vs 18.0 / 17.4 us at 2^20 lanes — and cost 4 % at 2^18,
         // profiles/r03/ab_eager_rows_via_lds.log: one memory round trip per launch bounds it, not the write requests;
@@ -594,7 +595,7 @@ __device__ __forceinline__ void small_obs_body(const typename Env::args& a, cons
         float head[HEAD];
         const bsx_bit_sink sink{planes, stride, (uint32_t)((int)threadIdx.x * numel + HEAD), s_tf};
         type = Env::template step<LOG, MT, true>(a, i, oi, lane, step0 + (uint64_t)t, head, reward, &sink);
-        bsx_emit_at<LOG, NOISE, F64, MT>(a.ctl, a.out, i, oi, lane, step0 + (uint64_t)t, type, reward);
+        bsx_emit_at<LOG, NOISE, F64, MT, true>(a.ctl, a.out, i, oi, lane, step0 + (uint64_t)t, type, reward);
 #pragma unroll
         for (int k = 0; k < HEAD; ++k) s_head[threadIdx.x * HEAD + k] = head[k];
         if (t == 0) {
@@ -642,7 +643,7 @@ __device__ __forceinline__ void small_obs_body(const typename Env::args& a, cons
           q.z = (hm & 4u) ? h2 : q.z;
           q.w = (hm & 8u) ? h3 : q.w;
         }
-        t4[ch] = q;
+        bsx_st<(BSX_SMALL_NT & 32) != 0>(&t4[ch], q);
       }
       // elements beyond the 16-byte chunks (an unaligned [t] slice, or the < 4 floats at the end of an odd tile)
       for (int f = (n_chunks << 2) + (int)threadIdx.x; f < total; f += BSX_BLOCK) {
@@ -710,7 +711,7 @@ __global__ void __launch_bounds__(BSX_BLOCK) small_obs_eager2_kernel(const typen
       double reward = 0.0;
       float o[8];
       type[h] = Env::template core<0, 0, false, false, false, V>(a, rg[h], act[h], i[h], a.ctl.lane_offset + (uint64_t)i[h], step, o, reward);
-      bsx_emit_at<0, 0, false>(a.ctl, a.out, i[h], i[h], a.ctl.lane_offset + (uint64_t)i[h], step, type[h], reward);
+      bsx_emit_at<0, 0, false, -1, true>(a.ctl, a.out, i[h], i[h], a.ctl.lane_offset + (uint64_t)i[h], step, type[h], reward);
       small_obs_store_row(a.out.observation + i[h] * (int64_t)numel, o, numel);
       Env::store(a, i[h], rg[h]);
     }
