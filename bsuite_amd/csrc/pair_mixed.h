@@ -54,6 +54,9 @@ int bsx_sweep_launch_pipelined(bsx_group* streams_of, bsx_group* advances_of, hi
 #ifndef PAIR_HOT_NT
 #define PAIR_HOT_NT true
 #endif
+// (The segments' pointers arrive through the argument table, so the compiler emits FLAT loads and stores here.  Typed as
+// global memory — global_store_dwordx4, no lgkmcnt traffic — the closed-loop sweep step is SLOWER: 159.4-161.9 us against
+// 151.2-159.5, same call, four repetitions; profiles/r06/ab_sweep_global_pointers.log.  Left as the compiler has it.)
 __device__ __forceinline__ void pair_mixed_stream_body(const uint8_t* __restrict__ table, const int32_t* __restrict__ family,
                                                        const bsx_group_index& gi, uint32_t block, float* s_lut) {
   const bsx_group_slot w = bsx_group_find(gi, (int)block);

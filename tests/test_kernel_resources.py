@@ -150,3 +150,33 @@ def test_lean_instantiations_keep_full_occupancy(kernels):
   assert len(lean) >= 8
   for k in lean:
     assert k['vgpr_count'] <= 64, (k['name'], k['vgpr_count'])
+
+
+def test_non_temporal_stores_are_where_they_were_measured_to_pay():
+  """Round 6: non-temporal stores pay where a wave's store instruction covers one contiguous range of outputs that
+  nobody reads again while the kernel's own INPUTS compete for the cache — and cost 8-40 % elsewhere.  From the ISA:
+  the stand-alone one-hot stream and deep_sea's single-launch step (scattered writer threads) have none; the sweep's mixed
+  stream, the fused rollouts' rows and cartpole's eager step (16-byte chunks through the wave's LDS) have them; cartpole never
+  stores an 8-byte row piece non-temporally (partial lines: 18 -> 25 us)."""
+  import kernel_isa as ki
+  csrc = os.path.join(ROOT, 'bsuite_amd', 'csrc')
+
+  def stores(src, want):
+    _, text = ki.kernel_text(os.path.join(csrc, src), want)
+    ins = [l.split(';')[0].strip() for l in text]
+    return [l for l in ins if l.startswith(('global_store', 'flat_store'))]
+
+  for src, want in (('deep_sea.hip', 'deep_sea_step1_kernel<4>'), ('deep_sea.hip', 'bsx_hot_stream_kernel<deep_sea_hot, 4, 256>'),
+                    ('catch.hip', 'bsx_hot_stream_kernel<catch_hot, 2, 256>'), ('deep_sea.hip', 'bsx_advance_kernel<deep_sea_fam, true>')):
+    st = stores(src, want)
+    assert st and not any(l.endswith(' nt') for l in st), (want, [l for l in st if l.endswith(' nt')])
+  st = stores('pair_mixed.hip', 'pair_mixed_stream_kernel')
+  assert sum(l.startswith('flat_store_dwordx4') and l.endswith(' nt') for l in st) >= 6          # deep_sea 4 + catch 2 chunks (flat: the pointers come from the argument table)
+  st = stores('mountain_car.hip', 'small_obs_lean_rollout_kernel<mountain_car_env, false, 0, true>')
+  assert any(l.startswith('global_store_dwordx3') and l.endswith(' nt') for l in st)
+  assert not any(l.startswith('global_store_byte') and l.endswith(' nt') for l in st)              # its scalars stay ordinary
+  st = stores('bandit.hip', 'small_obs_lean_rollout_kernel<bandit_env, false, 0, false>')
+  assert any(l.startswith('global_store_byte') and l.endswith(' nt') for l in st)
+  st = stores('cartpole.hip', 'small_obs_kernel<cartpole_env, false, 0, 0, 0, true, false>')
+  assert any(l.startswith('global_store_dwordx4') and l.endswith(' nt') for l in st)
+  assert not any(l.startswith('global_store_dwordx2') and l.endswith(' nt') for l in st)
