@@ -54,6 +54,10 @@ done
 for w in bandit discounting_chain memory_len umbrella_length mnist; do
   timeout 300 python tools/kernel_stats.py $out/${w}_kernel_stats.csv -- --workload $w --steps 200 --warmup 20 $A > /dev/null 2>>$out/kernel_stats.err
 done
+# issue-side counters of the two store streams round 6 rebuilt: the mnist observation stream and the sweep's mixed stream
+pm sq mnist_eager $out/mnist_eager_pmc_sq.json --kernels "mnist_observe_kernel" -- --workload mnist --steps 20 --warmup 4 $A
+pm sq sweep_split $out/sweep_split_pmc_sq.json --kernels sweep_pipelined_kernel --last 40 -- --workload sweep --sweep-schedule split --steps 40 --warmup 10
+pm sq deep_sea_eager $out/deep_sea_eager_pmc_sq.json --kernels "bsx_hot_stream_kernel<deep_sea_hot" -- --workload deep_sea --steps 20 --warmup 4 $A
 pm sq umbrella_length_eager $out/umbrella_length_eager_pmc_sq.json --kernels "small_obs_kernel<umbrella_chain_env" -- --workload umbrella_length --steps 20 --warmup 4 $A
 # issue-side counters of the fused rollouts (bound "valu") and of the eager physics steps
 for w in cartpole mountain_car; do
