@@ -424,11 +424,11 @@ __device__ __forceinline__ void bsx_advance_body(const typename Fam::args& a, ui
   bsx_flush_counts(a.ctl, s_cnt, block_id);
 }
 
-template <class Fam, bool LEAN = false>
+template <class Fam, bool LEAN = false, int MT = -1>
 __global__ void __launch_bounds__(BSX_BLOCK) bsx_advance_kernel(const typename Fam::args a) {
   __shared__ typename Fam::shared s_fam;
   __shared__ unsigned int s_cnt[2];
-  bsx_advance_body<Fam, LEAN>(a, blockIdx.x, s_fam, s_cnt);
+  bsx_advance_body<Fam, LEAN, MT>(a, blockIdx.x, s_fam, s_cnt);
 }
 // (the WRAPPED call with two lanes per thread — Logging / RewardNoise instantiation — measured in round 6 and not kept:
 // catch_noise/0 49.4-50.0 -> 51.4-51.7 us per step, its normal draws then run twice in series; deep_sea under Logging equal;

@@ -110,6 +110,8 @@ static inline int bsx_launch_advance(const typename Fam::args& a, hipStream_t st
     return 0;
   }
   if (lean) bsx_advance_kernel<Fam, true><<<dim3((unsigned)blocks), dim3(BSX_BLOCK), 0, st>>>(a);
+  // the wrapped call on the counter-based stream (the common one): the MT19937-exact generators compiled out
+  else if (a.ctl.mt_state == nullptr) bsx_advance_kernel<Fam, false, 0><<<dim3((unsigned)blocks), dim3(BSX_BLOCK), 0, st>>>(a);
   else bsx_advance_kernel<Fam, false><<<dim3((unsigned)blocks), dim3(BSX_BLOCK), 0, st>>>(a);
   return 0;
 }
