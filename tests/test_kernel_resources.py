@@ -29,8 +29,8 @@ BUDGET = {
     # BASELINE configs 1/2: deep_sea / catch lane advance + observation store stream (eager and pipelined rollout)
     'bsx_hot_stream_kernel<deep_sea_hot, 4, 256>': 32,
     'bsx_hot_stream_kernel<catch_hot, 2, 256>': 32,
-    'bsx_advance_kernel<deep_sea_fam, true>': 64,
-    'bsx_advance_kernel<catch_fam, true>': 32,
+    'bsx_advance_kernel<deep_sea_fam, true, -1>': 64,
+    'bsx_advance_kernel<catch_fam, true, -1>': 32,
     'bsx_pipelined_kernel<deep_sea_fam, true, deep_sea_hot, 4>': 64,
     'bsx_pipelined_kernel<catch_fam, true, catch_hot, 2>': 32,
     'bsx_fused_tile_kernel<catch_fam, true, catch_hot>': 32,
@@ -107,7 +107,7 @@ def test_last_barrier_of_a_workgroup_does_not_wait_for_its_stores():
   import kernel_isa as ki
   for src, want in (('mountain_car.hip', 'small_obs_kernel<mountain_car_env, false, 0, 0, 0, true, false>'),
                     ('cartpole.hip', 'small_obs_kernel<cartpole_env, false, 0, 0, 0, true, false>'),
-                    ('deep_sea.hip', 'bsx_advance_kernel<deep_sea_fam, true>')):
+                    ('deep_sea.hip', 'bsx_advance_kernel<deep_sea_fam, true, -1>')):
     name, text = ki.kernel_text(os.path.join(ROOT, 'bsuite_amd', 'csrc', src), want)
     ins = [l.split(';')[0].strip() for l in text if l.strip() and not l.strip().startswith((';', '.'))]
     bars = [k for k, l in enumerate(ins) if l.startswith('s_barrier')]
@@ -167,7 +167,7 @@ def test_non_temporal_stores_are_where_they_were_measured_to_pay():
     return [l for l in ins if l.startswith(('global_store', 'flat_store'))]
 
   for src, want in (('deep_sea.hip', 'deep_sea_step1_kernel<4>'), ('deep_sea.hip', 'bsx_hot_stream_kernel<deep_sea_hot, 4, 256>'),
-                    ('catch.hip', 'bsx_hot_stream_kernel<catch_hot, 2, 256>'), ('deep_sea.hip', 'bsx_advance_kernel<deep_sea_fam, true>')):
+                    ('catch.hip', 'bsx_hot_stream_kernel<catch_hot, 2, 256>'), ('deep_sea.hip', 'bsx_advance_kernel<deep_sea_fam, true, -1>')):
     st = stores(src, want)
     assert st and not any(l.endswith(' nt') for l in st), (want, [l for l in st if l.endswith(' nt')])
   st = stores('pair_mixed.hip', 'pair_mixed_stream_kernel')
