@@ -322,9 +322,10 @@ static int bsx_pair_call(const typename Fam::args& a0, const bsx_call_t* call, c
   static const int fused_cells = bsx_env_int("BSX_FUSED_TILE_MAX_CELLS", 128);
   static const int fused_step_mib = bsx_env_int("BSX_FUSED_TILE_MAX_MIB", 128);
   static const int fused_roll_mib = bsx_env_int("BSX_FUSED_ROLLOUT_MAX_MIB", 128);
-  // (64-lane tiles up to 2^17 lanes: catch 2^15 7.3 -> 5.6 us, 2^16 8.1 -> 6.0, 2^17 9.1 -> 8.0; 2^18 12.3 -> 12.7 keeps the
-  // 256-lane tiles; profiles/r04/ab_catch_fused_tile64.log)
-  static const int64_t tile64_max_lanes = bsx_env_int("BSX_FUSED_TILE64_MAX_LANES", 1 << 17);
+  // (64-lane tiles up to 2^18 lanes: catch 2^15 7.3 -> 5.6 us, 2^16 8.1 -> 6.0, 2^17 9.1 -> 8.0 (r04, ordinary stores:
+  // profiles/r04/ab_catch_fused_tile64.log; 2^18 was 12.3 -> 12.7 then); with their chunks non-temporal (round 6) 2^17 8.0 ->
+  // 6.8 and 2^18 12.2 -> 11.55, 2^19 19.3 -> 19.8: profiles/r06/ab_catch_tile64_nt_larger_batches.log)
+  static const int64_t tile64_max_lanes = bsx_env_int("BSX_FUSED_TILE64_MAX_LANES", 1 << 18);
   const int64_t step_bytes = B * (int64_t)cells * 4;
   const bool fusable = call->obs_paint == nullptr && cells >= 4u && (int)cells <= fused_cells &&
                        (((uint64_t)B * cells) & 3ull) == 0 && (reinterpret_cast<uintptr_t>(out.observation) & 15u) == 0;

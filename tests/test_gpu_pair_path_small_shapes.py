@@ -33,7 +33,7 @@ def test_pair_path_parity_at_small_shapes():
 
 @pytest.mark.timeout(900)
 def test_256_lane_fused_tiles_at_small_shapes():
-  """Up to 2^17 lanes the fused one-launch step uses 64-lane tiles (bsx_fused_tile64_kernel), so the in-process tests at
+  """Up to 2^18 lanes the fused one-launch step uses 64-lane tiles (bsx_fused_tile64_kernel), so the in-process tests at
   small shapes no longer reach the 256-lane tile kernel that 2^17 < B <= 2^19 lanes take: here they do
   (BSX_FUSED_TILE64_MAX_LANES=0 in the tuning build)."""
   from bsuite_amd import build as _build
