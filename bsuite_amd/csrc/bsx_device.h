@@ -29,11 +29,46 @@ typedef float bsx_f2 __attribute__((ext_vector_type(2)));
 #ifndef BSX_SMALL_NT
 #define BSX_SMALL_NT 55        // 1 + 2 + 4 + 16 + 32: everything but the partial-line rows (small_obs.h has the measurements)
 #endif
-template <bool NT, class P, class V>
+// Cache policy of an OUTPUT store.  PLAIN; NT = non-temporal (`nt`): the lines neither stay in L2 nor allocate in the Infinity
+// Cache; WT = write-through (`sc1`): they leave L2 for the memory side at once but DO land in the Infinity Cache.
+// Which one pays depends on who reads the output next (round 6, profiles/r06/ab_store_cache_policies.log,
+// ab_nt_outputs_closed_loop_policy.log; cartpole at 2^20 lanes, us per step: eager alone | fused rollout | closed loop with
+// a device-side linear policy reading every observation):  plain 17.6-18.1 | 9.1-9.3 | 115-116.5;  nt 15.6-16.6 | 7.5-7.8 |
+// 119.5;  sc1 16.2-16.7 | 9.3-9.8 | 114.5.  A rollout's T x B outputs have no reader inside the call: NT.  An eager step()
+// exists to be followed by an agent that READS the observation: its outputs must not be pushed past the Infinity Cache —
+// WT keeps most of the step's gain (the step's own inputs are no longer evicted from L2) and costs the reader nothing.
+enum { BSX_ST_PLAIN = 0, BSX_ST_NT = 1, BSX_ST_WT = 2 };
+// (the write-through stores are inline asm — no builtin sets sc1 alone — and end with `s_nop 1`: the compiler's hazard
+// recognizer does not look inside an asm string, and a VALU write of the data registers right behind a store of more than
+// 8 bytes is a hazard on gfx9: without it mountain_car's 12-byte rows came out corrupted on a few lanes per wave)
+#if defined(__HIP_DEVICE_COMPILE__)
+template <int BYTES> struct bsx_wt_store;
+template <> struct bsx_wt_store<1> { template <class T> __device__ static __forceinline__ void go(const void* p, T v) { uint32_t w = 0; __builtin_memcpy(&w, &v, 1); asm volatile("global_store_byte %0, %1, off sc1\n\ts_nop 1" :: "v"(p), "v"(w) : "memory"); } };
+template <> struct bsx_wt_store<4> { template <class T> __device__ static __forceinline__ void go(const void* p, T v) { uint32_t w; __builtin_memcpy(&w, &v, 4); asm volatile("global_store_dword %0, %1, off sc1\n\ts_nop 1" :: "v"(p), "v"(w) : "memory"); } };
+template <> struct bsx_wt_store<8> { template <class T> __device__ static __forceinline__ void go(const void* p, T v) { uint64_t w; __builtin_memcpy(&w, &v, 8); asm volatile("global_store_dwordx2 %0, %1, off sc1\n\ts_nop 1" :: "v"(p), "v"(w) : "memory"); } };
+template <> struct bsx_wt_store<12> { template <class T> __device__ static __forceinline__ void go(const void* p, T v) { typedef uint32_t u3 __attribute__((ext_vector_type(3))); u3 w; __builtin_memcpy(&w, &v, 12); asm volatile("global_store_dwordx3 %0, %1, off sc1\n\ts_nop 1" :: "v"(p), "v"(w) : "memory"); } };
+template <> struct bsx_wt_store<16> { template <class T> __device__ static __forceinline__ void go(const void* p, T v) { bsx_f4 w; __builtin_memcpy(&w, &v, 16); asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" :: "v"(p), "v"(w) : "memory"); } };
+#endif
+template <int POLICY, class P, class V>
 __device__ __forceinline__ void bsx_st(P* p, V v) {
-  if (NT) __builtin_nontemporal_store((P)v, p);
+#if defined(__HIP_DEVICE_COMPILE__)
+  if constexpr (POLICY == BSX_ST_NT) __builtin_nontemporal_store((P)v, p);
+  else if constexpr (POLICY == BSX_ST_WT) bsx_wt_store<sizeof(P)>::go((const void*)p, (P)v);
   else *p = (P)v;
+#else
+  *p = (P)v;
+#endif
 }
+// policy of an output kind (a bit of BSX_SMALL_NT) in a fused rollout (R) / in an eager step (E)
+#define BSX_POLICY_R(bit) ((BSX_SMALL_NT & (bit)) ? BSX_ST_NT : BSX_ST_PLAIN)
+#if defined(BSX_AB_EAGER_NT)           // measurement builds only: the eager step's outputs non-temporal as well
+#define BSX_POLICY_E(bit) ((BSX_SMALL_NT & (bit)) ? BSX_ST_NT : BSX_ST_PLAIN)
+#else
+#define BSX_POLICY_E(bit) ((BSX_SMALL_NT & (bit)) ? BSX_ST_WT : BSX_ST_PLAIN)
+#endif
+#ifndef BSX_TILE64_POLICY
+#define BSX_TILE64_POLICY BSX_ST_WT     // the 64-lane tiles of a small catch batch (an eager step: write-through)
+#endif
 
 // Per-call values every kernel needs, flattened out of bsx_call_t on the host.
 struct bsx_ctl {
@@ -224,18 +259,18 @@ __device__ __forceinline__ void bsx_emit_values(const bsx_ctl& c, int64_t i, int
 
 // Writes the scalar TimeStep fields of one lane (coalesced: lane i -> element oi of each column;
 // oi == i for step(), oi == t*B + i inside a fused T-step rollout).
-// NTS: non-temporal stores (BSX_SMALL_NT bit 1) — ONLY where every lane of a wave emits, lane by lane (the small-observation
+// POLICY: other than plain stores (BSX_SMALL_NT bit 1) ONLY where every lane of a wave emits, lane by lane (the small-observation
 // kernels): a wave's store is then one contiguous range.  A lone emitting thread (the writer threads of deep_sea's
 // single-launch step: one lane per 225 threads) must not — 4-byte non-temporal stores scattered over the grid took that
 // kernel from 81 to 125 us at 2^17 lanes.
-template <int LOG = -1, int NOISE = -1, bool F64 = true, int MT = -1, bool NTS = false>
+template <int LOG = -1, int NOISE = -1, bool F64 = true, int MT = -1, int POLICY = BSX_ST_PLAIN>
 __device__ __forceinline__ void bsx_emit_at(const bsx_ctl& c, const bsx_timestep_t& out, int64_t i, int64_t oi,
                                             uint64_t lane, uint64_t step, int type, double reward) {
   float r, d;
   bsx_emit_values<LOG, NOISE, F64, MT>(c, i, oi, lane, step, type, reward, r, d);
-  bsx_st<NTS && (BSX_SMALL_NT & 1) != 0>(&out.reward[oi], r);
-  bsx_st<NTS && (BSX_SMALL_NT & 1) != 0>(&out.discount[oi], d);
-  bsx_st<NTS && (BSX_SMALL_NT & 1) != 0>(&out.step_type[oi], (int8_t)type);
+  bsx_st<POLICY>(&out.reward[oi], r);
+  bsx_st<POLICY>(&out.discount[oi], d);
+  bsx_st<POLICY>(&out.step_type[oi], (int8_t)type);
 }
 __device__ __forceinline__ void bsx_emit(const bsx_ctl& c, const bsx_timestep_t& out, int64_t i,
                                          uint64_t lane, uint64_t step, int type, double reward) {
@@ -593,11 +628,13 @@ __global__ void __launch_bounds__(BS) bsx_hot_stream_kernel(float* __restrict__ 
 // hot cells decoded from LDS.  At 2^20 lanes the decoupled pair wins (no store waits behind a barrier: the
 // barrier'd single-kernel designs lost 15-35 % there); when the whole step is a few microseconds
 // the second launch and the state column's round trip through L2 are what is left to remove.
-// NT: non-temporal chunk stores — for the 64-lane tiles of small batches and for the fused rollout (catch at 2^17 lanes, a
-// rank's share of an 8-GPU run: 8.0 -> 6.8 us per step, rollout 7.2 -> 5.5; rollouts at 2^18 / 2^19 lanes equal / -4 %); the
-// 256-lane tiles of a single step at 2^18-2^19 lanes are SLOWER with them (12.3 -> 13.0, 19.3 -> 23.3) and keep ordinary
-// stores, as do the catch tiles inside the sweep's phase 0 (profiles/r06/ab_nt_wide_rows_and_small_batches.log).
-template <class HotFn, bool NT = false>
+// POLICY: the chunk stores' cache policy (bsx_st).  The fused rollout's tiles are non-temporal (catch at 2^17 lanes: 7.2 -> 5.5
+// us per step; 2^18 / 2^19 equal / -4 %).  The 64-lane tiles of an EAGER step of a small batch (up to 2^18 lanes) are
+// write-through: catch at 2^17 lanes 7.96 -> 6.32 us per step (non-temporal: 6.77), at 2^18 12.5 -> 10.9 (11.8), and the closed
+// loop with a device-side policy reading the boards 37.4 -> 35-36 / 46.2 -> 44.7 us (non-temporal: 48.1, WORSE than plain).
+// The 256-lane tiles at 2^18-2^19 lanes and the catch tiles inside the sweep's phase 0 keep plain stores
+// (profiles/r06/ab_nt_wide_rows_and_small_batches.log, ab_eager_output_policy.log).
+template <class HotFn, int POLICY = BSX_ST_PLAIN>
 __device__ __forceinline__ void bsx_tile_stream(float* __restrict__ tile, const int32_t* s_state, int lanes_here,
                                                 uint32_t cells, uint32_t cells_magic, const HotFn& fn) {
   const uint32_t total = (uint32_t)lanes_here * cells;                  // <= 256 * 4096 floats
@@ -625,7 +662,7 @@ __device__ __forceinline__ void bsx_tile_stream(float* __restrict__ tile, const 
       if (over <= 2) v.z = (a1 == 2 || b1 == 2) ? 1.0f : 0.0f;
       v.w = (a1 == 3 || b1 == 3) ? 1.0f : 0.0f;
     }
-    bsx_st<NT>(&t4[c], v);
+    bsx_st<POLICY>(&t4[c], v);
   }
   // ragged tail (< 4 floats): only the last, partial workgroup of an odd-sized array can have one
   const uint32_t f = (n_chunks << 2) + threadIdx.x;
@@ -688,7 +725,7 @@ __global__ void __launch_bounds__(BSX_BLOCK) bsx_fused_tile64_kernel(const typen
   }
   __syncthreads();
   const int64_t left = a.ctl.n_lanes - lane0;
-  bsx_tile_stream<HotFn, true>(obs + lane0 * (int64_t)cells, s_state, left < BSX_WAVE ? (int)left : BSX_WAVE, cells, cells_magic, fn);
+  bsx_tile_stream<HotFn, BSX_TILE64_POLICY>(obs + lane0 * (int64_t)cells, s_state, left < BSX_WAVE ? (int)left : BSX_WAVE, cells, cells_magic, fn);
 }
 
 // The same for a rollout of T steps: ONE launch.  Lanes never interact, so a workgroup can take its 256 lanes
@@ -731,7 +768,7 @@ __global__ void __launch_bounds__(BSX_BLOCK) bsx_fused_rollout_kernel(const type
     // one barrier per step: tile t is read from s_state[t & 1] after it; step t+1 writes the other buffer, and no
     // thread reaches step t+2 (which rewrites this one) before every thread has passed the barrier of step t+1
     __syncthreads();
-    bsx_tile_stream<HotFn, true>(obs + ((int64_t)t * B + lane0) * (int64_t)cells, s_state[t & 1], lanes_here, cells, cells_magic, fn);
+    bsx_tile_stream<HotFn, BSX_ST_NT>(obs + ((int64_t)t * B + lane0) * (int64_t)cells, s_state[t & 1], lanes_here, cells, cells_magic, fn);
   }
   if (mine) a.state[i] = st;
   bsx_final_barrier();

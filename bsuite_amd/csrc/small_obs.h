@@ -96,32 +96,34 @@ template <class Env> struct small_rollout_nt_scalars { static constexpr bool val
 
 // A lane's own thread stores its short row (<= 8 floats).  A wave's 64 rows are one contiguous range, written by
 // back-to-back instructions that the L2 merges line by line.
+template <bool ROLLOUT_ST>
 __device__ __forceinline__ void small_obs_store_row(float* __restrict__ dst, const float* o, int numel) {
+  constexpr int P2 = ROLLOUT_ST ? BSX_POLICY_R(2) : BSX_POLICY_E(2), P8 = ROLLOUT_ST ? BSX_POLICY_R(8) : BSX_POLICY_E(8);
   if ((numel & 1) == 0) {
     bsx_f2* __restrict__ d2 = reinterpret_cast<bsx_f2*>(dst);
 #pragma unroll
     for (int k = 0; k < 4; ++k)
       if (2 * k < numel) {
         bsx_f2 v; v.x = o[2 * k]; v.y = o[2 * k + 1];
-        if (numel == 2) bsx_st<(BSX_SMALL_NT & 2) != 0>(&d2[k], v);
-        else bsx_st<(BSX_SMALL_NT & 8) != 0>(&d2[k], v);
+        if (numel == 2) bsx_st<P2>(&d2[k], v);
+        else bsx_st<P8>(&d2[k], v);
       }
   } else if (numel == 3) {
     // one 12-byte store per lane (global_store_dwordx3): a wave's 64 rows are 768 contiguous bytes
-    if (BSX_SMALL_NT & 16) {
+    if (ROLLOUT_ST && (BSX_SMALL_NT & 16)) {
       typedef float row3v __attribute__((ext_vector_type(3), aligned(4)));
       row3v v; v.x = o[0]; v.y = o[1]; v.z = o[2];
       __builtin_nontemporal_store(v, reinterpret_cast<row3v*>(dst));
     } else {
       struct __attribute__((packed, aligned(4))) row3 { float a, b, c; };
       row3 v; v.a = o[0]; v.b = o[1]; v.c = o[2];
-      *reinterpret_cast<row3*>(dst) = v;
+      bsx_st<(ROLLOUT_ST ? BSX_ST_PLAIN : BSX_POLICY_E(16))>(reinterpret_cast<row3*>(dst), v);
     }
   } else {
 #pragma unroll
     for (int k = 0; k < 7; ++k)                                   // numel == 1, 5, 7: 4-byte stores
       if (k < numel) {
-        if (numel == 1) bsx_st<(BSX_SMALL_NT & 2) != 0>(&dst[k], o[k]);
+        if (numel == 1) bsx_st<P2>(&dst[k], o[k]);
         else dst[k] = o[k];
       }
   }
@@ -152,6 +154,7 @@ __device__ __forceinline__ const BSX_GLOBAL T* bsx_at_off(const T* base, uint32_
 // families turned out to be bound by exactly that (profiles/r03/exp_store_ablation.log: without the row stores
 // cartpole's step takes 8.1 us instead of 13.3).  No workgroup barrier: LDS serves a wave's accesses in order.
 // dst = row of the wave's first lane (16-byte aligned: the caller checks), s_wave = 64 * 8 floats, wl = lane in the wave.
+template <bool ROLLOUT_ST>
 __device__ __forceinline__ void small_obs_store_rows_wave(float* __restrict__ dst, const float* o, int numel, float* s_wave, int wl) {
   float* mine = s_wave + wl * numel;
   if ((numel & 1) == 0) {
@@ -168,7 +171,7 @@ __device__ __forceinline__ void small_obs_store_rows_wave(float* __restrict__ ds
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
   const int chunks = 16 * numel;                                 // 64 rows x numel floats / 4
   for (int c = wl; c < chunks; c += 64)
-    bsx_st<(BSX_SMALL_NT & 4) != 0>(&reinterpret_cast<bsx_f4*>(dst)[c], reinterpret_cast<const bsx_f4*>(s_wave)[c]);
+    bsx_st<(ROLLOUT_ST ? BSX_POLICY_R(4) : BSX_POLICY_E(4))>(&reinterpret_cast<bsx_f4*>(dst)[c], reinterpret_cast<const bsx_f4*>(s_wave)[c]);
   __builtin_amdgcn_wave_barrier();                               // (the next step's rows are written after these reads)
 }
 // ... the same with the destination as {uniform slab pointer, byte offset of the wave's first row}
@@ -188,7 +191,7 @@ __device__ __forceinline__ void small_obs_store_rows_wave_off(float* slab, uint3
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
   const int chunks = 16 * numel;
   for (int c = wl; c < chunks; c += 64)
-    bsx_st<(BSX_SMALL_NT & 4) != 0>(bsx_at_off(reinterpret_cast<bsx_f4*>(slab), wave_off + 16u * (uint32_t)c), reinterpret_cast<const bsx_f4*>(s_wave)[c]);
+    bsx_st<BSX_POLICY_R(4)>(bsx_at_off(reinterpret_cast<bsx_f4*>(slab), wave_off + 16u * (uint32_t)c), reinterpret_cast<const bsx_f4*>(s_wave)[c]);
   __builtin_amdgcn_wave_barrier();
 }
 
@@ -389,21 +392,21 @@ __device__ __forceinline__ void small_obs_regs_rollout(const typename Env::args&
           if constexpr (OFF32) {
             float r, d;
             bsx_emit_values<LOG, NOISE, F64, MT>(a.ctl, i, oi, lane, step0 + (uint64_t)t, type, reward, r, d);
-            constexpr bool NTS = (BSX_SMALL_NT & 1) != 0 && small_rollout_nt_scalars<Env>::value;
+            constexpr int NTS = small_rollout_nt_scalars<Env>::value ? BSX_POLICY_R(1) : BSX_ST_PLAIN;
             bsx_st<NTS>(bsx_at_off(rp, iu * 4u), r);
             bsx_st<NTS>(bsx_at_off(dp, iu * 4u), d);
             bsx_st<NTS>(bsx_at_off(sp, iu), (int8_t)type);
           } else {
-            bsx_emit_at<LOG, NOISE, F64, MT, true>(a.ctl, a.out, i, oi, lane, step0 + (uint64_t)t, type, reward);
+            bsx_emit_at<LOG, NOISE, F64, MT, BSX_POLICY_R(1)>(a.ctl, a.out, i, oi, lane, step0 + (uint64_t)t, type, reward);
           }
         }
         if (rows) {
           if constexpr (OFF32) {
             if (rows_via_lds) small_obs_store_rows_wave_off(op, (iu - (uint32_t)wl) * (uint32_t)(numel * 4), o, numel, s_rows + (threadIdx.x - wl) * 8, wl);
-            else small_obs_store_row(bsx_at_off(op, iu * (uint32_t)(numel * 4)), o, numel);
+            else small_obs_store_row<true>(bsx_at_off(op, iu * (uint32_t)(numel * 4)), o, numel);
           } else {
-            if (rows_via_lds) small_obs_store_rows_wave(a.out.observation + (oi - wl) * (int64_t)numel, o, numel, s_rows + (threadIdx.x - wl) * 8, wl);
-            else small_obs_store_row(a.out.observation + oi * (int64_t)numel, o, numel);
+            if (rows_via_lds) small_obs_store_rows_wave<true>(a.out.observation + (oi - wl) * (int64_t)numel, o, numel, s_rows + (threadIdx.x - wl) * 8, wl);
+            else small_obs_store_row<true>(a.out.observation + oi * (int64_t)numel, o, numel);
           }
         }
       }
@@ -501,7 +504,7 @@ __device__ __forceinline__ void small_obs_body(const typename Env::args& a, cons
         float o[Env::HEAD];
         const bsx_bit_sink sink{wplanes, (int)wstride, (uint32_t)(wl * numel + Env::HEAD)};
         type = Env::template step<LOG, MT, true>(a, i, oi, lane, step0 + (uint64_t)t, o, reward, &sink);
-        bsx_emit_at<LOG, NOISE, F64, MT, true>(a.ctl, a.out, i, oi, lane, step0 + (uint64_t)t, type, reward);
+        bsx_emit_at<LOG, NOISE, F64, MT, (ROLLOUT ? BSX_POLICY_R(1) : BSX_POLICY_E(1))>(a.ctl, a.out, i, oi, lane, step0 + (uint64_t)t, type, reward);
         float* __restrict__ heads = reinterpret_cast<float*>(a.rows + (uint64_t)R::PLANES * (uint64_t)a.row_plane_words);
         uint32_t head_bits = 0u;
 #pragma unroll
@@ -536,7 +539,7 @@ __device__ __forceinline__ void small_obs_body(const typename Env::args& a, cons
         BSX_LIFE_AFTER_S(2, (uint32_t)step0);                   // the argument slot and the call counter have arrived
         type = Env::template step<LOG, MT>(a, i, oi, lane, step0 + (uint64_t)t, o, reward);
         BSX_LIFE_AFTER_V(4, type);                              // loads + arithmetic (+ the state stores issued)
-        bsx_emit_at<LOG, NOISE, F64, MT, true>(a.ctl, a.out, i, oi, lane, step0 + (uint64_t)t, type, reward);
+        bsx_emit_at<LOG, NOISE, F64, MT, (ROLLOUT ? BSX_POLICY_R(1) : BSX_POLICY_E(1))>(a.ctl, a.out, i, oi, lane, step0 + (uint64_t)t, type, reward);
         // (row-per-lane stores also in a big launch: staging the rows like the fused rollout does left the eager step
         // where it was — 17.5 / 17.5 vs 18.0 / 17.4 us at 2^20 lanes — and cost 4 % at 2^18,
         // profiles/r03/ab_eager_rows_via_lds.log: one memory round trip per launch bounds it, not the write requests;
@@ -553,12 +556,12 @@ __device__ __forceinline__ void small_obs_body(const typename Env::args& a, cons
             float* s_rows_e = s_obs;                                // dynamic LDS: small_obs_lds() reserves 256 rows x 8 floats
             const int wl_e = (int)(threadIdx.x & 63u);
             if (i - wl_e + 64 <= B) {                              // (uniform per wave: all 64 lanes are in range)
-              small_obs_store_rows_wave(a.out.observation + (oi - wl_e) * (int64_t)numel, o, numel, s_rows_e + (threadIdx.x - wl_e) * 8, wl_e);
+              small_obs_store_rows_wave<false>(a.out.observation + (oi - wl_e) * (int64_t)numel, o, numel, s_rows_e + (threadIdx.x - wl_e) * 8, wl_e);
               staged = true;
             }
           }
         }
-        if (!staged) small_obs_store_row(a.out.observation + oi * (int64_t)numel, o, numel);
+        if (!staged) small_obs_store_row<ROLLOUT>(a.out.observation + oi * (int64_t)numel, o, numel);
       }
       bsx_count_types(a.ctl, type, s_cnt);
     } else {
@@ -595,7 +598,7 @@ __device__ __forceinline__ void small_obs_body(const typename Env::args& a, cons
         float head[HEAD];
         const bsx_bit_sink sink{planes, stride, (uint32_t)((int)threadIdx.x * numel + HEAD), s_tf};
         type = Env::template step<LOG, MT, true>(a, i, oi, lane, step0 + (uint64_t)t, head, reward, &sink);
-        bsx_emit_at<LOG, NOISE, F64, MT, true>(a.ctl, a.out, i, oi, lane, step0 + (uint64_t)t, type, reward);
+        bsx_emit_at<LOG, NOISE, F64, MT, (ROLLOUT ? BSX_POLICY_R(1) : BSX_POLICY_E(1))>(a.ctl, a.out, i, oi, lane, step0 + (uint64_t)t, type, reward);
 #pragma unroll
         for (int k = 0; k < HEAD; ++k) s_head[threadIdx.x * HEAD + k] = head[k];
         if (t == 0) {
@@ -643,7 +646,7 @@ __device__ __forceinline__ void small_obs_body(const typename Env::args& a, cons
           q.z = (hm & 4u) ? h2 : q.z;
           q.w = (hm & 8u) ? h3 : q.w;
         }
-        bsx_st<(BSX_SMALL_NT & 32) != 0>(&t4[ch], q);
+        bsx_st<(ROLLOUT ? BSX_POLICY_R(32) : BSX_POLICY_E(32))>(&t4[ch], q);
       }
       // elements beyond the 16-byte chunks (an unaligned [t] slice, or the < 4 floats at the end of an odd tile)
       for (int f = (n_chunks << 2) + (int)threadIdx.x; f < total; f += BSX_BLOCK) {
@@ -711,8 +714,8 @@ __global__ void __launch_bounds__(BSX_BLOCK) small_obs_eager2_kernel(const typen
       double reward = 0.0;
       float o[8];
       type[h] = Env::template core<0, 0, false, false, false, V>(a, rg[h], act[h], i[h], a.ctl.lane_offset + (uint64_t)i[h], step, o, reward);
-      bsx_emit_at<0, 0, false, -1, true>(a.ctl, a.out, i[h], i[h], a.ctl.lane_offset + (uint64_t)i[h], step, type[h], reward);
-      small_obs_store_row(a.out.observation + i[h] * (int64_t)numel, o, numel);
+      bsx_emit_at<0, 0, false, -1, BSX_POLICY_E(1)>(a.ctl, a.out, i[h], i[h], a.ctl.lane_offset + (uint64_t)i[h], step, type[h], reward);
+      small_obs_store_row<false>(a.out.observation + i[h] * (int64_t)numel, o, numel);
       Env::store(a, i[h], rg[h]);
     }
     bsx_count_types(a.ctl, type[h], s_cnt);

@@ -177,6 +177,9 @@ def test_non_temporal_stores_are_where_they_were_measured_to_pay():
   assert not any(l.startswith('global_store_byte') and l.endswith(' nt') for l in st)              # its scalars stay ordinary
   st = stores('bandit.hip', 'small_obs_lean_rollout_kernel<bandit_env, false, 0, false>')
   assert any(l.startswith('global_store_byte') and l.endswith(' nt') for l in st)
+  # an EAGER step's outputs are write-through (sc1: an agent reads them next), never non-temporal
   st = stores('cartpole.hip', 'small_obs_kernel<cartpole_env, false, 0, 0, 0, true, false>')
-  assert any(l.startswith('global_store_dwordx4') and l.endswith(' nt') for l in st)
-  assert not any(l.startswith('global_store_dwordx2') and l.endswith(' nt') for l in st)
+  assert any(l.startswith('global_store_dwordx4') and l.endswith(' sc1') for l in st)
+  assert not any(l.endswith(' nt') for l in st)
+  st = stores('bandit.hip', 'small_obs_eager2_kernel<bandit_env, 0, 2>')
+  assert any(l.endswith(' sc1') for l in st) and not any(l.endswith(' nt') for l in st)
