@@ -19,7 +19,8 @@
 typedef float bsx_f4 __attribute__((ext_vector_type(4)));
 typedef float bsx_f2 __attribute__((ext_vector_type(2)));
 
-// Which per-lane OUTPUT stores are non-temporal (bits; -DBSX_SMALL_NT=<n> in measurement builds, tools/ab_flag_lib.py):
+// Which per-lane OUTPUT stores take a cache policy other than plain — non-temporal in a fused rollout, write-through in an
+// eager step (bsx_st below) — as bits (-DBSX_SMALL_NT=<n> in measurement builds, tools/ab_flag_lib.py):
 //   1  reward / discount / step_type columns (a wave's store is one contiguous 256- / 64-byte range)
 //   2  observation rows of one or two floats stored by their own thread (contiguous per wave as well)
 //   4  rows staged through a wave's LDS and stored as 16-byte chunks (full lines)

@@ -82,16 +82,20 @@ struct bsx_reset_pool {
   unsigned int n[2];                 // how many; [step parity]
 };
 
-// Non-temporal OUTPUT stores (BSX_SMALL_NT, bsx_device.h; round 6).  What a step or a rollout writes — TimeStep columns and
-// observation rows — is never read again on the device, while what it READS (actions a run ahead, state and info columns,
-// tables) is what the stores evict: the fused rollouts were bound by exactly those reads (r04: 6.5 us with, 4.8 without the
-// action loads).  With the outputs non-temporal wherever a wave's store instruction covers one contiguous range:
-// mountain_car r16 6.45 -> 4.45-4.7 us per step, memory_len r16 7.0 -> 5.2, discounting_chain r16 5.2 -> 3.8, bandit r16
-// 5.0 -> 4.0, cartpole r16 9.8 -> 7.7 (its rows leave as 16-byte chunks through the wave's LDS), eager steps -3 ... -7 %;
-// the wide rows' tile chunks: umbrella_length eager 25.8 -> 21.7 us, r16 23.8 -> 21.4, memory_size 42.7 -> 37.4, umbrella_distract
-// 94.9 -> 91.0 (ab_nt_wide_rows_and_small_batches.log); deep_sea / catch / mnist / the sweep equal (profiles/r06/ab_small_families_nt*.log,
-// ab_small_nt_other_paths.log).  NOT for rows written as 8-byte pieces at the row stride (cartpole's eager step: 18 -> 25 us —
-// partial lines want the L2 to merge them).  Per family: does the fused rollout store reward / discount / step_type non-temporal?
+// The cache policy of the OUTPUT stores (bsx_st<POLICY>, BSX_SMALL_NT: bsx_device.h; round 6).  What a step or a rollout writes —
+// TimeStep columns and observation rows — is never read again by the engine, while what it READS (actions a run ahead, state
+// and info columns, tables) is what the stores evict: the fused rollouts were bound by exactly those reads (r04: 6.5 us with,
+// 4.8 without the action loads).  A FUSED ROLLOUT's outputs are NON-TEMPORAL wherever a wave's store instruction covers one
+// contiguous range: mountain_car r16 6.45 -> 4.45-4.7 us per step, memory_len r16 7.0 -> 5.2, discounting_chain r16 5.2 ->
+// 3.8, bandit r16 5.0 -> 4.0, cartpole r16 9.8 -> 7.7 (its rows leave as 16-byte chunks through the wave's LDS), umbrella_length
+// r16 23.8 -> 21.4 (profiles/r06/ab_small_families_nt*.log, ab_nt_wide_rows_and_small_batches.log).  An EAGER step's outputs are
+// WRITE-THROUGH: non-temporal ones make the step itself faster still (umbrella_length 25.8 -> 21.7 us, mountain_car 8.2 -> 7.3)
+// but cost the agent that reads the observation next more than that (ab_nt_outputs_closed_loop_policy.log); write-through:
+// cartpole 17.7 -> 15.8 us, discounting_chain 7.05 -> 6.05, memory_len 10.0 -> 9.25, bandit 8.46 -> 7.96, the closed loop equal or
+// faster everywhere (ab_eager_output_policy.log).  NEITHER for rows written as 8-byte pieces at the row stride (cartpole
+// row-per-lane: 18 -> 25 us non-temporal — partial lines want the L2 to merge them).  deep_sea / catch / mnist / the sweep are
+// not touched by this (ab_small_nt_other_paths.log).  Per family: does the fused rollout store reward / discount / step_type
+// non-temporal?
 template <class Env> struct small_rollout_nt_scalars { static constexpr bool value = true; };
 
 // A lane's own thread stores its short row (<= 8 floats).  A wave's 64 rows are one contiguous range, written by
