@@ -633,8 +633,8 @@ __global__ void __launch_bounds__(BS) bsx_hot_stream_kernel(float* __restrict__ 
 // us per step; 2^18 / 2^19 equal / -4 %).  The 64-lane tiles of an EAGER step of a small batch (up to 2^18 lanes) are
 // write-through: catch at 2^17 lanes 7.96 -> 6.32 us per step (non-temporal: 6.77), at 2^18 12.5 -> 10.9 (11.8), and the closed
 // loop with a device-side policy reading the boards 37.4 -> 35-36 / 46.2 -> 44.7 us (non-temporal: 48.1, WORSE than plain).
-// The 256-lane tiles at 2^18-2^19 lanes and the catch tiles inside the sweep's phase 0 keep plain stores
-// (profiles/r06/ab_nt_wide_rows_and_small_batches.log, ab_eager_output_policy.log).
+// The 256-lane tiles of an eager step (2^19 lanes) are write-through too: 19.4 -> 18.6 us, closed loop 78.9 -> 77.7 (non-temporal:
+// 23.3).  (profiles/r06/ab_nt_wide_rows_and_small_batches.log, ab_eager_output_policy.log, ab_catch_tile256_write_through.log)
 template <class HotFn, int POLICY = BSX_ST_PLAIN>
 __device__ __forceinline__ void bsx_tile_stream(float* __restrict__ tile, const int32_t* s_state, int lanes_here,
                                                 uint32_t cells, uint32_t cells_magic, const HotFn& fn) {
@@ -686,7 +686,7 @@ __global__ void __launch_bounds__(BSX_BLOCK) bsx_fused_tile_kernel(const typenam
   bsx_advance_body<Fam, LEAN>(a, blockIdx.x, s_fam, s_cnt, s_state);    // ends with a barrier: s_state is complete
   const int64_t lane0 = (int64_t)blockIdx.x * BSX_BLOCK;
   const int64_t left = a.ctl.n_lanes - lane0;
-  bsx_tile_stream(obs + lane0 * (int64_t)cells, s_state, left < BSX_BLOCK ? (int)left : BSX_BLOCK, cells, cells_magic, fn);
+  bsx_tile_stream<HotFn, BSX_ST_WT>(obs + lane0 * (int64_t)cells, s_state, left < BSX_BLOCK ? (int)left : BSX_BLOCK, cells, cells_magic, fn);
 }
 
 // ... with 64-lane tiles: wave 0 advances the workgroup's 64 lanes, all four waves stream their [64 x cells] boards.  A

@@ -78,7 +78,9 @@ __device__ __forceinline__ void sweep_phase0_body(const uint8_t* __restrict__ ta
       if (tile != nullptr) {                   // (the advance ended with a barrier: the tile's states are complete)
         const int64_t lane0 = (int64_t)blk * BSX_BLOCK, left = a.ctl.n_lanes - lane0;
         const uint32_t cells = (uint32_t)(a.rows * a.columns);
-        bsx_tile_stream(a.out.observation + lane0 * (int64_t)cells, tile, left < BSX_BLOCK ? (int)left : BSX_BLOCK, cells,
+        // (write-through chunks like every eager output: the closed schedule 168-171 -> 166.5-168.4 us per sweep step, split and
+        // pipelined within noise; profiles/r06/ab_catch_tile256_write_through.log)
+        bsx_tile_stream<catch_hot, BSX_ST_WT>(a.out.observation + lane0 * (int64_t)cells, tile, left < BSX_BLOCK ? (int)left : BSX_BLOCK, cells,
                         a.tile_cells_magic, catch_hot{a.rows, a.columns});
       }
       break;
