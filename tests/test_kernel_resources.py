@@ -183,3 +183,11 @@ def test_non_temporal_stores_are_where_they_were_measured_to_pay():
   assert not any(l.endswith(' nt') for l in st)
   st = stores('bandit.hip', 'small_obs_eager2_kernel<bandit_env, 0, 2>')
   assert any(l.endswith(' sc1') for l in st) and not any(l.endswith(' nt') for l in st)
+  # catch's single-launch steps (64- and 256-lane tiles): write-through observation chunks; its fused rollout: non-temporal
+  for want in ('bsx_fused_tile_kernel<catch_fam, true, catch_hot>', 'bsx_fused_tile64_kernel<catch_fam, true, catch_hot>'):
+    st = stores('catch.hip', want)
+    assert any(l.startswith('global_store_dwordx4') and l.endswith(' sc1') for l in st) and not any(l.endswith(' nt') for l in st), want
+  st = stores('catch.hip', 'bsx_fused_rollout_kernel<catch_fam, true, catch_hot>')
+  assert any(l.startswith('global_store_dwordx4') and l.endswith(' nt') for l in st)
+  st = stores('sweep_mixed.hip', 'sweep_phase0_kernel')
+  assert any(l.endswith(' sc1') for l in st)                                                        # the sweep's catch tiles
