@@ -90,6 +90,42 @@ def test_catch_full_batch():
   assert float((ball_cols - 0.2).abs().max()) < 0.005                      # randint(5) is uniform
 
 
+@pytest.mark.parametrize('form', ['eager', 'rollout', 'eager_logging'])
+def test_catch_wrapped_full_batch(form):
+  """catch_noise at B = 2^20: a WRAPPED step (RewardNoise; with the Logging bookkeeping in `eager_logging`) is ONE fused launch up to
+  this size since round 6 (bsx_host.h: BSX_FUSED_WRAPPED_MAX_MIB), where the lean step is the decoupled pair — a 4096-lane
+  subsample against the oracle bit for bit on every step (f64 noise draws included), one-hot invariants on all lanes."""
+  T, seed, sigma = 24, 11, 0.3
+  env = eu.make_env('catch', dict(), batch=B, lane_offset=0, seed=seed, wrap=('noise', sigma), num_buffers=1)
+  if form == 'eager_logging':
+    from bsuite_amd.utils import wrappers
+    env = wrappers.Logging(env, None)
+  rng = np.random.default_rng(4)
+  idx = _subsample(rng)
+  idx_t = torch.from_numpy(idx).cuda()
+  orc = coracle.OracleEnv('catch', dict(), idx.astype(np.uint64), seed=seed, wrap=('noise', sigma))
+  g = torch.Generator(device='cuda'); g.manual_seed(6)
+  actions = torch.randint(3, (T, B), generator=g, device='cuda', dtype=torch.int32)
+  if form == 'rollout':
+    out = env.rollout(actions)
+    steps = [type(out)(out.step_type[t], out.reward[t], out.discount[t], out.observation[t]) for t in range(T)]
+  else:
+    steps = None
+  for t in range(T):
+    ts = steps[t] if steps is not None else env.step(actions[t])
+    obs = ts.observation.view(B, 50)
+    s = obs.sum(dim=1)
+    assert bool(((s == 1) | (s == 2)).all()) and bool(((obs == 0) | (obs == 1)).all())
+    ost, orr, od, oo = orc.call(actions[t][idx_t].cpu().numpy(), t)
+    np.testing.assert_array_equal(ts.step_type[idx_t].cpu().numpy(), ost)
+    np.testing.assert_array_equal(ts.observation[idx_t].cpu().numpy(), oo)
+    live = ost != 0
+    np.testing.assert_array_equal(eu.f32_bits(ts.reward[idx_t].cpu().numpy()[live]), eu.f32_bits(orr[live].astype(np.float32)))
+    np.testing.assert_array_equal(ts.discount[idx_t].cpu().numpy()[live], od[live].astype(np.float32))
+  regret = eu.raw(env).bsuite_info()['total_regret']
+  np.testing.assert_array_equal(regret[idx_t].cpu().numpy(), orc.bsuite_info()['total_regret'])
+
+
 def test_physics_full_batch_one_step_teacher_forced():
   """cartpole + mountain_car at B=2^20 (BASELINE config 4): one teacher-forced step on all lanes vs the oracle."""
   for family, kwargs in (('cartpole', {}), ('mountain_car', {})):
