@@ -329,12 +329,13 @@ static int bsx_pair_call(const typename Fam::args& a0, const bsx_call_t* call, c
   const int64_t step_bytes = B * (int64_t)cells * 4;
   const bool fusable = call->obs_paint == nullptr && cells >= 4u && (int)cells <= fused_cells &&
                        (((uint64_t)B * cells) & 3ull) == 0 && (reinterpret_cast<uintptr_t>(out.observation) & 15u) == 0;
-  // A WRAPPED step (RewardNoise / Logging / MT19937-exact draws: catch_noise's lane advance is 18 us against the lean 9) fuses up
-  // to 256 MiB, i.e. catch at 2^20 lanes too: inside the one launch the heavy advance of a tile hides among the other workgroups'
-  // tile stores, in front of a stand-alone stream it does not — catch_noise/0 at 2^20 lanes 48.3-48.6 -> 42.8-43.2 us per step,
-  // rollout r32 49.0-49.5 -> 44.6-45.6, r8 48.9-49.8 -> 41.7-42.4 (profiles/r06/ab_catch_noise_fused_at_2p20.log; the lean step
-  // in the same call: 41.0 -> 43.8, ab_catch_fused_at_2p20.log)
-  static const int fused_wrapped_mib = bsx_env_int("BSX_FUSED_WRAPPED_MAX_MIB", 256);
+  // A WRAPPED step (RewardNoise / Logging / MT19937-exact draws: catch_noise's lane advance is 18 us against the lean 9) fuses at
+  // EVERY batch size: inside the one launch the heavy advance of a tile hides among the other workgroups' tile stores, in front
+  // of a stand-alone stream it does not — catch_noise/0 at 2^20 lanes 48.3-48.6 -> 42.8-43.2 us per step, rollout r32 49.0-49.5
+  // -> 44.6-45.6, r8 48.9-49.8 -> 41.7-42.4 (profiles/r06/ab_catch_noise_fused_at_2p20.log; the lean step in the same call:
+  // 41.0 -> 43.8, ab_catch_fused_at_2p20.log); 1.5 * 2^20 lanes 69.1-70.5 -> 63.5-64.1, 2^21 91.6-92.7 -> 82.9-83.5, 2^22
+  // 200.6-202.1 -> 170.8-171.3 (ab_catch_wrapped_fused_larger.log).  (MiB; 2^20 = no limit in practice)
+  static const int fused_wrapped_mib = bsx_env_int("BSX_FUSED_WRAPPED_MAX_MIB", 1 << 20);
   const bool lean_f = bsx_ctl_lean(a0.ctl);
   int fused_mib = T > 1 ? fused_roll_mib : fused_step_mib;
   if (!lean_f && fused_wrapped_mib > fused_mib) fused_mib = fused_wrapped_mib;

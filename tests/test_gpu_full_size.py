@@ -126,6 +126,28 @@ def test_catch_wrapped_full_batch(form):
   np.testing.assert_array_equal(regret[idx_t].cpu().numpy(), orc.bsuite_info()['total_regret'])
 
 
+def test_catch_wrapped_beyond_the_benched_batch():
+  """A wrapped catch step is the fused launch at EVERY batch size (the lean one only up to 128 MiB of observations): a ragged
+  2^21 + 257 lanes (420 MB per step), a subsample that includes the last, partial tile, against the oracle bit for bit."""
+  n, T, seed, sigma = (1 << 21) + 257, 8, 13, 0.1
+  env = eu.make_env('catch', dict(), batch=n, lane_offset=0, seed=seed, wrap=('noise', sigma), num_buffers=1)
+  rng = np.random.default_rng(8)
+  idx = np.unique(np.concatenate([rng.integers(0, n, size=4096), [0, 255, 256, (1 << 20) - 1, 1 << 20, (1 << 21) - 1, 1 << 21, n - 2, n - 1]])).astype(np.int64)
+  idx_t = torch.from_numpy(idx).cuda()
+  orc = coracle.OracleEnv('catch', dict(), idx.astype(np.uint64), seed=seed, wrap=('noise', sigma))
+  g = torch.Generator(device='cuda'); g.manual_seed(9)
+  for t in range(T):
+    a = torch.randint(3, (n,), generator=g, device='cuda', dtype=torch.int32)
+    ts = env.step(a)
+    s = ts.observation.view(n, 50).sum(dim=1)
+    assert bool(((s == 1) | (s == 2)).all())
+    ost, orr, od, oo = orc.call(a[idx_t].cpu().numpy(), t)
+    np.testing.assert_array_equal(ts.step_type[idx_t].cpu().numpy(), ost)
+    np.testing.assert_array_equal(ts.observation[idx_t].cpu().numpy(), oo)
+    live = ost != 0
+    np.testing.assert_array_equal(eu.f32_bits(ts.reward[idx_t].cpu().numpy()[live]), eu.f32_bits(orr[live].astype(np.float32)))
+
+
 def test_physics_full_batch_one_step_teacher_forced():
   """cartpole + mountain_car at B=2^20 (BASELINE config 4): one teacher-forced step on all lanes vs the oracle."""
   for family, kwargs in (('cartpole', {}), ('mountain_car', {})):
